@@ -1,0 +1,191 @@
+/*
+ * pointslam_hip.h -- C ABI of libpointslam_hip.so: the MI355X (gfx950) render /
+ * optimise hot path of Point-SLAM.
+ *
+ * The reference (eriksandstroem/Point-SLAM, /root/reference) has no native
+ * plugin API; its narrowest seams are Python method signatures.
+ * Every entry point below names the reference interface it stands in for
+ * (file:line relative to the reference tree).  The Python mirrors of those
+ * interfaces live in point_slam_amd/{renderer,neural_point}.py and call ONLY
+ * these functions (through ctypes).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no exceptions cross the boundary.
+ *  - every function returns 0 on success, a negative psl_status on failure;
+ *    psl_last_error() returns a thread-local message.
+ *  - all array arguments are BORROWED DEVICE pointers (owned by the caller,
+ *    e.g. torch) valid until the work enqueued on `stream` has completed,
+ *    unless the parameter is documented as host memory.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and
+ *    nothing synchronises the device except the functions documented to.
+ *  - one psl_ctx per (process, device); a ctx is not thread-safe.
+ *  - fixed architecture constants (asserted by psl_create): S = 5 samples per
+ *    ray, K = 8 neighbours, C = 32 feature channels (configs/point_slam.yaml:10,95,107).
+ */
+#ifndef POINTSLAM_HIP_H
+#define POINTSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psl_ctx psl_ctx;
+
+enum psl_status {
+  PSL_OK = 0,
+  PSL_ERR_ARG = -1,      /* bad argument */
+  PSL_ERR_HIP = -2,      /* a HIP runtime call failed */
+  PSL_ERR_CAPACITY = -3, /* point capacity exhausted */
+  PSL_ERR_STATE = -4,    /* call order (e.g. render before index build) */
+  PSL_ERR_UNSUPPORTED = -5
+};
+
+/* Hot-path subset of the reference YAML (configs/point_slam.yaml). */
+typedef struct psl_config {
+  int32_t n_surface;        /* rendering.N_surface (must be 5)           :95  */
+  int32_t nn_num;           /* pointcloud.nn_num (must be 8)             :107 */
+  int32_t c_dim;            /* model.c_dim (must be 32)                  :10  */
+  int32_t min_nn_num;       /* pointcloud.min_nn_num                     :108 */
+  float near_end_surface;   /* rendering.near_end_surface                :97  */
+  float far_end_surface;    /* rendering.far_end_surface                 :98  */
+  float radius_query;       /* pointcloud.radius_query (fixed-radius mode):112 */
+  float max_query_radius;   /* largest radius any query may use; sets the grid cell size.
+                               dynamic mode: radius_add_max*radius_query_ratio (:113,115) */
+  int32_t encode_rel_pos;   /* model.encode_rel_pos_in_col               :13  */
+  int32_t max_points;       /* position capacity of this ctx (points)         */
+} psl_config;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+int psl_create(int device, const psl_config* cfg, psl_ctx** out);
+void psl_destroy(psl_ctx* ctx);
+const char* psl_last_error(void);
+int psl_abi_version(void);
+
+/* ---- decoder parameter blob ----------------------------------------------
+ * The decoders (src/conv_onet/models/decoder.py:452-475, POINT) are handed over
+ * as ONE flat fp32 "master" blob: the tensors named by psl_param_entry(),
+ * each in its torch layout ([out][in] row-major), concatenated in table
+ * order.  Entries [0, psl_param_color_count()) form the colour-decoder
+ * group (trainable in mapping), the rest the geometry-decoder group.
+ * Gradients are returned in the same layout.  The fixed, non-persistent colour
+ * Fourier matrix (decoder.py:305-306, `_B` [3][20]) is a separate argument. */
+int psl_param_count(void);
+int psl_param_color_count(void);
+/* name: reference state_dict key; rows/cols: torch shape (cols=1 for biases); offset in floats */
+int psl_param_entry(int i, char* name_out, int name_cap, int* rows, int* cols, int* offset);
+int psl_param_master_floats(void);
+
+/* ---- neural point cloud: positions + spatial index -------------------------
+ * Replaces NeuralPointCloud._cloud_pos (a Python list, src/neural_point.py:29,147)
+ * and the FAISS IVF index (src/neural_point.py:37-41).  Features stay with the
+ * caller (torch tensors), exactly as in the reference. */
+int psl_points_reset(psl_ctx* ctx);
+/* raw append of n positions [n][3] f32 (no dedupe); index becomes stale */
+int psl_points_append(psl_ctx* ctx, const float* pos, int n, void* stream);
+/* number of points (host value; exact after psl_sync or any *_sync call) */
+int psl_points_count(psl_ctx* ctx);
+/* copy positions [count][3] f32 to a device buffer (checkpoint compatibility, src/utils/Logger.py:22-40) */
+int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_points, void* stream);
+/* (re)build the uniform-grid index over all points: index.train/index.add (src/neural_point.py:161-164) */
+int psl_index_build(psl_ctx* ctx, void* stream);
+
+/* find_neighbors_faiss (src/neural_point.py:169-215): EXACT search restricted to the query
+ * radius.  D[nq][8] f32 squared distances ascending, I[nq][8] int64, cnt[nq] int32 = #(D < r^2).
+ * Slots farther than the radius hold D=+inf, I=-1 (they carry weight 0 everywhere in the
+ * reference, decoder.py:157,367).  r_per_query may be NULL -> r_scalar for all. */
+int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq,
+            float* D_out, int64_t* I_out, int32_t* cnt_out, void* stream);
+
+/* add_neural_points (src/neural_point.py:91-167): for rays with depth>0 compute the surface
+ * point o+d*depth, keep locations with ZERO existing points closer than the radius
+ * (dedupe against the index as built, not against this batch), append n_add=3 points per
+ * kept location at linspace(near,far,3)*depth.  keep_out[n] uint8 (0 for depth<=0 rays).
+ * Synchronises `stream` and returns the number of kept LOCATIONS in *n_kept_host.
+ * The index is stale afterwards (call psl_index_build). */
+int psl_add_points_sync(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth,
+                        const float* radius_per_ray, float r_scalar, int n, float near_end, float far_end,
+                        uint8_t* keep_out, int* n_kept_host, void* stream);
+
+/* ---- render forward / backward ---------------------------------------------
+ * Renderer.render_batch_ray (src/utils/Renderer.py:77-202) for rays with sensor depth > 0,
+ * through POINT.forward (decoder.py:476-518) and raw2outputs_nerf_color (src/common.py:298-336). */
+enum psl_render_flags {
+  PSL_STAGE_COLOR = 1,      /* stage == 'color' (else 'geometry': rgb = 0)            */
+  PSL_PTS_GRAD = 2,         /* is_tracker: d/d(rays) through D, embeddings, rel-pos   */
+  PSL_PARAM_GRAD = 4,       /* produce colour-decoder parameter gradients             */
+  PSL_FEAT_GRAD = 8,        /* produce feature gradients                              */
+  PSL_NO_SIGMOID = 16,      /* encode_exposure without exposure_feat (decoder.py:439-446) */
+  PSL_HAS_AFFINE = 32       /* exposure affine given (decoder.py:432-438)             */
+};
+
+/* floats of scratch the caller must provide to fwd and keep alive (unchanged) until bwd */
+int64_t psl_render_ws_floats(int n_rays, int flags);
+
+typedef struct psl_render_args {
+  int32_t n_rays;
+  int32_t flags;                 /* psl_render_flags */
+  float sigmoid_coef;            /* Renderer.sigmoid_coefficient (Tracker.py:36, Mapper.py:45) */
+  const float* rays_o;           /* [R][3] */
+  const float* rays_d;           /* [R][3] unnormalised */
+  const float* gt_depth;         /* [R] > 0 */
+  const float* r_query;          /* [R] per-ray query radius or NULL (fixed radius) */
+  const float* geo_feats;        /* [N][32] */
+  const float* col_feats;        /* [N][32] */
+  const float* params;           /* master blob, psl_param_master_floats() */
+  const float* col_embed_B;      /* [3][20] fixed colour Fourier matrix */
+  const float* fallback_geo;     /* [32] random vector for samples with < min_nn neighbours (decoder.py:170) */
+  const float* fallback_col;     /* [32] (decoder.py:387) */
+  const float* exposure_affine;  /* [12] (rot 3x3 row-major, trans) or NULL */
+  float* ws;                     /* scratch, psl_render_ws_floats() floats */
+  /* outputs */
+  float* depth;                  /* [R] */
+  float* var;                    /* [R] */
+  float* rgb;                    /* [R][3] */
+  uint8_t* valid_ray;            /* [R] valid_ray_mask (decoder.py:200-201) */
+} psl_render_args;
+
+int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream);
+
+typedef struct psl_render_grads {
+  const float* g_depth;          /* [R] cotangents */
+  const float* g_var;            /* [R] or NULL */
+  const float* g_rgb;            /* [R][3] or NULL */
+  /* outputs (may be NULL when the matching flag is off). Feature gradients are ACCUMULATED
+   * (+=) with atomics into caller-zeroed buffers: row i of g_*_feats is feature row
+   * feat_row_map[i_point] (or i_point itself when feat_row_map is NULL; -1 = not trainable). */
+  float* g_geo_feats;
+  float* g_col_feats;
+  const int32_t* feat_row_map;   /* [N] or NULL */
+  float* g_params;               /* master layout, OVERWRITTEN (colour group; geo group zeroed) */
+  float* g_rays_o;               /* [R][3] overwritten */
+  float* g_rays_d;               /* [R][3] overwritten */
+  float* g_exposure_affine;      /* [12] overwritten */
+} psl_render_grads;
+
+int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, void* stream);
+
+/* raw2outputs_nerf_color alone (src/common.py:298-336), for unit parity: raw [R][5][4], z [R][5] */
+int psl_composite_fwd(const float* raw, const float* z, int n_rays, float coef, float* depth, float* var,
+                      float* rgb, float* weights, void* stream);
+
+/* ---- fused optimiser step (torch.optim.Adam defaults; Mapper.py:394-402,556) ------
+ * p,g,m,v [n]; step is the 1-based step count of this group. g is zeroed afterwards when zero_grad != 0. */
+int psl_adam_step(float* p, float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                  float beta2, float eps, int zero_grad, void* stream);
+/* same over rows of a [N][32] feature matrix selected by rows[n_rows]; g,m,v are compact [n_rows][32] */
+int psl_adam_step_rows(float* feats, const int32_t* rows, float* g, float* m, float* v, int n_rows, int step,
+                       float lr, float beta1, float beta2, float eps, int zero_grad, void* stream);
+
+/* ---- timing helpers for the bench harness ---------------------------------- */
+int psl_sync(psl_ctx* ctx, void* stream);
+/* last kernel-time breakdown collected when profiling is enabled (ms per kernel class) */
+int psl_profile_enable(psl_ctx* ctx, int on);
+int psl_profile_read(psl_ctx* ctx, float* ms_out, int cap, int* n_out);
+const char* psl_profile_name(int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTSLAM_HIP_H */

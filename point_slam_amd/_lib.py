@@ -1,0 +1,114 @@
+"""ctypes binding of libpointslam_hip.so (include/pointslam_hip.h).
+
+The library is the product; there is NO Python/CPU fallback: if the shared
+object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpointslam_hip.so")
+
+
+class PslError(RuntimeError):
+    pass
+
+
+class psl_config(C.Structure):
+    _fields_ = [("n_surface", C.c_int32), ("nn_num", C.c_int32), ("c_dim", C.c_int32), ("min_nn_num", C.c_int32),
+                ("near_end_surface", C.c_float), ("far_end_surface", C.c_float), ("radius_query", C.c_float),
+                ("max_query_radius", C.c_float), ("encode_rel_pos", C.c_int32), ("max_points", C.c_int32)]
+
+
+class psl_render_args(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("flags", C.c_int32), ("sigmoid_coef", C.c_float),
+                ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("gt_depth", C.c_void_p), ("r_query", C.c_void_p),
+                ("geo_feats", C.c_void_p), ("col_feats", C.c_void_p), ("params", C.c_void_p),
+                ("col_embed_B", C.c_void_p), ("fallback_geo", C.c_void_p), ("fallback_col", C.c_void_p),
+                ("exposure_affine", C.c_void_p), ("ws", C.c_void_p),
+                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("valid_ray", C.c_void_p)]
+
+
+class psl_render_grads(C.Structure):
+    _fields_ = [("g_depth", C.c_void_p), ("g_var", C.c_void_p), ("g_rgb", C.c_void_p),
+                ("g_geo_feats", C.c_void_p), ("g_col_feats", C.c_void_p), ("feat_row_map", C.c_void_p),
+                ("g_params", C.c_void_p), ("g_rays_o", C.c_void_p), ("g_rays_d", C.c_void_p),
+                ("g_exposure_affine", C.c_void_p)]
+
+
+# psl_render_flags
+STAGE_COLOR, PTS_GRAD, PARAM_GRAD, FEAT_GRAD, NO_SIGMOID, HAS_AFFINE = 1, 2, 4, 8, 16, 32
+
+_SIGS = {
+    "psl_create": (C.c_int, [C.c_int, C.POINTER(psl_config), C.POINTER(C.c_void_p)]),
+    "psl_destroy": (None, [C.c_void_p]),
+    "psl_last_error": (C.c_char_p, []),
+    "psl_abi_version": (C.c_int, []),
+    "psl_param_count": (C.c_int, []),
+    "psl_param_color_count": (C.c_int, []),
+    "psl_param_entry": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
+    "psl_param_master_floats": (C.c_int, []),
+    "psl_points_reset": (C.c_int, [C.c_void_p]),
+    "psl_points_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "psl_points_count": (C.c_int, [C.c_void_p]),
+    "psl_points_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "psl_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_void_p]),
+    "psl_add_points_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
+                                      C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "psl_render_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
+    "psl_render_fwd": (C.c_int, [C.c_void_p, C.POINTER(psl_render_args), C.c_void_p]),
+    "psl_render_bwd": (C.c_int, [C.c_void_p, C.POINTER(psl_render_args), C.POINTER(psl_render_grads), C.c_void_p]),
+    "psl_composite_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "psl_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "psl_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "psl_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "psl_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
+    "psl_profile_name": (C.c_char_p, [C.c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises PslError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PslError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc < 0:
+        msg = lib().psl_last_error().decode()
+        raise PslError(f"{what or 'psl call'} failed ({rc}): {msg}")
+    return rc
+
+
+def ptr(t):
+    """data_ptr of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,257 @@
+// C ABI entry points: context lifecycle, parameter table, render forward/backward orchestration.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+#include "psl_decode.h"
+
+namespace psl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_decode_fwd(const DecodeArgs& a, hipStream_t s);
+int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s);
+int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
+                         const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
+                         unsigned char* valid, float* cw, float* ray_aux, hipStream_t s);
+int launch_composite_bwd(const float4* raw, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
+                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s);
+int launch_ray_grad(const float4* dp, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
+                    float* g_d, hipStream_t s);
+
+static inline int64_t al4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+RenderWs carve_ws(float* base, int n_rays, int flags) {
+  RenderWs w;
+  memset(&w, 0, sizeof(w));
+  w.P = n_rays * S;
+  w.Ppad = ((w.P + TILE - 1) / TILE) * TILE;
+  const int64_t Pp = w.Ppad;
+  const bool grad = flags & (PSL_PTS_GRAD | PSL_PARAM_GRAD | PSL_FEAT_GRAD);
+  const bool color = flags & PSL_STAGE_COLOR;
+  const bool relpos = flags & 0x10000;
+  const bool pgrad = flags & PSL_PARAM_GRAD;
+  int64_t off = 0;
+  auto take = [&](int64_t n) -> float* { float* p = base ? base + off : nullptr; off += al4(n); return p; };
+  w.I = (int*)take(Pp * K);
+  w.cnt = (int*)take(Pp);
+  w.raw = take(Pp * 4);
+  w.w = take(Pp * K);
+  w.cg = take(Pp * C);
+  w.cc = take(Pp * C);
+  w.out3 = take(Pp * 4);
+  w.cw = take((int64_t)n_rays * S);
+  w.ray_aux = take((int64_t)n_rays * 4);
+  if (grad) {
+    w.g_y = take(Pp * 5 * HG);
+    w.d_raw = take(Pp * 4);
+    w.dp = take(Pp * 4);
+    if (color) {
+      w.c_y = take(Pp * 5 * HC);
+      w.c_hin = take(Pp * 5 * HC);
+      w.c_emb = take(Pp * EC);
+      w.d_out3 = take(Pp * 4);
+      if (relpos) {
+        w.n_h1 = take(Pp * K * HC);
+        w.n_out = take(Pp * K * C);
+        w.n_x = take(Pp * K * NX);
+      }
+      if (pgrad) {
+        w.c_dz = take(Pp * 5 * HC);
+        w.c_g = take(Pp * 5 * HC);
+        if (relpos) { w.n_dz1 = take(Pp * K * HC); w.n_dnf = take(Pp * K * C); }
+      }
+    }
+  }
+  w.total = off;
+  return w;
+}
+
+static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& d) {
+  memset(&d, 0, sizeof(d));
+  int flags = a->flags;
+  if (ctx->cfg.encode_rel_pos) flags |= 0x10000;
+  d.P = a->n_rays * S;
+  d.n_rays = a->n_rays;
+  d.flags = flags;
+  d.min_nn = ctx->cfg.min_nn_num;
+  d.near_s = ctx->cfg.near_end_surface;
+  d.far_s = ctx->cfg.far_end_surface;
+  d.r2_fixed = (float)((double)ctx->cfg.radius_query * (double)ctx->cfg.radius_query);
+  d.rays_o = a->rays_o; d.rays_d = a->rays_d; d.depth = a->gt_depth; d.r_query = a->r_query;
+  d.pos = ctx->pos;
+  d.geo_feats = a->geo_feats; d.col_feats = a->col_feats;
+  d.master = a->params; d.wt = ctx->wt; d.Bcol = a->col_embed_B;
+  d.fb_geo = a->fallback_geo; d.fb_col = a->fallback_col; d.affine = a->exposure_affine;
+  d.ws = carve_ws(a->ws, a->n_rays, flags);
+  return PSL_OK;
+}
+
+static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char* who) {
+  if (!ctx || !a) { set_error("%s: null argument", who); return PSL_ERR_ARG; }
+  if (a->n_rays < 0) { set_error("%s: n_rays < 0", who); return PSL_ERR_ARG; }
+  if (!a->rays_o || !a->rays_d || !a->gt_depth || !a->geo_feats || !a->params || !a->fallback_geo || !a->ws) {
+    set_error("%s: missing required pointer", who); return PSL_ERR_ARG;
+  }
+  if ((a->flags & PSL_STAGE_COLOR) && (!a->col_feats || !a->col_embed_B || !a->fallback_col)) {
+    set_error("%s: colour stage needs col_feats, col_embed_B, fallback_col", who); return PSL_ERR_ARG;
+  }
+  if ((a->flags & PSL_HAS_AFFINE) && !a->exposure_affine) { set_error("%s: PSL_HAS_AFFINE without affine", who); return PSL_ERR_ARG; }
+  if (ctx->index_points != ctx->n_points) { set_error("%s: index is stale, call psl_index_build", who); return PSL_ERR_STATE; }
+  return PSL_OK;
+}
+
+}  // namespace psl
+
+using namespace psl;
+
+extern "C" const char* psl_last_error(void) { return g_err; }
+extern "C" int psl_abi_version(void) { return 1; }
+
+extern "C" int psl_param_count(void) { return kNumParams; }
+extern "C" int psl_param_color_count(void) { return kNumColorParams; }
+extern "C" int psl_param_master_floats(void) { return kMasterFloats; }
+extern "C" int psl_param_entry(int i, char* name_out, int name_cap, int* rows, int* cols, int* offset) {
+  if (i < 0 || i >= kNumParams) { set_error("psl_param_entry: index %d out of range", i); return PSL_ERR_ARG; }
+  if (name_out && name_cap > 0) { strncpy(name_out, kParams[i].name, name_cap - 1); name_out[name_cap - 1] = 0; }
+  if (rows) *rows = kParams[i].rows;
+  if (cols) *cols = kParams[i].cols;
+  if (offset) *offset = poff(i);
+  return PSL_OK;
+}
+
+extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
+  if (!cfg || !out) { set_error("psl_create: null argument"); return PSL_ERR_ARG; }
+  if (cfg->n_surface != S || cfg->nn_num != K || cfg->c_dim != C) {
+    set_error("psl_create: this build is specialised for N_surface=5, nn_num=8, c_dim=32 (got %d,%d,%d)",
+              cfg->n_surface, cfg->nn_num, cfg->c_dim);
+    return PSL_ERR_UNSUPPORTED;
+  }
+  if (cfg->max_points <= 0 || cfg->max_query_radius <= 0.f) { set_error("psl_create: bad capacity/radius"); return PSL_ERR_ARG; }
+  PSL_HIP(hipSetDevice(device));
+  psl_ctx* c = new psl_ctx();
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  c->cfg = *cfg;
+  c->index_points = -1;
+  size_t np = (size_t)cfg->max_points;
+  PSL_HIP(hipMalloc(&c->pos, sizeof(float4) * np));
+  PSL_HIP(hipMalloc(&c->spos, sizeof(float4) * np));
+  PSL_HIP(hipMalloc(&c->cell_of, sizeof(int) * np));
+  PSL_HIP(hipMalloc(&c->cell_start, sizeof(int) * (kMaxCells + 1)));
+  PSL_HIP(hipMalloc(&c->cell_fill, sizeof(int) * kMaxCells));
+  PSL_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * 4096));
+  PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8));
+  PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta)));
+  PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats));
+  PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4));
+  for (int i = 0; i < 2 * PROF_N; ++i) PSL_HIP(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return PSL_OK;
+}
+
+extern "C" void psl_destroy(psl_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
+  (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
+  (void)hipFree(c->wt); (void)hipFree(c->d_counter);
+  if (c->dw_slabs) (void)hipFree(c->dw_slabs);
+  if (c->scan_flags) (void)hipFree(c->scan_flags);
+  for (int i = 0; i < 2 * PROF_N; ++i) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+}
+
+extern "C" int64_t psl_render_ws_floats(int n_rays, int flags) {
+  if (n_rays < 0) return PSL_ERR_ARG;
+  // size for the worst case of the rel-pos bit (the ctx decides it at run time)
+  return carve_ws(nullptr, n_rays, flags | 0x10000).total;
+}
+
+extern "C" int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream) {
+  int rc = check_render_args(ctx, a, "psl_render_fwd");
+  if (rc) return rc;
+  if (!a->depth || !a->var || !a->rgb) { set_error("psl_render_fwd: missing output pointer"); return PSL_ERR_ARG; }
+  if (a->n_rays == 0) return PSL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DecodeArgs d;
+  fill_decode_args(ctx, a, d);
+  { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
+  { ProfScope ps(ctx, PROF_KNN, s);
+    rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
+    if (rc) return rc; }
+  { ProfScope ps(ctx, PROF_DECODE_FWD, s); rc = launch_decode_fwd(d, s); if (rc) return rc; }
+  { ProfScope ps(ctx, PROF_COMPOSITE, s);
+    rc = launch_composite_fwd((const float4*)d.ws.raw, nullptr, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
+                              a->n_rays, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, d.ws.cw,
+                              d.ws.ray_aux, s);
+    if (rc) return rc; }
+  return PSL_OK;
+}
+
+extern "C" int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, void* stream) {
+  int rc = check_render_args(ctx, a, "psl_render_bwd");
+  if (rc) return rc;
+  if (!g || !g->g_depth) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
+  if (!(a->flags & (PSL_PTS_GRAD | PSL_PARAM_GRAD | PSL_FEAT_GRAD))) {
+    set_error("psl_render_bwd: forward was run without any gradient flag"); return PSL_ERR_STATE;
+  }
+  if (a->n_rays == 0) return PSL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DecodeArgs d;
+  fill_decode_args(ctx, a, d);
+  { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s);
+    rc = launch_composite_bwd((const float4*)d.ws.raw, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
+                              g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, s);
+    if (rc) return rc; }
+  rc = launch_decode_bwd(ctx, d, *g, s);
+  if (rc) return rc;
+  if ((a->flags & PSL_PTS_GRAD) && (g->g_rays_o || g->g_rays_d)) {
+    ProfScope ps(ctx, PROF_MISC, s);
+    rc = launch_ray_grad((const float4*)d.ws.dp, a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
+    if (rc) return rc;
+  }
+  return PSL_OK;
+}
+
+extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
+  if (!ctx) return PSL_ERR_ARG;
+  PSL_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return PSL_OK;
+}
+
+static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
+                                         "misc"};
+extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
+
+extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
+  if (!ctx) return PSL_ERR_ARG;
+  ctx->prof_on = on;
+  memset(ctx->prof_used, 0, sizeof(ctx->prof_used));
+  return PSL_OK;
+}
+
+// elapsed ms of the LAST launch of each kernel class (synchronises the events)
+extern "C" int psl_profile_read(psl_ctx* ctx, float* ms_out, int cap, int* n_out) {
+  if (!ctx || !ms_out) return PSL_ERR_ARG;
+  int n = std::min(cap, (int)PROF_N);
+  for (int i = 0; i < n; ++i) {
+    ms_out[i] = 0.f;
+    if (ctx->prof_used[i]) {
+      PSL_HIP(hipEventSynchronize(ctx->ev[2 * i + 1]));
+      float ms = 0.f;
+      PSL_HIP(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+      ms_out[i] = ms;
+    }
+  }
+  if (n_out) *n_out = n;
+  return PSL_OK;
+}

@@ -1,0 +1,226 @@
+// Internal definitions shared by the HIP translation units of libpointslam_hip.so.
+// gfx950 only: 64-wide wavefronts, f32 MFMA 16x16x4, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pointslam_hip.h"
+
+namespace psl {
+
+// ---------------------------------------------------------------- constants
+constexpr int S = 5;    // samples per ray        (configs/point_slam.yaml:95)
+constexpr int K = 8;    // neighbours per sample   (configs/point_slam.yaml:107)
+constexpr int C = 32;   // feature channels        (configs/point_slam.yaml:10)
+constexpr int HG = 32;  // geometry decoder hidden (decoder.py:468-470)
+constexpr int HC = 128; // colour decoder hidden   (decoder.py:471-474)
+constexpr int EG = 93;  // geometry Fourier size (sin only)   (decoder.py:99-104)
+constexpr int EGP = 96; // ... padded to a multiple of 4 for the MFMA k-step
+constexpr int ECF = 20; // colour Fourier frequencies (sin+cos -> 40) (decoder.py:302-306)
+constexpr int EC = 40;
+constexpr int ERF = 10; // rel-pos Fourier frequencies (sin+cos -> 20) (decoder.py:314-315)
+constexpr int ER = 20;
+constexpr int NX = ER + C;  // neighbour-MLP input width 52 (decoder.py:316-317)
+constexpr int TILE = 16;    // samples per workgroup tile (= M of mfma_f32_16x16x4f32)
+constexpr int WG = 512;     // threads per decode workgroup (8 waves)
+constexpr float TWO_PI = 6.2831855f;  // float32(2*pi), decoder.py:33
+
+// ------------------------------------------------ master parameter blob layout
+// torch layouts ([out][in]) concatenated; colour group first (see include/pointslam_hip.h)
+struct PEntry { const char* name; int rows, cols; };
+constexpr PEntry kParams[] = {
+    {"color_decoder.fc_c.0.weight", HC, C}, {"color_decoder.fc_c.0.bias", HC, 1},
+    {"color_decoder.fc_c.1.weight", HC, C}, {"color_decoder.fc_c.1.bias", HC, 1},
+    {"color_decoder.fc_c.2.weight", HC, C}, {"color_decoder.fc_c.2.bias", HC, 1},
+    {"color_decoder.fc_c.3.weight", HC, C}, {"color_decoder.fc_c.3.bias", HC, 1},
+    {"color_decoder.fc_c.4.weight", HC, C}, {"color_decoder.fc_c.4.bias", HC, 1},
+    {"color_decoder.embedder_rel_pos._B", 3, ERF},
+    {"color_decoder.mlp_col_neighbor.linear1.weight", HC, NX}, {"color_decoder.mlp_col_neighbor.linear1.bias", HC, 1},
+    {"color_decoder.mlp_col_neighbor.linear2.weight", C, HC}, {"color_decoder.mlp_col_neighbor.linear2.bias", C, 1},
+    {"color_decoder.pts_linears.0.weight", HC, EC}, {"color_decoder.pts_linears.0.bias", HC, 1},
+    {"color_decoder.pts_linears.1.weight", HC, HC}, {"color_decoder.pts_linears.1.bias", HC, 1},
+    {"color_decoder.pts_linears.2.weight", HC, HC}, {"color_decoder.pts_linears.2.bias", HC, 1},
+    {"color_decoder.pts_linears.3.weight", HC, EC + HC}, {"color_decoder.pts_linears.3.bias", HC, 1},
+    {"color_decoder.pts_linears.4.weight", HC, HC}, {"color_decoder.pts_linears.4.bias", HC, 1},
+    {"color_decoder.output_linear.weight", 3, HC}, {"color_decoder.output_linear.bias", 3, 1},
+    // ---- geometry group
+    {"geo_decoder.fc_c.0.weight", HG, C}, {"geo_decoder.fc_c.0.bias", HG, 1},
+    {"geo_decoder.fc_c.1.weight", HG, C}, {"geo_decoder.fc_c.1.bias", HG, 1},
+    {"geo_decoder.fc_c.2.weight", HG, C}, {"geo_decoder.fc_c.2.bias", HG, 1},
+    {"geo_decoder.fc_c.3.weight", HG, C}, {"geo_decoder.fc_c.3.bias", HG, 1},
+    {"geo_decoder.fc_c.4.weight", HG, C}, {"geo_decoder.fc_c.4.bias", HG, 1},
+    {"geo_decoder.embedder._B", 3, EG},
+    {"geo_decoder.pts_linears.0.weight", HG, EG}, {"geo_decoder.pts_linears.0.bias", HG, 1},
+    {"geo_decoder.pts_linears.1.weight", HG, HG}, {"geo_decoder.pts_linears.1.bias", HG, 1},
+    {"geo_decoder.pts_linears.2.weight", HG, HG}, {"geo_decoder.pts_linears.2.bias", HG, 1},
+    {"geo_decoder.pts_linears.3.weight", HG, EG + HG}, {"geo_decoder.pts_linears.3.bias", HG, 1},
+    {"geo_decoder.pts_linears.4.weight", HG, HG}, {"geo_decoder.pts_linears.4.bias", HG, 1},
+    {"geo_decoder.output_linear.weight", 1, HG}, {"geo_decoder.output_linear.bias", 1, 1},
+};
+constexpr int kNumParams = sizeof(kParams) / sizeof(kParams[0]);
+constexpr int kNumColorParams = 27;
+
+constexpr int poff(int i) {  // master offset (floats) of entry i
+  int o = 0;
+  for (int j = 0; j < i; ++j) o += kParams[j].rows * kParams[j].cols;
+  return o;
+}
+constexpr int kMasterFloats = poff(kNumParams);
+constexpr int kColorFloats = poff(kNumColorParams);
+
+// indices into kParams
+constexpr int PI_C_FCC = 0;    // + 2*i (weight), +2*i+1 (bias)
+constexpr int PI_C_BREL = 10;
+constexpr int PI_C_N1 = 11, PI_C_N2 = 13;
+constexpr int PI_C_L = 15;     // + 2*i
+constexpr int PI_C_OUT = 25;
+constexpr int PI_G_FCC = 27;
+constexpr int PI_G_B = 37;
+constexpr int PI_G_L = 38;
+constexpr int PI_G_OUT = 48;
+
+// --------------------------------------------- forward ("wt") layout: [Kpad][N]
+// Every linear layer used as an MFMA B operand in the FORWARD pass is kept
+// transposed ([in][out], in padded to a multiple of 4, zero rows) so that a
+// wave's B fragment (4 k-rows x 16 columns) is four 64-byte segments.
+struct WtDesc { int pi; int Kin, N, Kpad, split, gap; };
+// split/gap: input index k maps to padded row (k < split ? k : k + gap)
+constexpr WtDesc kWt[] = {
+    {PI_C_FCC + 0, C, HC, C, C, 0}, {PI_C_FCC + 2, C, HC, C, C, 0}, {PI_C_FCC + 4, C, HC, C, C, 0},
+    {PI_C_FCC + 6, C, HC, C, C, 0}, {PI_C_FCC + 8, C, HC, C, C, 0},
+    {PI_C_N1, NX, HC, NX, NX, 0}, {PI_C_N2, HC, C, HC, HC, 0},
+    {PI_C_L + 0, EC, HC, EC, EC, 0}, {PI_C_L + 2, HC, HC, HC, HC, 0}, {PI_C_L + 4, HC, HC, HC, HC, 0},
+    {PI_C_L + 6, EC + HC, HC, EC + HC, EC + HC, 0}, {PI_C_L + 8, HC, HC, HC, HC, 0},
+    {PI_G_FCC + 0, C, HG, C, C, 0}, {PI_G_FCC + 2, C, HG, C, C, 0}, {PI_G_FCC + 4, C, HG, C, C, 0},
+    {PI_G_FCC + 6, C, HG, C, C, 0}, {PI_G_FCC + 8, C, HG, C, C, 0},
+    {PI_G_L + 0, EG, HG, EGP, EG, 0}, {PI_G_L + 2, HG, HG, HG, HG, 0}, {PI_G_L + 4, HG, HG, HG, HG, 0},
+    {PI_G_L + 6, EG + HG, HG, EGP + HG, EG, EGP - EG}, {PI_G_L + 8, HG, HG, HG, HG, 0},
+};
+constexpr int kNumWt = sizeof(kWt) / sizeof(kWt[0]);
+constexpr int WT_C_FCC = 0, WT_C_N1 = 5, WT_C_N2 = 6, WT_C_L = 7, WT_G_FCC = 12, WT_G_L = 17;
+constexpr int wtoff(int i) {
+  int o = 0;
+  for (int j = 0; j < i; ++j) o += kWt[j].Kpad * kWt[j].N;
+  return o;
+}
+constexpr int kWtFloats = wtoff(kNumWt);
+
+// ---------------------------------------------------------- grid (spatial index)
+constexpr int kMaxCells = 1 << 22;
+struct GridMeta {      // lives in device memory; written by k_grid_meta
+  float ox, oy, oz;    // origin (min corner)
+  float inv_cell;      // 1 / cell size
+  float cell;
+  int nx, ny, nz;
+  int ncells;
+  int npts;
+};
+
+// --------------------------------------------------------------------- context
+enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BWD, PROF_DECODE_BWD, PROF_DW,
+                PROF_MISC, PROF_N };
+
+}  // namespace psl
+
+struct psl_ctx {
+  int device;
+  psl_config cfg;
+  // positions, original (append) order, float4 {x,y,z,0}
+  float4* pos;
+  int n_points;          // host mirror
+  int index_points;      // number of points covered by the current index (-1: none)
+  // grid index
+  psl::GridMeta* meta;   // device
+  float4* spos;          // positions sorted by cell; .w = original index (int bits)
+  int* cell_of;          // [max_points]
+  int* cell_start;       // [kMaxCells + 1] exclusive prefix sums
+  int* cell_fill;        // [kMaxCells]
+  int* scan_tmp;         // block sums for the scan
+  int* bounds;           // 6 ints: ordered-int min/max
+  // forward-layout weights (rebuilt per render call from the master blob)
+  float* wt;
+  // dW partial slabs
+  float* dw_slabs;
+  int dw_slab_cap;       // number of slabs allocated
+  // small device scratch
+  int* d_counter;
+  int* scan_flags;       // for add_points compaction
+  int scan_flags_cap;
+  // profiling
+  int prof_on;
+  hipEvent_t ev[2 * psl::PROF_N];
+  float prof_ms[psl::PROF_N];
+  int prof_used[psl::PROF_N];
+};
+
+namespace psl {
+
+void set_error(const char* fmt, ...);
+
+#define PSL_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e__ = (call);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      psl::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return PSL_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+#define PSL_LAUNCH_CHECK()                                                             \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      psl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+      return PSL_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+struct ProfScope {  // brackets a kernel class with HIP events on the launch stream when profiling is on
+  psl_ctx* c; int slot; hipStream_t s;
+  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) {
+    if (c && c->prof_on) (void)hipEventRecord(c->ev[2 * slot], s);
+  }
+  ~ProfScope() {
+    if (c && c->prof_on) { (void)hipEventRecord(c->ev[2 * slot + 1], s); c->prof_used[slot] = 1; }
+  }
+};
+
+// ---- internal launchers (defined in the .hip files) -------------------------
+int grid_build(psl_ctx* ctx, hipStream_t s);
+int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* r_query,
+             int n_rays, int* I_out, int* cnt_out, hipStream_t s);
+int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
+                int64_t* I_out, int* cnt_out, hipStream_t s);
+int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);
+
+// workspace carving for render fwd/bwd (all sizes in floats, P = 5 * n_rays padded to TILE)
+struct RenderWs {
+  int P, Ppad;
+  int* I;            // [Ppad][8]
+  int* cnt;          // [Ppad]
+  float* raw;        // [Ppad][4]  rgb (post sigmoid/affine), occ (masked)
+  float* w;          // [Ppad][8]  normalised interpolation weights
+  float* cg;         // [Ppad][32]
+  float* cc;         // [Ppad][32]
+  float* g_y;        // [Ppad][5][32]   geo post-activation
+  float* c_y;        // [Ppad][5][128]  colour post-activation
+  float* c_hin;      // [Ppad][5][128]  colour layer inputs h_1..h_5 (after +fc_c)
+  float* c_emb;      // [Ppad][40]
+  float* out3;       // [Ppad][4] pre-affine colour logits
+  float* n_x;        // [Ppad][8][52]
+  float* n_h1;       // [Ppad][8][128]
+  float* n_out;      // [Ppad][8][32]
+  float* cw;         // [R][5] compositing weights
+  float* ray_aux;    // [R][4] depth, W(sum+eps), var, -
+  // backward-produced
+  float* d_raw;      // [Ppad][4]
+  float* c_dz;       // [Ppad][5][128]
+  float* c_g;        // [Ppad][5][128]
+  float* n_dz1;      // [Ppad][8][128]
+  float* n_dnf;      // [Ppad][8][32]
+  float* d_out3;     // [Ppad][4]
+  float* dp;         // [Ppad][4]
+  int64_t total;
+};
+RenderWs carve_ws(float* base, int n_rays, int flags);
+
+}  // namespace psl

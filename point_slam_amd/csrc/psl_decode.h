@@ -1,0 +1,70 @@
+// Shared between the decode forward / backward translation units.
+#pragma once
+#include "psl_common.h"
+#include "psl_device.h"
+
+namespace psl {
+
+struct DecodeArgs {
+  int P, n_rays, flags, min_nn;
+  float near_s, far_s, r2_fixed;
+  const float *rays_o, *rays_d, *depth, *r_query;
+  const float4* pos;
+  const float *geo_feats, *col_feats;
+  const float* master;   // torch-layout parameter blob
+  const float* wt;       // forward-layout weights
+  const float* Bcol;     // [3][20]
+  const float *fb_geo, *fb_col, *affine;
+  RenderWs ws;
+};
+
+// LDS strides (floats): even with ld/2 odd => the 16x4 A-fragment reads are bank-conflict free
+constexpr int LD_G = 130;   // geo X: [emb 96 | h 32]
+constexpr int LD_C = 170;   // colour X: [emb 40 | h 128]
+constexpr int LD_CF = 34;   // interpolated feature tiles [16][32]
+constexpr int LD_XN = 54;   // neighbour-MLP input [128][52]
+constexpr int LD_HN = 130;  // neighbour-MLP hidden, per wave [16][128]
+
+// master offsets (floats)
+constexpr int MO(int pi) { return poff(pi); }
+
+// per-sample geometry shared by fwd and bwd: sample position, squared radius
+struct SampleGeom { float x, y, z, r2, zval; int ray; };
+
+__device__ __forceinline__ SampleGeom sample_geom(const DecodeArgs& a, int p) {
+  SampleGeom g;
+  int ray = p / S, si = p - ray * S;
+  g.ray = ray;
+  float dep = a.depth[ray];
+  g.zval = sample_z(dep, si, a.near_s, a.far_s);
+  sample_point(a.rays_o[ray * 3], a.rays_o[ray * 3 + 1], a.rays_o[ray * 3 + 2], a.rays_d[ray * 3],
+               a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2], g.zval, g.x, g.y, g.z);
+  if (a.r_query) { float r = a.r_query[ray]; g.r2 = __fmul_rn(r, r); }
+  else g.r2 = a.r2_fixed;
+  return g;
+}
+
+// (2*pi*p) . B[:, f] -- the Fourier phase of decoder.py:33 (matmul of [.,3] by [3,F])
+__device__ __forceinline__ float fourier_phase(float x, float y, float z, const float* __restrict__ B, int F, int f) {
+  float x2 = __fmul_rn(TWO_PI, x), y2 = __fmul_rn(TWO_PI, y), z2 = __fmul_rn(TWO_PI, z);
+  return fmaf(z2, B[2 * F + f], fmaf(y2, B[F + f], __fmul_rn(x2, B[f])));
+}
+
+// NT output column tiles at once: the A fragment is read from LDS once per k-step
+template <int KDIM, int NT>
+__device__ __forceinline__ void gemm16_multi(const float* Xs, int ldx, const float* __restrict__ W, int ldw,
+                                             f32x4 (&acc)[NT]) {
+  const int lane = threadIdx.x & 63;
+  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
+  const float* wp = W + (size_t)(lane >> 4) * ldw + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < KDIM / 4; ++ks) {
+    float xa = xp[4 * ks];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(xa, wp[(size_t)(4 * ks) * ldw + 16 * t], acc[t]);
+  }
+}
+
+}  // namespace psl

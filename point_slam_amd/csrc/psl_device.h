@@ -1,0 +1,86 @@
+// Device helpers shared by the kernels.  Everything parity-critical is written with explicit
+// round-to-nearest mul/add intrinsics so that it reproduces torch's unfused fp32 op sequence
+// regardless of -ffp-contract (the library is built with -ffp-contract=off as well).
+#pragma once
+#include "psl_common.h"
+
+namespace psl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// squared distance exactly as torch.sum(torch.square(a-b), -1): ((dx*dx + dy*dy) + dz*dz)
+// (decoder.py:146-147 recompute; oracle.sqdist)
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// z_s = near*d*(1-t_s) + far*d*t_s, t = linspace(0,1,5)  (Renderer.py:134-141)
+__device__ __forceinline__ float sample_z(float depth, int s, float near_s, float far_s) {
+  float t = 0.25f * (float)s;
+  return __fadd_rn(__fmul_rn(__fmul_rn(near_s, depth), 1.0f - t), __fmul_rn(__fmul_rn(far_s, depth), t));
+}
+
+// pts = o + d*z : separate multiply then add (Renderer.py:172-173)
+__device__ __forceinline__ void sample_point(float ox, float oy, float oz, float dx, float dy, float dz, float z,
+                                             float& x, float& y, float& zz) {
+  x = __fadd_rn(ox, __fmul_rn(dx, z));
+  y = __fadd_rn(oy, __fmul_rn(dy, z));
+  zz = __fadd_rn(oz, __fmul_rn(dz, z));
+}
+
+// torch.nn.Softplus(beta=100, threshold=20): x if 100x > 20 else log1p(exp(100x))/100
+__device__ __forceinline__ float softplus100(float x) {
+  float bx = 100.0f * x;
+  return bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
+}
+// derivative of softplus100 expressed through its OUTPUT y: sigmoid(100 z) = 1 - exp(-100 y)
+__device__ __forceinline__ float softplus100_grad_from_out(float y) {
+  return (100.0f * y > 20.0f) ? 1.0f : 1.0f - expf(-100.0f * y);
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// acc(16 x 16 slice at column n0) += X[16][K] (LDS, row stride ldx) * W[K][N] (global, row stride ldw).
+// Lane l: A = X[l&15][4*ks + (l>>4)], B = W[4*ks + (l>>4)][n0 + (l&15)]; C/D: col = l&15, row = 4*(l>>4)+reg.
+// Two accumulator chains hide the 40-cycle dependent MFMA latency behind the 32-cycle issue interval.
+template <int KDIM>
+__device__ __forceinline__ f32x4 gemm16(const float* Xs, int ldx, const float* __restrict__ W, int ldw, int n0) {
+  static_assert(KDIM % 4 == 0, "K must be a multiple of 4");
+  const int lane = threadIdx.x & 63;
+  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
+  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NK = KDIM / 4;
+#pragma unroll 8
+  for (int ks = 0; ks + 1 < NK; ks += 2) {
+    float xa = xp[4 * ks], xb = xp[4 * ks + 4];
+    float wa = wp[(size_t)(4 * ks) * ldw], wb = wp[(size_t)(4 * ks + 4) * ldw];
+    a0 = mfma16(xa, wa, a0);
+    a1 = mfma16(xb, wb, a1);
+  }
+  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wp[(size_t)(4 * (NK - 1)) * ldw], a0);
+  return a0 + a1;
+}
+
+// store a C/D fragment to a row-major LDS/global tile: dst[row][n0 + col]
+__device__ __forceinline__ void frag_store(float* dst, int ld, int n0, f32x4 v) {
+  const int lane = threadIdx.x & 63;
+  float* p = dst + (4 * (lane >> 4)) * ld + n0 + (lane & 15);
+  p[0] = v[0]; p[ld] = v[1]; p[2 * ld] = v[2]; p[3 * ld] = v[3];
+}
+
+// wave-level sums
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// hardware float atomic add (no CAS loop)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+}  // namespace psl

@@ -1,0 +1,519 @@
+// Uniform-grid spatial index + exact radius-bounded 8-NN for gfx950.
+//
+// Replaces FAISS-GPU IndexIVFFlat as used at src/neural_point.py:37-41,161-164,193
+// (reference tree).  Design (MI355X-first, not a FAISS translation):
+//   * points are counting-sorted by grid cell (cell >= max query radius) into `spos`
+//     (float4: xyz + original index) so the candidates of an x-run of cells are ONE
+//     contiguous, coalesced 16 B/lane stream;
+//   * one 64-lane wavefront serves one ray (its 5 samples share most candidate cells) or one
+//     free query; lanes evaluate 64 candidates per step, survivors are found with a
+//     wave ballot and inserted into a wave-uniform sorted top-8 of 64-bit keys
+//     (distance bits << 32 | index): a single integer compare gives the oracle's
+//     (distance, lower-index-first) order, so results do not depend on scan order;
+//   * only candidates with d2 <= r2 are ever admitted: slots beyond the query radius are
+//     reported as (inf, -1) -- they carry weight 0 everywhere in the reference
+//     (decoder.py:157,367; neural_point.py:210-213).
+#include "psl_common.h"
+#include "psl_device.h"
+
+namespace psl {
+
+// ------------------------------------------------------------------ grid build
+__device__ __forceinline__ int f2ord(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_bounds_init(int* b) {
+  if (threadIdx.x < 3) b[threadIdx.x] = 0x7FFFFFFF;
+  else if (threadIdx.x < 6) b[threadIdx.x] = (int)0x80000000;
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const float4* __restrict__ pos, int n, int* b) {
+  int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+  int mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pos[i];
+    int ox = f2ord(p.x), oy = f2ord(p.y), oz = f2ord(p.z);
+    mn[0] = min(mn[0], ox); mn[1] = min(mn[1], oy); mn[2] = min(mn[2], oz);
+    mx[0] = max(mx[0], ox); mx[1] = max(mx[1], oy); mx[2] = max(mx[2], oz);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { atomicMin(&b[a], mn[a]); atomicMax(&b[3 + a], mx[a]); }
+  }
+}
+
+__global__ void k_grid_meta(const int* b, int n, float min_cell, GridMeta* m) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = ord2f(b[a]); hi[a] = ord2f(b[3 + a]); }
+  if (n == 0) { for (int a = 0; a < 3; ++a) { lo[a] = 0.f; hi[a] = 0.f; } }
+  float cell = min_cell * 1.001f;  // margin: a point within r <= min_cell never lands two cells away
+  int nx, ny, nz;
+  for (;;) {
+    nx = (int)floorf((hi[0] - lo[0]) / cell) + 1;
+    ny = (int)floorf((hi[1] - lo[1]) / cell) + 1;
+    nz = (int)floorf((hi[2] - lo[2]) / cell) + 1;
+    if ((long long)nx * ny * nz <= (long long)kMaxCells) break;
+    cell *= 1.26f;
+  }
+  m->ox = lo[0]; m->oy = lo[1]; m->oz = lo[2];
+  m->cell = cell; m->inv_cell = 1.0f / cell;
+  m->nx = nx; m->ny = ny; m->nz = nz; m->ncells = nx * ny * nz; m->npts = n;
+}
+
+__device__ __forceinline__ int cell_coord(float x, float o, float inv, int n) {
+  int c = (int)floorf((x - o) * inv);
+  return min(max(c, 0), n - 1);
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pos, const GridMeta* __restrict__ m,
+                                                    int* cell_of, int* cell_fill) {
+  int n = m->npts;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pos[i];
+    int cx = cell_coord(p.x, m->ox, m->inv_cell, m->nx);
+    int cy = cell_coord(p.y, m->oy, m->inv_cell, m->ny);
+    int cz = cell_coord(p.z, m->oz, m->inv_cell, m->nz);
+    int c = (cz * m->ny + cy) * m->nx + cx;
+    cell_of[i] = c;
+    atomicAdd(&cell_fill[c], 1);
+  }
+}
+
+// exclusive scan of cell_fill[0..ncells) -> cell_start[0..ncells], in 3 launches of 1024-wide blocks
+constexpr int SCAN_B = 1024;  // elements per block (256 threads x 4)
+
+__device__ __forceinline__ int block_excl_scan_256(int v, int* lds, int& total) {
+  // exclusive scan of one int per thread across 256 threads
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) lds[w] = x;
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { int s = lds[i]; if (i < w) woff += s; tot += s; }
+  __syncthreads();
+  total = tot;
+  return woff + x - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_block_sums(const int* __restrict__ in, const GridMeta* __restrict__ m,
+                                                         int* block_sums) {
+  __shared__ int lds[4];
+  int n = m->ncells;
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n) { if (threadIdx.x == 0) block_sums[blockIdx.x] = 0; return; }
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { int i = base + threadIdx.x * 4 + j; if (i < n) s += in[i]; }
+  int tot;
+  block_excl_scan_256(s, lds, tot);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_top(int* block_sums, int nblocks) {
+  // nblocks <= 4096: each thread owns 16 consecutive entries
+  __shared__ int lds[4];
+  int v[16]; int s = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { int i = threadIdx.x * 16 + j; v[j] = (i < nblocks) ? block_sums[i] : 0; s += v[j]; }
+  int tot;
+  int off = block_excl_scan_256(s, lds, tot);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { int i = threadIdx.x * 16 + j; if (i < nblocks) block_sums[i] = off; off += v[j]; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_final(int* cell_fill, const GridMeta* __restrict__ m,
+                                                    const int* __restrict__ block_sums, int* cell_start) {
+  __shared__ int lds[4];
+  int n = m->ncells;
+  int base = blockIdx.x * SCAN_B;
+  if (base >= n) return;
+  int v[4]; int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { int i = base + threadIdx.x * 4 + j; v[j] = (i < n) ? cell_fill[i] : 0; s += v[j]; }
+  int tot;
+  int off = block_excl_scan_256(s, lds, tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int i = base + threadIdx.x * 4 + j;
+    if (i < n) { cell_start[i] = off; cell_fill[i] = 0; }
+    off += v[j];
+  }
+  if (blockIdx.x == (n - 1) / SCAN_B && threadIdx.x == 0) cell_start[n] = m->npts;
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const float4* __restrict__ pos, const GridMeta* __restrict__ m,
+                                                 const int* __restrict__ cell_of, const int* __restrict__ cell_start,
+                                                 int* cell_fill, float4* spos) {
+  int n = m->npts;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int c = cell_of[i];
+    int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+    float4 p = pos[i];
+    p.w = __int_as_float(i);
+    spos[slot] = p;
+  }
+}
+
+int grid_build(psl_ctx* ctx, hipStream_t s) {
+  int n = ctx->n_points;
+  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, ctx->bounds);
+  if (n > 0) {
+    int nb = min((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, s, ctx->pos, n, ctx->bounds);
+  }
+  hipLaunchKernelGGL(k_grid_meta, dim3(1), dim3(1), 0, s, ctx->bounds, n, ctx->cfg.max_query_radius, ctx->meta);
+  PSL_HIP(hipMemsetAsync(ctx->cell_fill, 0, sizeof(int) * kMaxCells, s));
+  const int nblk = kMaxCells / SCAN_B;
+  if (n > 0) {
+    int nb = min((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, ctx->pos, ctx->meta, ctx->cell_of, ctx->cell_fill);
+  }
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, s, ctx->cell_fill, ctx->meta, ctx->scan_tmp);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, ctx->scan_tmp, nblk);
+  hipLaunchKernelGGL(k_scan_final, dim3(nblk), dim3(256), 0, s, ctx->cell_fill, ctx->meta, ctx->scan_tmp,
+                     ctx->cell_start);
+  if (n > 0) {
+    int nb = min((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, s, ctx->pos, ctx->meta, ctx->cell_of, ctx->cell_start,
+                       ctx->cell_fill, ctx->spos);
+  }
+  PSL_LAUNCH_CHECK();
+  ctx->index_points = n;
+  return PSL_OK;
+}
+
+// ------------------------------------------------------------------------ k-NN
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void topk_insert(u64 (&b)[K], u64 kk) {
+  // precondition kk < b[K-1]; b sorted ascending
+#pragma unroll
+  for (int j = K - 1; j > 0; --j) {
+    u64 lo = b[j - 1], cur = b[j];
+    b[j] = (kk < lo) ? lo : ((kk < cur) ? kk : cur);
+  }
+  b[0] = (kk < b[0]) ? kk : b[0];
+}
+
+struct CellBox { int lo[3], hi[3]; };
+
+__device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, float z, float r, CellBox& bx) {
+  float rr = r * 1.0001f + 1e-6f;
+  bx.lo[0] = cell_coord(x - rr, m.ox, m.inv_cell, m.nx); bx.hi[0] = cell_coord(x + rr, m.ox, m.inv_cell, m.nx);
+  bx.lo[1] = cell_coord(y - rr, m.oy, m.inv_cell, m.ny); bx.hi[1] = cell_coord(y + rr, m.oy, m.inv_cell, m.ny);
+  bx.lo[2] = cell_coord(z - rr, m.oz, m.inv_cell, m.nz); bx.hi[2] = cell_coord(z + rr, m.oz, m.inv_cell, m.nz);
+}
+
+// One wavefront scans every cell of `bx` and keeps, for each of its NS queries, the 8 smallest
+// (d2, index) keys with d2 <= r2.  q* and r2 are wave-uniform.
+template <int NS>
+__device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
+                                         const int* __restrict__ cell_start, const float (&qx)[NS],
+                                         const float (&qy)[NS], const float (&qz)[NS], float r2, const CellBox& bx,
+                                         u64 (&best)[NS][K]) {
+  const int lane = threadIdx.x & 63;
+  const u64 sentinel = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[s][j] = sentinel;
+  for (int cz = bx.lo[2]; cz <= bx.hi[2]; ++cz) {
+    for (int cy = bx.lo[1]; cy <= bx.hi[1]; ++cy) {
+      const int rowbase = (cz * m.ny + cy) * m.nx;
+      const int beg = cell_start[rowbase + bx.lo[0]];
+      const int end = cell_start[rowbase + bx.hi[0] + 1];
+      for (int j0 = beg; j0 < end; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < end;
+        float4 c = valid ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned idx = __float_as_uint(c.w);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          float d2 = dist2(c.x, c.y, c.z, qx[s], qy[s], qz[s]);
+          u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
+          u64 mask = __ballot(valid && key < best[s][K - 1]);
+          while (mask) {
+            int l = __builtin_ctzll(mask);
+            unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
+            unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
+            topk_insert(best[s], ((u64)khi << 32) | klo);
+            mask &= mask - 1;
+            if (mask) mask &= __ballot(valid && key < best[s][K - 1]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ray mode: wave per ray, its 5 samples; I_out [R*5][8] int32, cnt_out [R*5]
+__global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                  const int* __restrict__ cell_start,
+                                                  const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                  const float* __restrict__ depth, const float* __restrict__ r_query,
+                                                  float r_fixed, float near_s, float far_s, int n_rays,
+                                                  int* __restrict__ I_out, int* __restrict__ cnt_out) {
+  const int ray = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (ray >= n_rays) return;
+  const int lane = threadIdx.x & 63;
+  const GridMeta m = *meta;
+  const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+  const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+  const float dep = depth[ray];
+  const float r = r_query ? r_query[ray] : r_fixed;
+  const float r2 = r * r;
+  float qx[S], qy[S], qz[S];
+  CellBox bx;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float z = sample_z(dep, s, near_s, far_s);
+    sample_point(ox, oy, oz, dx, dy, dz, z, qx[s], qy[s], qz[s]);
+    CellBox b1;
+    box_of(m, qx[s], qy[s], qz[s], r, b1);
+    if (s == 0) bx = b1;
+    else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { bx.lo[a] = min(bx.lo[a], b1.lo[a]); bx.hi[a] = max(bx.hi[a], b1.hi[a]); }
+    }
+  }
+  u64 best[S][K];
+  wave_knn<S>(m, spos, cell_start, qx, qy, qz, r2, bx, best);
+  const unsigned r2b = __float_as_uint(r2);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    u64 mine = 0; int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (lane == j) mine = best[s][j];
+      unsigned db = (unsigned)(best[s][j] >> 32), ib = (unsigned)(best[s][j] & 0xFFFFFFFFull);
+      cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
+    }
+    if (lane < K) {
+      unsigned ib = (unsigned)(mine & 0xFFFFFFFFull);
+      I_out[(ray * S + s) * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
+    }
+    if (lane == 0) cnt_out[ray * S + s] = cnt;
+  }
+}
+
+// free-query mode: wave per query; outputs follow find_neighbors_faiss (D f32, I int64, cnt int32)
+__global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict__ meta,
+                                                     const float4* __restrict__ spos,
+                                                     const int* __restrict__ cell_start, const float* __restrict__ q,
+                                                     const float* __restrict__ r_per_query, float r_fixed, int nq,
+                                                     float* __restrict__ D_out, long long* __restrict__ I_out,
+                                                     int* __restrict__ cnt_out) {
+  const int qi = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (qi >= nq) return;
+  const int lane = threadIdx.x & 63;
+  const GridMeta m = *meta;
+  float qx[1] = {q[qi * 3 + 0]}, qy[1] = {q[qi * 3 + 1]}, qz[1] = {q[qi * 3 + 2]};
+  const float r = r_per_query ? r_per_query[qi] : r_fixed;
+  const float r2 = r * r;
+  CellBox bx;
+  box_of(m, qx[0], qy[0], qz[0], r, bx);
+  u64 best[1][K];
+  wave_knn<1>(m, spos, cell_start, qx, qy, qz, r2, bx, best);
+  const unsigned r2b = __float_as_uint(r2);
+  u64 mine = 0; int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (lane == j) mine = best[0][j];
+    unsigned db = (unsigned)(best[0][j] >> 32), ib = (unsigned)(best[0][j] & 0xFFFFFFFFull);
+    cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
+  }
+  if (lane < K) {
+    unsigned ib = (unsigned)(mine & 0xFFFFFFFFull);
+    bool empty = ib == 0xFFFFFFFFu;
+    if (I_out) I_out[(long long)qi * K + lane] = empty ? -1ll : (long long)ib;
+    if (D_out) D_out[(long long)qi * K + lane] = empty ? __int_as_float(0x7F800000) : __uint_as_float((unsigned)(mine >> 32));
+  }
+  if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
+}
+
+int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* r_query,
+             int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
+  if (n_rays <= 0) return PSL_OK;
+  int blocks = (n_rays + 3) / 4;
+  hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                     rays_d, depth, r_query, ctx->cfg.radius_query, ctx->cfg.near_end_surface,
+                     ctx->cfg.far_end_surface, n_rays, I_out, cnt_out);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
+                int64_t* I_out, int* cnt_out, hipStream_t s) {
+  if (nq <= 0) return PSL_OK;
+  int blocks = (nq + 3) / 4;
+  hipLaunchKernelGGL(k_knn_queries, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, q,
+                     r_per_query, r_scalar, nq, D_out, (long long*)I_out, cnt_out);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+// ----------------------------------------------------------------- point growth
+__global__ __launch_bounds__(256) void k_append_raw(const float* __restrict__ src, int n, float4* pos, int base) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[base + i] = make_float4(src[i * 3 + 0], src[i * 3 + 1], src[i * 3 + 2], 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_download(const float4* __restrict__ pos, int n, float* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { float4 p = pos[i]; out[i * 3 + 0] = p.x; out[i * 3 + 1] = p.y; out[i * 3 + 2] = p.z; }
+}
+
+// surface points o + d*depth for rays with depth > 0 (neural_point.py:108-113); others get a far-away sentinel
+__global__ __launch_bounds__(256) void k_surface_pts(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                     const float* __restrict__ dep, int n, float* q) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float d = dep[i];
+  float x, y, z;
+  sample_point(ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2], rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2], d, x, y, z);
+  q[i * 3] = x; q[i * 3 + 1] = y; q[i * 3 + 2] = z;
+}
+
+// single-block ordered compaction: keep[i] = depth>0 && cnt==0 ; appends 3 points per kept location in
+// ray order (neural_point.py:141-147: pts[mask].reshape(-1,3)).
+__global__ __launch_bounds__(1024) void k_append_kept(const float* __restrict__ ro, const float* __restrict__ rd,
+                                                      const float* __restrict__ dep, const int* __restrict__ cnt,
+                                                      int has_index, int n, float near_e, float far_e, float4* pos,
+                                                      int base, int capacity, unsigned char* keep_out,
+                                                      int* n_kept_out) {
+  __shared__ int wsum[16];
+  __shared__ int running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    int i = i0 + threadIdx.x;
+    bool keep = false;
+    float d = 0.f;
+    if (i < n) { d = dep[i]; keep = d > 0.f && (!has_index || cnt[i] == 0); }
+    u64 bal = __ballot(keep);
+    int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = running;
+    for (int j = 0; j < w; ++j) off += wsum[j];
+    int rank = off + pre;
+    if (i < n) keep_out[i] = keep ? 1 : 0;
+    if (keep && base + 3 * rank + 2 < capacity) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        // z = near*d*(1-t) + far*d*t, t = linspace(0,1,3)  (neural_point.py:126-139)
+        float t = 0.5f * (float)a;
+        float z = __fadd_rn(__fmul_rn(__fmul_rn(near_e, d), 1.0f - t), __fmul_rn(__fmul_rn(far_e, d), t));
+        float x, y, zz;
+        sample_point(ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2], rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2], z, x, y, zz);
+        pos[base + 3 * rank + a] = make_float4(x, y, zz, 0.f);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int j = 0; j < 16; ++j) t += wsum[j]; running += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_kept_out = running;
+}
+
+}  // namespace psl
+
+using namespace psl;
+
+extern "C" int psl_points_reset(psl_ctx* ctx) {
+  if (!ctx) return PSL_ERR_ARG;
+  ctx->n_points = 0; ctx->index_points = -1;
+  return PSL_OK;
+}
+
+extern "C" int psl_points_append(psl_ctx* ctx, const float* pos, int n, void* stream) {
+  if (!ctx || n < 0) { set_error("psl_points_append: bad argument"); return PSL_ERR_ARG; }
+  if (n == 0) return PSL_OK;
+  if (ctx->n_points + n > ctx->cfg.max_points) {
+    set_error("psl_points_append: capacity %d exceeded (%d + %d)", ctx->cfg.max_points, ctx->n_points, n);
+    return PSL_ERR_CAPACITY;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_append_raw, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, ctx->pos, ctx->n_points);
+  PSL_LAUNCH_CHECK();
+  ctx->n_points += n;
+  ctx->index_points = -1;
+  return PSL_OK;
+}
+
+extern "C" int psl_points_count(psl_ctx* ctx) { return ctx ? ctx->n_points : PSL_ERR_ARG; }
+
+extern "C" int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_points, void* stream) {
+  if (!ctx || !pos_out) return PSL_ERR_ARG;
+  int n = min(ctx->n_points, capacity_points);
+  if (n > 0) hipLaunchKernelGGL(k_download, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->pos, n, pos_out);
+  PSL_LAUNCH_CHECK();
+  return n;
+}
+
+extern "C" int psl_index_build(psl_ctx* ctx, void* stream) {
+  if (!ctx) return PSL_ERR_ARG;
+  return grid_build(ctx, (hipStream_t)stream);
+}
+
+extern "C" int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq,
+                       float* D_out, int64_t* I_out, int32_t* cnt_out, void* stream) {
+  if (!ctx || !q || nq < 0) { set_error("psl_knn: bad argument"); return PSL_ERR_ARG; }
+  if (ctx->index_points != ctx->n_points) { set_error("psl_knn: index is stale, call psl_index_build"); return PSL_ERR_STATE; }
+  return knn_queries(ctx, q, r_per_query, r_scalar, nq, D_out, I_out, cnt_out, (hipStream_t)stream);
+}
+
+extern "C" int psl_add_points_sync(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth,
+                                   const float* radius_per_ray, float r_scalar, int n, float near_end, float far_end,
+                                   uint8_t* keep_out, int* n_kept_host, void* stream) {
+  if (!ctx || n < 0 || !keep_out || !n_kept_host) { set_error("psl_add_points_sync: bad argument"); return PSL_ERR_ARG; }
+  *n_kept_host = 0;
+  if (n == 0) return PSL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int has_index = ctx->n_points > 0;
+  if (has_index && ctx->index_points != ctx->n_points) {
+    set_error("psl_add_points_sync: index is stale, call psl_index_build"); return PSL_ERR_STATE;
+  }
+  if (ctx->scan_flags_cap < 4 * n) {
+    if (ctx->scan_flags) (void)hipFree(ctx->scan_flags);
+    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * 4 * (size_t)n));
+    ctx->scan_flags_cap = 4 * n;
+  }
+  float* qsurf = (float*)ctx->scan_flags;            // [n][3]
+  int* cnt = ctx->scan_flags + 3 * n;                // [n]
+  if (has_index) {
+    hipLaunchKernelGGL(k_surface_pts, dim3((n + 255) / 256), dim3(256), 0, s, rays_o, rays_d, depth, n, qsurf);
+    int rc = knn_queries(ctx, qsurf, radius_per_ray, r_scalar, n, nullptr, nullptr, cnt, s);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_append_kept, dim3(1), dim3(1024), 0, s, rays_o, rays_d, depth, cnt, has_index, n, near_end,
+                     far_end, ctx->pos, ctx->n_points, ctx->cfg.max_points, keep_out, ctx->d_counter);
+  PSL_LAUNCH_CHECK();
+  int kept = 0;
+  PSL_HIP(hipMemcpyAsync(&kept, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  PSL_HIP(hipStreamSynchronize(s));
+  if (ctx->n_points + 3 * kept > ctx->cfg.max_points) {
+    set_error("psl_add_points_sync: capacity %d exceeded", ctx->cfg.max_points);
+    return PSL_ERR_CAPACITY;
+  }
+  ctx->n_points += 3 * kept;
+  if (kept > 0) ctx->index_points = -1;
+  *n_kept_host = kept;
+  return PSL_OK;
+}

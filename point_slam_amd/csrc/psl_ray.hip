@@ -1,0 +1,241 @@
+// Per-ray kernels: occupancy alpha-compositing (forward + backward), ray-gradient assembly, Adam.
+//
+// raw2outputs_nerf_color (src/common.py:298-336): alpha_s = sigmoid(coef*occ_s),
+// T_s = prod_{j<s}(1 - alpha_j + 1e-10), w = alpha*T, W = sum(w)+1e-10, rgb = sum(w c)/W,
+// depth = sum(w z)/W, var = sum(w (z-depth)^2).  S = 5 samples fit in registers: one lane per ray.
+#include "psl_common.h"
+#include "psl_device.h"
+
+namespace psl {
+
+__global__ __launch_bounds__(256) void k_composite_fwd(const float4* __restrict__ raw, const float* __restrict__ z_in,
+                                                       const float* __restrict__ gt_depth, float near_s, float far_s,
+                                                       const int* __restrict__ cnt, int min_nn, int n_rays, float coef,
+                                                       float* __restrict__ depth, float* __restrict__ var,
+                                                       float* __restrict__ rgb, unsigned char* __restrict__ valid,
+                                                       float* __restrict__ cw, float* __restrict__ ray_aux) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float w[S], z[S], c0[S], c1[S], c2[S];
+  float T = 1.0f, wsum = 0.f;
+  int nhas = 0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float4 q = raw[r * S + s];
+    z[s] = z_in ? z_in[r * S + s] : sample_z(gt_depth[r], s, near_s, far_s);
+    float alpha = sigmoidf(coef * q.w);
+    w[s] = alpha * T;
+    T = T * (1.0f - alpha + 1e-10f);
+    wsum += w[s];
+    c0[s] = q.x; c1[s] = q.y; c2[s] = q.z;
+    if (cnt) nhas += (cnt[r * S + s] >= min_nn) ? 1 : 0;
+  }
+  float W = wsum + 1e-10f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a0 += w[s] * c0[s]; a1 += w[s] * c1[s]; a2 += w[s] * c2[s]; ad += w[s] * z[s]; }
+  float d = ad / W;
+  float v = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { float tmp = z[s] - d; v += w[s] * tmp * tmp; }
+  depth[r] = d; var[r] = v;
+  rgb[r * 3 + 0] = a0 / W; rgb[r * 3 + 1] = a1 / W; rgb[r * 3 + 2] = a2 / W;
+  // valid ray: at least int(S/2+1) = 3 samples with >= min_nn neighbours (decoder.py:200-201)
+  if (valid) valid[r] = nhas >= (S / 2 + 1) ? 1 : 0;
+  if (cw) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) cw[r * S + s] = w[s];
+  }
+  if (ray_aux) { ray_aux[r * 4 + 0] = d; ray_aux[r * 4 + 1] = W; ray_aux[r * 4 + 2] = v; ray_aux[r * 4 + 3] = 0.f; }
+}
+
+// d(raw) from d(depth), d(var), d(rgb).  The -100 written into masked samples (Renderer.py:189-190) replaces the
+// VALUE only; autograd still routes d/d(occ) to the decoder output (in-place write under no_grad), so d_raw.w is
+// produced for masked samples as well.
+__global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ gt_depth,
+                                                       float near_s, float far_s, int n_rays, float coef,
+                                                       const float* __restrict__ g_depth, const float* __restrict__ g_var,
+                                                       const float* __restrict__ g_rgb, float4* __restrict__ d_raw) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
+  float T = 1.0f, wsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float4 q = raw[r * S + s];
+    z[s] = sample_z(gt_depth[r], s, near_s, far_s);
+    al[s] = sigmoidf(coef * q.w);
+    Tt[s] = T;
+    w[s] = al[s] * T;
+    T = T * (1.0f - al[s] + 1e-10f);
+    wsum += w[s];
+    c0[s] = q.x; c1[s] = q.y; c2[s] = q.z;
+  }
+  float W = wsum + 1e-10f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a0 += w[s] * c0[s]; a1 += w[s] * c1[s]; a2 += w[s] * c2[s]; ad += w[s] * z[s]; }
+  float d = ad / W, m0 = a0 / W, m1 = a1 / W, m2 = a2 / W;
+  float gd = g_depth ? g_depth[r] : 0.f, gv = g_var ? g_var[r] : 0.f;
+  float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+  // var = sum w (z-d)^2 : d var / d depth = -2 sum w (z - d)
+  float dvd = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) dvd += w[s] * (z[s] - d);
+  float gdt = gd + gv * (-2.0f * dvd);
+  float gw[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float dz = z[s] - d;
+    gw[s] = gv * dz * dz + (gdt * dz + gr0 * (c0[s] - m0) + gr1 * (c1[s] - m1) + gr2 * (c2[s] - m2)) / W;
+  }
+  // w_s = alpha_s T_s, T_s = prod_{j<s} (1 - alpha_j + 1e-10)
+  float suffix = 0.f;  // sum_{t>s} gw_t w_t
+#pragma unroll
+  for (int s = S - 1; s >= 0; --s) {
+    float ga = gw[s] * Tt[s] - suffix / (1.0f - al[s] + 1e-10f);
+    float gocc = ga * coef * al[s] * (1.0f - al[s]);
+    float ws = w[s] / W;
+    d_raw[r * S + s] = make_float4(gr0 * ws, gr1 * ws, gr2 * ws, gocc);
+    suffix += gw[s] * w[s];
+  }
+}
+
+// g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (pts = o + d*z, Renderer.py:172-173)
+__global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp, const float* __restrict__ gt_depth,
+                                                  float near_s, float far_s, int n_rays, float* __restrict__ g_o,
+                                                  float* __restrict__ g_d) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    float4 g = dp[r * S + s];
+    float z = sample_z(gt_depth[r], s, near_s, far_s);
+    o0 += g.x; o1 += g.y; o2 += g.z;
+    d0 += z * g.x; d1 += z * g.y; d2 += z * g.z;
+  }
+  if (g_o) { g_o[r * 3] = o0; g_o[r * 3 + 1] = o1; g_o[r * 3 + 2] = o2; }
+  if (g_d) { g_d[r * 3] = d0; g_d[r * 3 + 1] = d1; g_d[r * 3 + 2] = d2; }
+}
+
+int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
+                         const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
+                         unsigned char* valid, float* cw, float* ray_aux, hipStream_t s) {
+  if (n_rays <= 0) return PSL_OK;
+  hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
+                     cnt, min_nn, n_rays, coef, depth, var, rgb, valid, cw, ray_aux);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int launch_composite_bwd(const float4* raw, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
+                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s) {
+  if (n_rays <= 0) return PSL_OK;
+  hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, gt_depth, near_s, far_s,
+                     n_rays, coef, g_depth, g_var, g_rgb, d_raw);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int launch_ray_grad(const float4* dp, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
+                    float* g_d, hipStream_t s) {
+  if (n_rays <= 0) return PSL_OK;
+  hipLaunchKernelGGL(k_ray_grad, dim3((n_rays + 255) / 256), dim3(256), 0, s, dp, gt_depth, near_s, far_s, n_rays,
+                     g_o, g_d);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+// ------------------------------------------------------------------------ Adam
+// torch.optim.Adam (defaults, no weight decay / amsgrad):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Dense over every element each step (the reference steps all frustum-selected rows, Mapper.py:394-402).
+// Written in the operation order of torch's single-tensor path (lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_).
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr_bc1, float sqrt_bc2,
+                                            float b1, float b2, float eps) {
+  m = m + (1.0f - b1) * (g - m);
+  v = v * b2 + ((1.0f - b2) * g) * g;
+  float denom = sqrtf(v) / sqrt_bc2 + eps;
+  p = p + ((-lr_bc1) * m) / denom;
+}
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float lr_bc1, float sqrt_bc2,
+                                              float b1, float b2, float eps, int zero_grad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+    adam_update(pp, gg, mm, vv, lr_bc1, sqrt_bc2, b1, b2, eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+// rows of a [N][32] feature matrix through an index list; g/m/v compact [n_rows][32]; float4 per lane
+__global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, const int* __restrict__ rows,
+                                                   float4* __restrict__ g, float4* __restrict__ m,
+                                                   float4* __restrict__ v, int n_rows, float lr_bc1,
+                                                   float sqrt_bc2, float b1, float b2, float eps, int zero_grad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n4 = (long long)n_rows * (C / 4);
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    int row = (int)(i >> 3), q = (int)(i & 7);
+    int dst = rows ? rows[row] : row;
+    float4* pp4 = reinterpret_cast<float4*>(feats + (size_t)dst * C) + q;
+    float4 pp = *pp4, gg = g[i], mm = m[i], vv = v[i];
+    adam_update(pp.x, gg.x, mm.x, vv.x, lr_bc1, sqrt_bc2, b1, b2, eps);
+    adam_update(pp.y, gg.y, mm.y, vv.y, lr_bc1, sqrt_bc2, b1, b2, eps);
+    adam_update(pp.z, gg.z, mm.z, vv.z, lr_bc1, sqrt_bc2, b1, b2, eps);
+    adam_update(pp.w, gg.w, mm.w, vv.w, lr_bc1, sqrt_bc2, b1, b2, eps);
+    *pp4 = pp; m[i] = mm; v[i] = vv;
+    if (zero_grad) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+}  // namespace psl
+
+using namespace psl;
+
+extern "C" int psl_composite_fwd(const float* raw, const float* z, int n_rays, float coef, float* depth, float* var,
+                                 float* rgb, float* weights, void* stream) {
+  if (!raw || !z || !depth || !var || !rgb || n_rays < 0) { set_error("psl_composite_fwd: bad argument"); return PSL_ERR_ARG; }
+  return launch_composite_fwd((const float4*)raw, z, nullptr, 0.f, 0.f, nullptr, 0, n_rays, coef, depth, var, rgb,
+                              nullptr, weights, nullptr, (hipStream_t)stream);
+}
+
+static void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2) {
+  double bc1 = 1.0 - pow((double)b1, (double)step);
+  double bc2 = 1.0 - pow((double)b2, (double)step);
+  lr_bc1 = (float)((double)lr / bc1);
+  sqrt_bc2 = (float)sqrt(bc2);
+}
+
+extern "C" int psl_adam_step(float* p, float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                             float beta2, float eps, int zero_grad, void* stream) {
+  if (!p || !g || !m || !v || n < 0 || step < 1) { set_error("psl_adam_step: bad argument"); return PSL_ERR_ARG; }
+  if (n == 0) return PSL_OK;
+  float a, b;
+  adam_consts(step, lr, beta1, beta2, a, b);
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, a, b, beta1,
+                     beta2, eps, zero_grad);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+extern "C" int psl_adam_step_rows(float* feats, const int32_t* rows, float* g, float* m, float* v, int n_rows,
+                                  int step, float lr, float beta1, float beta2, float eps, int zero_grad, void* stream) {
+  if (!feats || !g || !m || !v || n_rows < 0 || step < 1) { set_error("psl_adam_step_rows: bad argument"); return PSL_ERR_ARG; }
+  if (n_rows == 0) return PSL_OK;
+  float a, b;
+  adam_consts(step, lr, beta1, beta2, a, b);
+  long long n4 = (long long)n_rows * (C / 4);
+  int blocks = (int)std::min<long long>((n4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_adam_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, rows, (float4*)g, (float4*)m,
+                     (float4*)v, n_rows, a, b, beta1, beta2, eps, zero_grad);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}

@@ -1,0 +1,204 @@
+"""HipNeuralPointCloud: drop-in for the reference's NeuralPointCloud
+(src/neural_point.py:9-277) -- same method names, argument meaning and return
+conventions -- backed by the uniform-grid index of libpointslam_hip.so instead
+of FAISS-GPU, with device-resident positions instead of Python lists.
+
+Deviations, all documented in DESIGN.md:
+  * the search is exact (FAISS IVF nprobe=4 is approximate); `nlist`/`nprobe` are ignored;
+  * find_neighbors_faiss returns (inf, -1) in slots beyond the query radius;
+  * cloud_pos() returns a [N,3] device tensor (the reference returns a list of lists;
+    its callers immediately do torch.tensor(...) on it, Mapper.py:336-337, Tracker.py:198-199).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class HipNeuralPointCloud(object):
+    def __init__(self, cfg, max_points: int = 4_000_000, device=None):
+        self.cfg = cfg
+        self.c_dim = cfg['model']['c_dim']
+        self.device = device or cfg['mapping']['device']
+        self.use_dynamic_radius = cfg['use_dynamic_radius']
+        self.nn_num = cfg['pointcloud']['nn_num']
+        self.radius_add = cfg['pointcloud']['radius_add']
+        self.radius_min = cfg['pointcloud']['radius_min']
+        self.radius_query = cfg['pointcloud']['radius_query']
+        self.fix_interval_when_add_along_ray = cfg['pointcloud']['fix_interval_when_add_along_ray']
+        if self.fix_interval_when_add_along_ray:
+            raise NotImplementedError("fix_interval_when_add_along_ray=True is not used by any shipped config")
+        self.N_surface = cfg['rendering']['N_surface']
+        self.N_add = cfg['pointcloud']['N_add']
+        if self.N_add != 3:
+            raise NotImplementedError("N_add must be 3")
+        self.near_end_surface = cfg['pointcloud']['near_end_surface']
+        self.far_end_surface = cfg['pointcloud']['far_end_surface']
+        self._input_pos = []
+        self._input_rgb = []
+        self.geo_feats = None
+        self.col_feats = None
+        self.keyframe_dict = []
+
+        pc = cfg['pointcloud']
+        max_r = pc['radius_add_max'] * pc['radius_query_ratio'] if self.use_dynamic_radius else pc['radius_query']
+        max_r = max(max_r, pc['radius_add'], pc['radius_query'] if not self.use_dynamic_radius else 0.0)
+        c = _lib.psl_config(n_surface=self.N_surface, nn_num=self.nn_num, c_dim=self.c_dim,
+                            min_nn_num=pc['min_nn_num'],
+                            near_end_surface=cfg['rendering']['near_end_surface'],
+                            far_end_surface=cfg['rendering']['far_end_surface'],
+                            radius_query=self.radius_query, max_query_radius=max_r,
+                            encode_rel_pos=1 if cfg['model']['encode_rel_pos_in_col'] else 0,
+                            max_points=max_points)
+        dev = torch.device(self.device)
+        self._dev_index = dev.index if dev.index is not None else 0
+        h = C.c_void_p()
+        _lib.check(_lib.lib().psl_create(self._dev_index, C.byref(c), C.byref(h)), "psl_create")
+        self._h = h
+        self._trained = False
+        self._cfgs = c
+        torch.manual_seed(cfg["setup_seed"])  # neural_point.py:42 (setup_seed) -- RNG for the feature init
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and _lib is not None:
+            try:
+                _lib.lib().psl_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- getters (neural_point.py:44-73) -------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def cloud_pos(self, index=None):
+        n = self.pts_num()
+        out = torch.empty(n, 3, device=self.device, dtype=torch.float32)
+        if n:
+            _lib.check(_lib.lib().psl_points_download(self._h, _lib.ptr(out), n, _lib.stream_ptr()), "download")
+        return out if index is None else out[index]
+
+    def input_pos(self):
+        return self._input_pos
+
+    def input_rgb(self):
+        return self._input_rgb
+
+    def pts_num(self):
+        return _lib.lib().psl_points_count(self._h)
+
+    def index_train(self, xb):
+        assert torch.is_tensor(xb), 'use tensor to train FAISS index'
+        self._build()
+        return True
+
+    def index_ntotal(self):
+        return self.pts_num()
+
+    def get_radius_query(self):
+        return self.radius_query
+
+    def get_geo_feats(self):
+        return self.geo_feats
+
+    def get_col_feats(self):
+        return self.col_feats
+
+    def update_geo_feats(self, feats, indices=None):
+        assert torch.is_tensor(feats), 'use tensor to update features'
+        if indices is not None:
+            self.geo_feats[indices] = feats.detach().clone()
+        else:
+            assert feats.shape[0] == self.geo_feats.shape[0], 'feature shape[0] mismatch'
+            self.geo_feats = feats.detach().clone()
+
+    def update_col_feats(self, feats, indices=None):
+        assert torch.is_tensor(feats), 'use tensor to update features'
+        if indices is not None:
+            self.col_feats[indices] = feats.detach().clone()
+        else:
+            assert feats.shape[0] == self.col_feats.shape[0], 'feature shape[0] mismatch'
+            self.col_feats = feats.detach().clone()
+
+    # ---- state upload (checkpoint / multi-GPU merge) ------------------------------------
+    def set_points(self, pos: torch.Tensor, geo_feats: torch.Tensor = None, col_feats: torch.Tensor = None):
+        """Replace the cloud by `pos` [N,3] (device tensor) and rebuild the index."""
+        L = _lib.lib()
+        _lib.check(L.psl_points_reset(self._h))
+        self.append_points(pos, geo_feats, col_feats)
+
+    def append_points(self, pos, geo_feats=None, col_feats=None):
+        pos = pos.to(self.device, torch.float32).contiguous()
+        n = pos.shape[0]
+        if n:
+            _lib.check(_lib.lib().psl_points_append(self._h, _lib.ptr(pos), n, _lib.stream_ptr()), "append")
+        if geo_feats is not None:
+            gf, cf = geo_feats.to(self.device).float(), col_feats.to(self.device).float()
+            self.geo_feats = gf.clone() if self.geo_feats is None else torch.cat([self.geo_feats, gf], 0)
+            self.col_feats = cf.clone() if self.col_feats is None else torch.cat([self.col_feats, cf], 0)
+        self._build()
+
+    def _build(self):
+        _lib.check(_lib.lib().psl_index_build(self._h, _lib.stream_ptr()), "psl_index_build")
+        self._trained = True
+
+    # ---- add_neural_points (neural_point.py:91-167) ---------------------------------------
+    def add_neural_points(self, batch_rays_o, batch_rays_d, batch_gt_depth, batch_gt_color,
+                          train=False, is_pts_grad=False, dynamic_radius=None, return_new=False):
+        n = batch_rays_o.shape[0]
+        if not n:
+            return 0
+        ro = batch_rays_o.detach().float().contiguous()
+        rd = batch_rays_d.detach().float().contiguous()
+        dep = batch_gt_depth.detach().float().contiguous()
+        rad = dynamic_radius.detach().float().contiguous() if dynamic_radius is not None else None
+        r_scalar = self.radius_min if is_pts_grad else self.radius_add      # neural_point.py:199-205
+        keep = torch.empty(n, dtype=torch.uint8, device=ro.device)
+        kept = C.c_int(0)
+        n_before = self.pts_num()
+        _lib.check(_lib.lib().psl_add_points_sync(self._h, _lib.ptr(ro), _lib.ptr(rd), _lib.ptr(dep), _lib.ptr(rad),
+                                                  float(r_scalar), n, float(self.near_end_surface),
+                                                  float(self.far_end_surface), _lib.ptr(keep), C.byref(kept),
+                                                  _lib.stream_ptr()), "psl_add_points_sync")
+        n_new = 3 * kept.value
+        # features ~ N(0, 0.1^2), geometry first then colour (neural_point.py:149-159)
+        gnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
+        cnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
+        if self.geo_feats is None:
+            self.geo_feats, self.col_feats = gnew, cnew
+        else:
+            self.geo_feats = torch.cat([self.geo_feats, gnew], 0)
+            self.col_feats = torch.cat([self.col_feats, cnew], 0)
+        self._build()
+        if return_new:
+            return kept.value, keep.bool(), n_before
+        return torch.tensor(kept.value, device=self.device)
+
+    # ---- find_neighbors_faiss (neural_point.py:169-215) -----------------------------------
+    def find_neighbors_faiss(self, pos, step='add', retrain=False, is_pts_grad=False, dynamic_radius=None):
+        assert step in ['add', 'query']
+        q = pos.detach().float().contiguous()
+        n = q.shape[0]
+        if step == 'query':
+            radius = self.radius_query
+        else:
+            radius = self.radius_min if is_pts_grad else self.radius_add
+        rad = None
+        if dynamic_radius is not None:
+            assert pos.shape[0] == dynamic_radius.shape[0], 'shape mis-match for input points and dynamic radius'
+            rad = dynamic_radius.detach().float().reshape(-1).contiguous()
+        D = torch.empty(n, self.nn_num, device=q.device, dtype=torch.float32)
+        I = torch.empty(n, self.nn_num, device=q.device, dtype=torch.int64)
+        cnt = torch.empty(n, device=q.device, dtype=torch.int32)
+        _lib.check(_lib.lib().psl_knn(self._h, _lib.ptr(q), _lib.ptr(rad), float(radius), n, _lib.ptr(D), _lib.ptr(I),
+                                      _lib.ptr(cnt), _lib.stream_ptr()), "psl_knn")
+        return D, I, cnt
+
+    def sample_near_pcl(self, rays_o, rays_d, near, far, num):
+        """Zero-depth pixels (neural_point.py:217-277): SURVEY §8f 'next' item, not built in this round."""
+        raise NotImplementedError("sample_near_pcl (zero-depth ray marching) is a §8f 'next' row")
