@@ -152,6 +152,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta)));
   PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4));
+  PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64));
   for (int i = 0; i < 2 * PROF_N; ++i) PSL_HIP(hipEventCreate(&c->ev[i]));
   *out = c;
   return PSL_OK;
@@ -163,7 +164,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipDeviceSynchronize();
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
-  (void)hipFree(c->wt); (void)hipFree(c->d_counter);
+  (void)hipFree(c->wt); (void)hipFree(c->d_counter); (void)hipFree(c->d_small);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   for (int i = 0; i < 2 * PROF_N; ++i) (void)hipEventDestroy(c->ev[i]);

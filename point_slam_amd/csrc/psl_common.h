@@ -143,6 +143,7 @@ struct psl_ctx {
   int dw_slab_cap;       // number of slabs allocated
   // small device scratch
   int* d_counter;
+  float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   int* scan_flags;       // for add_points compaction
   int scan_flags_cap;
   // profiling

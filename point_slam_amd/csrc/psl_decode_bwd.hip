@@ -1,7 +1,468 @@
+// Fused per-sample decode, backward: gradients w.r.t. the interpolated features (scatter-added to the
+// neural-point feature rows), w.r.t. the sample positions (-> camera pose) and the per-layer dZ / G
+// tiles that the parameter-gradient GEMM (psl_dw.hip) contracts over all samples.
+//
+// Mirrors autograd through MLP_color / MLP_geometry / get_feature_at_pos
+// (src/conv_onet/models/decoder.py:130-222,341-449), which the reference executes as ~1000 ATen
+// backward launches incl. a dense [N,32] zero-fill + index_add per gather.
+// Same tiling as the forward: 16 samples per 512-thread workgroup, every dX = dZ * W product is an
+// exact-fp32 MFMA whose B operand is the torch-layout weight itself ([out][in] row-major).
 #include "psl_decode.h"
+
 namespace psl {
-int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s) {
-  set_error("decode backward not built yet");
-  return PSL_ERR_UNSUPPORTED;
+
+constexpr int LD_DE = 98;   // geo d_emb tile [16][96]  (98/2 odd)
+constexpr int LD_DEC = 50;  // colour d_emb tile [16][40..48]
+constexpr int LD_DXN = 66;
+
+constexpr int BWD_LDS_FLOATS = 128 + 128 + 384 + 64 + 16 + /*sGW*/ 128 + /*sDP*/ 64 + /*sDB*/ 32 + /*sAff*/ 16 +
+                               /*sG*/ 16 * LD_C + /*sDZ*/ 16 * LD_HN + /*sDEg*/ 16 * LD_DE + /*sDEc*/ 16 * LD_DEC +
+                               /*sDCg,sDCc*/ 2 * 16 * LD_CF + /*sDO*/ 64 +
+                               /*per wave: dnf [16][34] + dz1 [16][130] + dx [16][66]*/ 8 * (16 * LD_CF + 16 * LD_HN + 16 * LD_DXN);
+
+struct BwdOut {
+  float* g_geo; float* g_col; const int* row_map;
+  float* g_brel;     // [30] accumulated with atomics (pre-zeroed)
+  float* g_affine;   // [12] accumulated with atomics (pre-zeroed)
+};
+
+// read a C/D-layout fragment from an LDS tile
+__device__ __forceinline__ f32x4 frag_load(const float* src, int ld, int n0) {
+  const int lane = threadIdx.x & 63;
+  const float* p = src + (4 * (lane >> 4)) * ld + n0 + (lane & 15);
+  f32x4 v;
+  v[0] = p[0]; v[1] = p[ld]; v[2] = p[2 * ld]; v[3] = p[3 * ld];
+  return v;
 }
+
+__global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* sI = (int*)smem;                     // [16][8]
+  float* sW = smem + 128;                   // [16][8] normalised weights
+  float* sRel = sW + 128;                   // [16][8][3]
+  float* sPts = sRel + 384;                 // [16][4]
+  int* sHas = (int*)(sPts + 64);            // [16]
+  float* sGW = (float*)(sHas + 16);         // [16][8] dL/dw
+  float* sDP = sGW + 128;                   // [16][4] dL/dp
+  float* sDB = sDP + 64;                    // [32]    dL/dB_rel (30 used)
+  float* sAff = sDB + 32;                   // [16]    dL/d affine (12 used)
+  float* sG = sAff + 16;                    // [16][170] dL/dh tile (colour uses cols 0..127, geo 0..31)
+  float* sDZ = sG + 16 * LD_C;              // [16][130]
+  float* sDEg = sDZ + 16 * LD_HN;           // [16][98]  dL/d geo embedding
+  float* sDEc = sDEg + 16 * LD_DE;          // [16][50]  dL/d colour embedding
+  float* sDCg = sDEc + 16 * LD_DEC;         // [16][34]  dL/d c_geo
+  float* sDCc = sDCg + 16 * LD_CF;          // [16][34]  dL/d c_col
+  float* sDO = sDCc + 16 * LD_CF;           // [16][4]   dL/d colour logits (pre-affine)
+  float* sWave = sDO + 64;                  // per wave scratch
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = lane >> 4, colw = lane & 15, g4 = 4 * g;
+  const int p0 = blockIdx.x * TILE;
+  const bool color = (a.flags & PSL_STAGE_COLOR) != 0;
+  const bool relpos = color && (a.flags & 0x10000) != 0;
+  const bool ptsg = (a.flags & PSL_PTS_GRAD) != 0;
+  const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
+  const bool parg = (a.flags & PSL_PARAM_GRAD) != 0 && color;
+  const float* __restrict__ M = a.master;
+
+  // ---------------------------------------------------------------- phase 0: reload per-sample state, zero accumulators
+  if (t < 128) {
+    const int s = t >> 3, k = t & 7;
+    const int p = min(p0 + s, a.P - 1);
+    SampleGeom sg = sample_geom(a, p);
+    int i = a.ws.I[p * K + k];
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (i >= 0) {
+      float4 q = a.pos[i];
+      rx = __fsub_rn(q.x, sg.x); ry = __fsub_rn(q.y, sg.y); rz = __fsub_rn(q.z, sg.z);
+    }
+    sI[s * K + k] = i;
+    sW[s * K + k] = a.ws.w[p * K + k];
+    sRel[(s * K + k) * 3 + 0] = rx; sRel[(s * K + k) * 3 + 1] = ry; sRel[(s * K + k) * 3 + 2] = rz;
+    sGW[s * K + k] = 0.f;
+    if (k == 0) {
+      sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
+      // samples past the end of the batch behave as "no neighbours, zero gradient"
+      sHas[s] = (p0 + s < a.P && a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
+    }
+  }
+  if (t < 64) sDP[t] = 0.f;
+  if (t < 32) sDB[t] = 0.f;
+  if (t < 16) sAff[t] = 0.f;
+  for (int e = t; e < 16 * LD_DE; e += WG) sDEg[e] = 0.f;
+  for (int e = t; e < 16 * LD_DEC; e += WG) sDEc[e] = 0.f;
+  __syncthreads();
+
+  // ================================================================== colour decoder
+  if (color) {
+    // ---- d(logits): sigmoid and exposure-affine backward (decoder.py:432-448)
+    if (t < TILE) {
+      int p = p0 + t;
+      float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+      if (p < a.P) {
+        float4 dr = reinterpret_cast<const float4*>(a.ws.d_raw)[p];
+        float4 rw = reinterpret_cast<const float4*>(a.ws.raw)[p];
+        d0 = dr.x; d1 = dr.y; d2 = dr.z;
+        if (!(a.flags & PSL_NO_SIGMOID)) { d0 *= rw.x * (1.f - rw.x); d1 *= rw.y * (1.f - rw.y); d2 *= rw.z * (1.f - rw.z); }
+        if (a.flags & PSL_HAS_AFFINE) {
+          const float* A = a.affine;
+          float o0 = a.ws.out3[(size_t)p * 4], o1 = a.ws.out3[(size_t)p * 4 + 1], o2 = a.ws.out3[(size_t)p * 4 + 2];
+          // out' = out @ A + t : dA[i][j] = out_i d_j ; dt_j = d_j ; d out_i = sum_j A[i][j] d_j
+          atomic_add_f32(&sAff[0], o0 * d0); atomic_add_f32(&sAff[1], o0 * d1); atomic_add_f32(&sAff[2], o0 * d2);
+          atomic_add_f32(&sAff[3], o1 * d0); atomic_add_f32(&sAff[4], o1 * d1); atomic_add_f32(&sAff[5], o1 * d2);
+          atomic_add_f32(&sAff[6], o2 * d0); atomic_add_f32(&sAff[7], o2 * d1); atomic_add_f32(&sAff[8], o2 * d2);
+          atomic_add_f32(&sAff[9], d0); atomic_add_f32(&sAff[10], d1); atomic_add_f32(&sAff[11], d2);
+          float e0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
+          float e1 = A[3] * d0 + A[4] * d1 + A[5] * d2;
+          float e2 = A[6] * d0 + A[7] * d1 + A[8] * d2;
+          d0 = e0; d1 = e1; d2 = e2;
+        }
+        if (a.ws.d_out3) reinterpret_cast<float4*>(a.ws.d_out3)[p] = make_float4(d0, d1, d2, 0.f);
+      }
+      sDO[t * 4] = d0; sDO[t * 4 + 1] = d1; sDO[t * 4 + 2] = d2; sDO[t * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+    // ---- G = d_out3 * W_out  (output_linear.weight [3][128])
+    {
+      const float* wo = M + MO(PI_C_OUT);
+      for (int e = t; e < TILE * HC; e += WG) {
+        int s = e >> 7, k = e & 127;
+        sG[s * LD_C + k] = sDO[s * 4] * wo[k] + sDO[s * 4 + 1] * wo[HC + k] + sDO[s * 4 + 2] * wo[2 * HC + k];
+      }
+    }
+    __syncthreads();
+    f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};   // waves 0,1: dL/dc_col column slice
+    const int n0 = 16 * wave;
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+      // step A: dz = G * act'(y)
+      f32x4 gv = frag_load(sG, LD_C, n0), dz;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int p = p0 + g4 + r;
+        float y = (p < a.P) ? a.ws.c_y[((size_t)p * 5 + i) * HC + n0 + colw] : 0.f;
+        dz[r] = (p < a.P) ? gv[r] * softplus100_grad_from_out(y) : 0.f;
+        if (parg && p < a.P) {
+          a.ws.c_dz[((size_t)p * 5 + i) * HC + n0 + colw] = dz[r];
+          a.ws.c_g[((size_t)p * 5 + i) * HC + n0 + colw] = gv[r];
+        }
+      }
+      frag_store(sDZ, LD_HN, n0, dz);
+      // step B: dL/dc += G * Wc_i   (fc_c.i.weight [128][32])
+      if (wave < 2) dcacc += gemm16<HC>(sG, LD_C, M + MO(PI_C_FCC + 2 * i), C, n0);
+      __syncthreads();
+      // step C: dL/d(input of layer i) = dz * W_i   (pts_linears.i.weight [128][Kin])
+      f32x4 gn = {0.f, 0.f, 0.f, 0.f}, ge = {0.f, 0.f, 0.f, 0.f};
+      const float* Wi = M + MO(PI_C_L + 2 * i);
+      if (i == 3) {
+        gn = gemm16<HC>(sDZ, LD_HN, Wi, EC + HC, EC + n0);                 // h part: input cols 40..167
+        if (ptsg && wave < 3) ge = gemm16<HC>(sDZ, LD_HN, Wi, EC + HC, n0); // embedding part: cols 0..39(47)
+      } else if (i == 0) {
+        if (ptsg && wave < 3) ge = gemm16<HC>(sDZ, LD_HN, Wi, EC, n0);
+      } else {
+        gn = gemm16<HC>(sDZ, LD_HN, Wi, HC, n0);
+      }
+      __syncthreads();
+      if (i > 0) frag_store(sG, LD_C, n0, gn);
+      if ((i == 3 || i == 0) && ptsg && wave < 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n0 + colw < EC) sDEc[(g4 + r) * LD_DEC + n0 + colw] += ge[r];
+      }
+      __syncthreads();
+    }
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDCc[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
+    }
+    __syncthreads();
+
+    if (!relpos) {
+      // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
+      const int s = t >> 5, ch = t & 31;
+      float dc = sDCc[s * LD_CF + ch];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int i = sI[s * K + k];
+        float w = sW[s * K + k];
+        float gwk = 0.f;
+        if (i >= 0 && sHas[s]) {
+          if (featg && w != 0.f) {
+            int row = o.row_map ? o.row_map[i] : i;
+            if (row >= 0) atomic_add_f32(&o.g_col[(size_t)row * C + ch], w * dc);
+          }
+          if (ptsg) gwk = a.col_feats[(size_t)i * C + ch] * dc;
+        }
+        if (ptsg) {
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) gwk += __shfl_xor(gwk, off);
+          if (ch == 0) sGW[s * K + k] += gwk;
+        }
+      }
+    } else {
+      // ---- F_theta backward, one wave per 16 (sample, neighbour) rows
+      float* sDnf = sWave + wave * (16 * LD_CF + 16 * LD_HN + 16 * LD_DXN);
+      float* sDz1 = sDnf + 16 * LD_CF;
+      float* sDx = sDz1 + 16 * LD_HN;
+      // d_nf[row][ch] = w[s][k] * dC[s][ch];  dL/dw[s][k] = sum_ch nf[row][ch] dC[s][ch]
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int e = lane + 64 * j;            // 16 rows x 32 channels
+        int rl = e >> 5, ch = e & 31;
+        int row = 16 * wave + rl, s = row >> 3, k = row & 7;
+        float dc = sDCc[s * LD_CF + ch];
+        float dnf = sW[s * K + k] * dc;
+        sDnf[rl * LD_CF + ch] = dnf;
+        bool live = (p0 + s) < a.P;
+        if (parg && live) a.ws.n_dnf[((size_t)p0 * K + row) * C + ch] = dnf;
+        if (ptsg) {
+          float v = live ? a.ws.n_out[((size_t)p0 * K + row) * C + ch] * dc : 0.f;
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+          if (ch == 0) sGW[s * K + k] += v;     // one writer per (s,k): this wave owns rows 16w..16w+15
+        }
+      }
+      __syncthreads();
+      // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        f32x4 dh = gemm16<C>(sDnf, LD_CF, M + MO(PI_C_N2), HC, 16 * nt), dz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = 16 * wave + g4 + r;
+          bool live = (p0 + (row >> 3)) < a.P;
+          float h1 = live ? a.ws.n_h1[((size_t)p0 * K + row) * HC + 16 * nt + colw] : 0.f;
+          dz[r] = live ? dh[r] * softplus100_grad_from_out(h1) : 0.f;
+          if (parg && live) a.ws.n_dz1[((size_t)p0 * K + row) * HC + 16 * nt + colw] = dz[r];
+        }
+        frag_store(sDz1, LD_HN, 16 * nt, dz);
+      }
+      __syncthreads();
+      // dX1 = dz1 * W1 (linear1.weight [128][52]): columns [sin 10 | cos 10 | feat 32]
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 dx = gemm16<HC>(sDz1, LD_HN, M + MO(PI_C_N1), NX, 16 * kt);
+        frag_store(sDx, LD_DXN, 16 * kt, dx);
+      }
+      __syncthreads();
+      // feature part -> scatter into the colour feature rows
+      if (featg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int e = lane + 64 * j;
+          int rl = e >> 5, ch = e & 31;
+          int row = 16 * wave + rl;
+          int i = sI[row];
+          if (i >= 0 && sW[row] != 0.f && sHas[row >> 3]) {
+            int dst = o.row_map ? o.row_map[i] : i;
+            if (dst >= 0) atomic_add_f32(&o.g_col[(size_t)dst * C + ch], sDx[rl * LD_DXN + ER + ch]);
+          }
+        }
+      }
+      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]
+      if (lane < 16 && (parg || ptsg)) {
+        int rl = lane, row = 16 * wave + rl, s = row >> 3;
+        bool live = (p0 + s) < a.P && sI[row] >= 0;
+        const float* Brel = M + MO(PI_C_BREL);
+        float rx = sRel[row * 3], ry = sRel[row * 3 + 1], rz = sRel[row * 3 + 2];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (live) {
+#pragma unroll
+          for (int f = 0; f < ERF; ++f) {
+            float sn, cs;
+            sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), &sn, &cs);
+            float dy = sDx[rl * LD_DXN + f] * cs - sDx[rl * LD_DXN + ERF + f] * sn;
+            float dy2 = TWO_PI * dy;
+            ax += dy2 * Brel[f]; ay += dy2 * Brel[ERF + f]; az += dy2 * Brel[2 * ERF + f];
+            if (parg) {
+              atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
+              atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
+            }
+          }
+          if (ptsg) {   // rel = x_k - p  =>  dp -= d_rel
+            atomic_add_f32(&sDP[s * 4], -ax); atomic_add_f32(&sDP[s * 4 + 1], -ay); atomic_add_f32(&sDP[s * 4 + 2], -az);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ================================================================== geometry decoder
+  {
+    // G = d_occ * w_out (output_linear.weight [1][32]); d_occ flows for masked samples too (straight-through)
+    if (t < TILE * HG) {
+      int s = t >> 5, k = t & 31;
+      int p = p0 + s;
+      float docc = (p < a.P) ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+      sG[s * LD_C + k] = docc * M[MO(PI_G_OUT) + k];
+    }
+    __syncthreads();
+    f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};
+    const int n0 = 16 * wave;
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {
+      if (wave < 2) {
+        f32x4 gv = frag_load(sG, LD_C, n0), dz;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int p = p0 + g4 + r;
+          float y = (p < a.P) ? a.ws.g_y[((size_t)p * 5 + i) * HG + n0 + colw] : 0.f;
+          dz[r] = (p < a.P && y > 0.f) ? gv[r] : 0.f;       // ReLU
+        }
+        frag_store(sDZ, LD_HN, n0, dz);
+        dcacc += gemm16<HG>(sG, LD_C, M + MO(PI_G_FCC + 2 * i), C, n0);   // fc_c.i.weight [32][32]
+      }
+      __syncthreads();
+      const float* Wi = M + MO(PI_G_L + 2 * i);
+      f32x4 gx = {0.f, 0.f, 0.f, 0.f};
+      const int Kin = (i == 0) ? EG : (i == 3 ? EG + HG : HG);
+      bool act = false;
+      if (i == 3) { act = ptsg || n0 + 15 >= EG; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, EG + HG, n0); }   // 8 slices of [32][125]
+      else if (i == 0) { act = ptsg && wave < 6; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, EG, n0); }
+      else { act = wave < 2; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, HG, n0); }
+      __syncthreads();
+      if (act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int col = n0 + colw;
+          if (i == 3) {
+            if (col < EG) { if (ptsg) sDEg[(g4 + r) * LD_DE + col] += gx[r]; }
+            else if (col < Kin) sG[(g4 + r) * LD_C + col - EG] = gx[r];
+          } else if (i == 0) {
+            if (col < EG) sDEg[(g4 + r) * LD_DE + col] += gx[r];
+          } else {
+            sG[(g4 + r) * LD_C + col] = gx[r];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDCg[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
+    }
+    __syncthreads();
+    // scatter into the geometry feature rows, collect dL/dw
+    {
+      const int s = t >> 5, ch = t & 31;
+      float dc = sDCg[s * LD_CF + ch];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int i = sI[s * K + k];
+        float w = sW[s * K + k];
+        float gwk = 0.f;
+        if (i >= 0 && sHas[s]) {
+          if (featg && w != 0.f) {
+            int row = o.row_map ? o.row_map[i] : i;
+            if (row >= 0) atomic_add_f32(&o.g_geo[(size_t)row * C + ch], w * dc);
+          }
+          if (ptsg) gwk = a.geo_feats[(size_t)i * C + ch] * dc;
+        }
+        if (ptsg) {
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) gwk += __shfl_xor(gwk, off);
+          if (ch == 0) atomic_add_f32(&sGW[s * K + k], gwk);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ================================================================== position gradient
+  if (ptsg) {
+    // (1) interpolation weights: w = a/S, a = [D<=r2]/(D+1e-10), D = |x_k - p|^2   (decoder.py:143-160)
+    if (t < 128) {
+      const int s = t >> 3, k = t & 7;
+      float rx = sRel[(s * K + k) * 3], ry = sRel[(s * K + k) * 3 + 1], rz = sRel[(s * K + k) * 3 + 2];
+      float D = (sI[s * K + k] >= 0)
+                    ? __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz))
+                    : __int_as_float(0x7F800000);
+      float av = (D > sPts[s * 4 + 3]) ? 0.f : 1.0f / (D + 1e-10f);
+      float S1 = av;
+      S1 += __shfl_xor(S1, 1); S1 += __shfl_xor(S1, 2); S1 += __shfl_xor(S1, 4);
+      float gw = sHas[s] ? sGW[s * K + k] : 0.f;
+      float dot = gw * sW[s * K + k];
+      dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+      float da = (gw - dot) / fmaxf(S1, 1e-12f);
+      float dD = -da * av * av;                 // a = 1/(D+eps) -> da/dD = -a^2 ; masked slots: a = 0
+      // dD/dp = -2 (x_k - p)
+      float px = -2.f * dD * rx, py = -2.f * dD * ry, pz = -2.f * dD * rz;
+      px += __shfl_xor(px, 1); px += __shfl_xor(px, 2); px += __shfl_xor(px, 4);
+      py += __shfl_xor(py, 1); py += __shfl_xor(py, 2); py += __shfl_xor(py, 4);
+      pz += __shfl_xor(pz, 1); pz += __shfl_xor(pz, 2); pz += __shfl_xor(pz, 4);
+      if (k == 0) {
+        atomic_add_f32(&sDP[s * 4], px); atomic_add_f32(&sDP[s * 4 + 1], py); atomic_add_f32(&sDP[s * 4 + 2], pz);
+      }
+    }
+    // (2) Fourier embeddings of p: geometry sin(2pi p.B) (93), colour [sin,cos] (20+20)
+    {
+      const int s = t >> 5, l32 = t & 31;
+      const float x = sPts[s * 4], y = sPts[s * 4 + 1], z = sPts[s * 4 + 2];
+      const float* Bg = M + MO(PI_G_B);
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      for (int f = l32; f < EG; f += 32) {
+        float dy2 = TWO_PI * sDEg[s * LD_DE + f] * cosf(fourier_phase(x, y, z, Bg, EG, f));
+        ax += dy2 * Bg[f]; ay += dy2 * Bg[EG + f]; az += dy2 * Bg[2 * EG + f];
+      }
+      if (color && l32 < ECF) {
+        float sn, cs;
+        sincosf(fourier_phase(x, y, z, a.Bcol, ECF, l32), &sn, &cs);
+        float dy2 = TWO_PI * (sDEc[s * LD_DEC + l32] * cs - sDEc[s * LD_DEC + ECF + l32] * sn);
+        ax += dy2 * a.Bcol[l32]; ay += dy2 * a.Bcol[ECF + l32]; az += dy2 * a.Bcol[2 * ECF + l32];
+      }
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        ax += __shfl_xor(ax, off); ay += __shfl_xor(ay, off); az += __shfl_xor(az, off);
+      }
+      if (l32 == 0) { atomic_add_f32(&sDP[s * 4], ax); atomic_add_f32(&sDP[s * 4 + 1], ay); atomic_add_f32(&sDP[s * 4 + 2], az); }
+    }
+    __syncthreads();
+    if (t < TILE && p0 + t < a.P)
+      reinterpret_cast<float4*>(a.ws.dp)[p0 + t] = make_float4(sDP[t * 4], sDP[t * 4 + 1], sDP[t * 4 + 2], 0.f);
+  }
+  // tile-level reductions that go out with a handful of global atomics
+  if (parg && relpos && t < 3 * ERF && o.g_brel) atomic_add_f32(&o.g_brel[t], sDB[t]);
+  if ((a.flags & PSL_HAS_AFFINE) && color && t < 12 && o.g_affine) atomic_add_f32(&o.g_affine[t], sAff[t]);
+}
+
+int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g_brel, hipStream_t s);
+
+int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds = sizeof(float) * BWD_LDS_FLOATS;
+  if (!attr_set) {
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const bool color = a.flags & PSL_STAGE_COLOR;
+  if ((a.flags & PSL_FEAT_GRAD) && (!g.g_geo_feats || (color && !g.g_col_feats))) {
+    set_error("psl_render_bwd: PSL_FEAT_GRAD needs g_geo_feats/g_col_feats"); return PSL_ERR_ARG;
+  }
+  if ((a.flags & PSL_PARAM_GRAD) && !g.g_params) { set_error("psl_render_bwd: PSL_PARAM_GRAD needs g_params"); return PSL_ERR_ARG; }
+  if ((a.flags & PSL_HAS_AFFINE) && !g.g_exposure_affine) { set_error("psl_render_bwd: affine gradient buffer missing"); return PSL_ERR_ARG; }
+  BwdOut o;
+  o.g_geo = g.g_geo_feats; o.g_col = g.g_col_feats; o.row_map = g.feat_row_map;
+  // small accumulators: [0..31] dB_rel, [32..47] affine  (ctx->d_small)
+  float* small = ctx->d_small;
+  PSL_HIP(hipMemsetAsync(small, 0, sizeof(float) * 64, s));
+  o.g_brel = small;
+  o.g_affine = small + 32;
+  int tiles = (a.P + TILE - 1) / TILE;
+  {
+    ProfScope ps(ctx, PROF_DECODE_BWD, s);
+    hipLaunchKernelGGL(k_decode_bwd, dim3(tiles), dim3(WG), lds, s, a, o);
+    PSL_LAUNCH_CHECK();
+  }
+  if ((a.flags & PSL_HAS_AFFINE) && color)
+    PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
+  if (a.flags & PSL_PARAM_GRAD) {
+    ProfScope ps(ctx, PROF_DW, s);
+    int rc = launch_dw(ctx, a, g.g_params, small, s);
+    if (rc) return rc;
+  }
+  return PSL_OK;
+}
+
 }  // namespace psl

@@ -166,3 +166,168 @@ def test_render_forward_matches_reference(dev, case):
     assert rep["var_rel"] < 2e-3
     assert rep["depth_loss_rel"] < 1e-4
     assert rep["color_loss_rel"] < 1e-4
+
+
+# ------------------------------------------------------------------------------ render backward
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_render_backward_matches_reference(dev, case):
+    fx, cfg, dec, (ro, rd, geo, col, ef), (d, v, c, valid) = _run_case(case, dev, grads=True)
+    obj = (d * fx["w_d"].to(dev)).sum() + (c * fx["w_c"].to(dev)).sum() + (v * fx["w_v"].to(dev)).sum()
+    obj.backward()
+    torch.cuda.synchronize()
+    rep = dict(test="render_bwd", case=case)
+    if fx["is_tracker"]:
+        rep["g_rays_o"] = relerr(ro.grad.cpu(), fx["ref_g_rays_o"])
+        rep["g_rays_d"] = relerr(rd.grad.cpu(), fx["ref_g_rays_d"])
+    rows = fx["ref_g_geo_rows"].long()
+    gg = geo.grad.cpu()
+    rep["g_geo"] = relerr(gg[rows], fx["ref_g_geo_vals"])
+    rep["g_geo_offrows"] = float(gg.abs().sum() - gg[rows].abs().sum())
+    if fx["stage"] == "color":
+        rows = fx["ref_g_col_rows"].long()
+        gc = col.grad.cpu()
+        rep["g_col"] = relerr(gc[rows], fx["ref_g_col_vals"])
+        rep["g_col_offrows"] = float(gc.abs().sum() - gc[rows].abs().sum())
+        pg = {k: p.grad.cpu() for k, p in dec.named_parameters() if p.grad is not None}
+        worst, worst_name = 0.0, ""
+        for k in fx:
+            if k.startswith("refgp_"):
+                name = k[len("refgp_"):]
+                if name.startswith("geo_decoder"):
+                    continue        # geometry decoder is frozen in every config (point_slam.yaml:47)
+                e = relerr(pg[name], fx[k])
+                if e > worst:
+                    worst, worst_name = e, name
+            if k.startswith("refgpnorm_"):
+                name = k[len("refgpnorm_"):]
+                if name.startswith("geo_decoder"):
+                    continue
+                e = abs(float(pg[name].double().norm()) - float(fx[k])) / float(fx[k])
+                if e > worst:
+                    worst, worst_name = e, name
+        rep["g_params_worst"], rep["g_params_worst_name"] = worst, worst_name
+    if ef is not None:
+        rep["g_exposure"] = relerr(ef.grad.cpu(), fx["ref_g_exposure_feat"])
+    report(**rep)
+    for k, val in rep.items():
+        if k.startswith("g_") and not k.endswith("_name") and not k.endswith("offrows"):
+            assert val < 2e-3, (k, val)
+    assert abs(rep["g_geo_offrows"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------ point growth
+def test_add_points_matches_oracle(dev):
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import synthetic as syn
+    cfg = base_cfg()
+    cam = syn.intrinsics(320, 240)
+    g = torch.Generator().manual_seed(77)
+    npc = make_npc(cfg, torch.zeros(0, 3), torch.zeros(0, 32), torch.zeros(0, 32), dev)
+    cloud = torch.zeros(0, 3)
+    for frame in range(3):
+        c2w = syn.pose(5.0 * frame)
+        depth, color = syn.render_frame(cam, c2w)
+        r_add, _ = syn.dynamic_radii(color, cfg)
+        n = 3000
+        u = torch.randint(0, cam["W"], (n,), generator=g)
+        v = torch.randint(0, cam["H"], (n,), generator=g)
+        ro, rd = O.rays_from_uv(u.float(), v.float(), c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        dep = depth[v, u].clone()
+        dep[::17] = 0.0                                   # depth-less pixels are skipped
+        rad = r_add[v, u]
+        new_pts, keep_o, _ = O.add_points_select(cloud, ro, rd, dep, rad)
+        kept, keep_h, n_before = npc.add_neural_points(ro.to(dev), rd.to(dev).contiguous(), dep.to(dev),
+                                                       torch.zeros(n, 3, device=dev), dynamic_radius=rad.to(dev),
+                                                       return_new=True)
+        pos_mask = dep > 0
+        assert kept == int(keep_o.sum())
+        assert torch.equal(keep_h.cpu()[pos_mask], keep_o)
+        assert not keep_h.cpu()[~pos_mask].any()
+        cloud = torch.cat([cloud, new_pts])
+        got = npc.cloud_pos().cpu()
+        assert got.shape == cloud.shape and torch.equal(got, cloud)       # bit-exact positions, same order
+        assert npc.get_geo_feats().shape[0] == cloud.shape[0]
+    report(test="add_points", total=int(cloud.shape[0]))
+
+
+# ------------------------------------------------------------------------------ Adam
+def test_adam_matches_torch(dev):
+    from point_slam_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=0.005)
+    pd = p.to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    for step in range(1, 8):
+        gr = torch.randn(n, generator=g) * (0.1 if step % 2 else 3.0)
+        ref.grad = gr.clone()
+        opt.step()
+        gd = gr.to(dev)
+        _lib.check(_lib.lib().psl_adam_step(_lib.ptr(pd), _lib.ptr(gd), _lib.ptr(m), _lib.ptr(v), n, step, 0.005, 0.9,
+                                            0.999, 1e-8, 1, _lib.stream_ptr()))
+        assert float(gd.abs().max()) == 0.0
+    err = float((pd.cpu() - ref.detach()).abs().max())
+    report(test="adam", max_abs=err)
+    assert err < 2e-7
+    # row-indexed variant
+    feats = torch.randn(500, 32, generator=g)
+    rows = torch.randperm(500, generator=g)[:200].int()
+    ref2 = feats[rows.long()].clone().requires_grad_(True)
+    opt2 = torch.optim.Adam([ref2], lr=0.03)
+    fd = feats.to(dev); rd_ = rows.to(dev)
+    m2 = torch.zeros(200, 32, device=dev); v2 = torch.zeros(200, 32, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(200, 32, generator=g)
+        ref2.grad = gr.clone(); opt2.step()
+        gd = gr.to(dev).contiguous()
+        _lib.check(_lib.lib().psl_adam_step_rows(_lib.ptr(fd), _lib.ptr(rd_), _lib.ptr(gd), _lib.ptr(m2), _lib.ptr(v2),
+                                                 200, step, 0.03, 0.9, 0.999, 1e-8, 0, _lib.stream_ptr()))
+    out = fd.cpu()
+    assert float((out[rows.long()] - ref2.detach()).abs().max()) < 2e-7
+    untouched = torch.ones(500, dtype=torch.bool); untouched[rows.long()] = False
+    assert torch.equal(out[untouched], feats[untouched])
+
+
+# ------------------------------------------------------------------------------ drop-in tracker iteration
+def test_tracker_iteration_through_hip_renderer(dev):
+    """The reference's Tracker.optimize_cam_in_batch step (golden: loss + pose after one Adam step), re-run with
+    HipRenderer substituted for Renderer and everything else (sampling, loss, torch Adam) as in the reference."""
+    import types
+    from point_slam_amd import host_ops as H, synthetic as syn
+    from point_slam_amd.renderer import HipRenderer
+    fx = load_npz("tracker_iter_replica")
+    cfg = base_cfg()
+    cam = syn.intrinsics(160, 120)
+    dec = make_decoders(cfg, "replica", dev)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    npc = make_npc(cfg, fx["cloud"], fx["geo"], fx["col"], dev)
+    rend = HipRenderer(cfg, None, types.SimpleNamespace(**cam))
+    rend.sigmoid_coefficient = cfg["rendering"]["sigmoid_coef_tracker"]
+    rend.fixed_fallback = (fx["fb_geo"].to(dev), fx["fb_col"].to(dev))
+    quad = fx["cam0"][:4].to(dev).requires_grad_(True)
+    T = fx["cam0"][4:].to(dev).requires_grad_(True)
+    lr = cfg["tracking"]["lr"]
+    opt = torch.optim.Adam([{"params": [T], "lr": lr}, {"params": [quad], "lr": lr * 0.2}])
+    c2w = H.get_camera_from_tensor(torch.cat([quad, T]))
+    u, v = H.pixels_from_flat_index(fx["pix_idx"].long().to(dev), 20, cam["H"] - 20, 20, cam["W"] - 20)
+    ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    depth_img, color_img, rq_img = fx["depth_img"].to(dev), fx["color_img"].to(dev).double(), fx["rq_img"].to(dev)
+    gd, gc, rq = depth_img[v.long(), u.long()], color_img[v.long(), u.long()], rq_img[v.long(), u.long()]
+    keep = gd > 0
+    ro, rd, gd, gc, rq = ro[keep], rd[keep], gd[keep], gc[keep], rq[keep]
+    inl = H.depth_inlier_mask(gd)
+    ro, rd, gd, gc, rq = ro[inl], rd[inl], gd[inl], gc[inl], rq[inl]
+    d, var, rgb, _ = rend.render_batch_ray(npc, dec, rd, ro, dev, "color", gt_depth=gd, npc_geo_feats=fx["geo"].to(dev),
+                                           npc_col_feats=fx["col"].to(dev), is_tracker=True, dynamic_r_query=rq)
+    loss, geo, colr, mask = H.tracker_loss(d, var, rgb, gd, gc)
+    loss.backward()
+    opt.step()
+    rel = abs(float(loss) - fx["ref_loss"]) / fx["ref_loss"]
+    dq = float((quad.detach().cpu() - fx["ref_quad_after"]).abs().max())
+    dT = float((T.detach().cpu() - fx["ref_T_after"]).abs().max())
+    report(test="tracker_iter", loss_rel=rel, dq=dq, dT=dT)
+    assert rel < 1e-4                     # BASELINE.json: render-loss rel-err <= 1e-4
+    # one Adam step moves each parameter by ~lr*sign(grad): equality means every gradient SIGN matches
+    assert dq < 1e-6 and dT < 1e-6
