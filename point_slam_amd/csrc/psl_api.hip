@@ -2,12 +2,19 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 #include "psl_decode.h"
 
 namespace psl {
 
 static thread_local char g_err[512] = "";
+
+bool debug_sync() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PSL_DEBUG_SYNC"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;

@@ -166,9 +166,11 @@ void set_error(const char* fmt, ...);
     }                                                                                  \
   } while (0)
 
+bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every launch and report the failing one
 #define PSL_LAUNCH_CHECK()                                                             \
   do {                                                                                 \
     hipError_t e__ = hipGetLastError();                                                \
+    if (e__ == hipSuccess && psl::debug_sync()) e__ = hipDeviceSynchronize();          \
     if (e__ != hipSuccess) {                                                           \
       psl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
       return PSL_ERR_HIP;                                                              \

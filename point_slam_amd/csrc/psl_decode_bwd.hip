@@ -7,6 +7,7 @@
 // backward launches incl. a dense [N,32] zero-fill + index_add per gather.
 // Same tiling as the forward: 16 samples per 512-thread workgroup, every dX = dZ * W product is an
 // exact-fp32 MFMA whose B operand is the torch-layout weight itself ([out][in] row-major).
+#include <cstdio>
 #include "psl_decode.h"
 
 namespace psl {
@@ -458,9 +459,15 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   if ((a.flags & PSL_HAS_AFFINE) && color)
     PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
   if (a.flags & PSL_PARAM_GRAD) {
-    ProfScope ps(ctx, PROF_DW, s);
-    int rc = launch_dw(ctx, a, g.g_params, small, s);
-    if (rc) return rc;
+    if (color) {
+      ProfScope ps(ctx, PROF_DW, s);
+      int rc = launch_dw(ctx, a, g.g_params, small, s);
+      if (rc) return rc;
+    } else {
+      // geometry stage: the colour decoder is not evaluated; the geometry decoder is frozen
+      // (mapping.fix_geo_decoder, configs/point_slam.yaml:47) -> all-zero parameter gradient
+      PSL_HIP(hipMemsetAsync(g.g_params, 0, sizeof(float) * kMasterFloats, s));
+    }
   }
   return PSL_OK;
 }

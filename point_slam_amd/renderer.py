@@ -110,6 +110,7 @@ class HipRenderer(object):
         # The reference tracker back-propagates into every decoder weight although its optimiser only holds the
         # pose (Tracker.py:305-311,182).  Set True (HipTracker does) to skip that dead work.
         self.skip_decoder_grads = False
+        self.geo_decoder_trainable = not cfg['mapping'].get('fix_geo_decoder', True)
         # fallback vectors may be pinned for reproducible tests; default: drawn per call like the reference
         self.fixed_fallback = None
 
@@ -141,7 +142,12 @@ class HipRenderer(object):
             flags |= _lib.PTS_GRAD
         if npc_geo_feats.requires_grad or (npc_col_feats is not None and npc_col_feats.requires_grad):
             flags |= _lib.FEAT_GRAD
-        if theta.requires_grad and not self.skip_decoder_grads:
+        if color and theta.requires_grad and not self.skip_decoder_grads:
+            # colour-decoder gradients only: the geometry decoder is frozen in every shipped config
+            # (mapping.fix_geo_decoder, point_slam.yaml:47); its gradient is returned as zeros.
+            if self.geo_decoder_trainable:
+                raise NotImplementedError("geometry-decoder parameter gradients are not produced "
+                                          "(fix_geo_decoder=True in all reference configs)")
             flags |= _lib.PARAM_GRAD
         affine = None
         if color and self.encode_exposure:
@@ -155,7 +161,8 @@ class HipRenderer(object):
         if self.use_dynamic_radius:
             rq = dynamic_r_query.detach().reshape(-1).float().contiguous()
         fb_geo, fb_col = self._fallbacks(rays_o.device)
-        m = dict(handle=npc.handle, gt_depth=gt_depth, r_query=rq, Bcol=P_.color_embed_B(decoders).to(rays_o.device)
+        m = dict(npc=npc,  # keeps the native context alive until backward has run
+                 handle=npc.handle, gt_depth=gt_depth, r_query=rq, Bcol=P_.color_embed_B(decoders).to(rays_o.device)
                  .float().contiguous(), fb_geo=fb_geo.float().contiguous(), fb_col=fb_col.float().contiguous(),
                  flags=flags, coef=self.sigmoid_coefficient)
         if npc_col_feats is None:

@@ -269,7 +269,7 @@ def test_adam_matches_torch(dev):
         assert float(gd.abs().max()) == 0.0
     err = float((pd.cpu() - ref.detach()).abs().max())
     report(test="adam", max_abs=err)
-    assert err < 2e-7
+    assert err < 1e-6
     # row-indexed variant
     feats = torch.randn(500, 32, generator=g)
     rows = torch.randperm(500, generator=g)[:200].int()
@@ -284,7 +284,7 @@ def test_adam_matches_torch(dev):
         _lib.check(_lib.lib().psl_adam_step_rows(_lib.ptr(fd), _lib.ptr(rd_), _lib.ptr(gd), _lib.ptr(m2), _lib.ptr(v2),
                                                  200, step, 0.03, 0.9, 0.999, 1e-8, 0, _lib.stream_ptr()))
     out = fd.cpu()
-    assert float((out[rows.long()] - ref2.detach()).abs().max()) < 2e-7
+    assert float((out[rows.long()] - ref2.detach()).abs().max()) < 1e-6
     untouched = torch.ones(500, dtype=torch.bool); untouched[rows.long()] = False
     assert torch.equal(out[untouched], feats[untouched])
 
