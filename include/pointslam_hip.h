@@ -178,6 +178,79 @@ int psl_adam_step(float* p, float* g, float* m, float* v, int64_t n, int step, f
 int psl_adam_step_rows(float* feats, const int32_t* rows, float* g, float* m, float* v, int n_rows, int step,
                        float lr, float beta1, float beta2, float eps, int zero_grad, void* stream);
 
+/* ---- fused optimisation loops (no host synchronisation inside) -------------------------------
+ * The bodies of the reference's per-frame loops, run n_iters times back-to-back on `stream`:
+ *   psl_track_iters : Tracker.optimize_cam_in_batch (src/Tracker.py:89-186) inside the loop of
+ *                     Tracker.run (src/Tracker.py:332-350, incl. the lowest-loss candidate pose);
+ *   psl_map_iters   : the joint_iter loop of Mapper.optimize_map (src/Mapper.py:408-568), without BA and
+ *                     without per-frame exposure.
+ * Random draws stay with the host (torch RNG): flat pixel indices as torch.randint would produce them in
+ * select_uv (src/common.py:59-74) and the per-call fallback vectors (decoder.py:170,387), pre-drawn for
+ * all iterations. */
+typedef struct psl_cam_intr { int32_t H, W; float fx, fy, cx, cy; } psl_cam_intr;
+
+typedef struct psl_frame_view {     /* one RGB-D (key)frame resident in device memory */
+  const float* depth;               /* [H][W] f32, 0 = no reading */
+  const float* color;               /* [H][W][3] f32 */
+  const float* r_query;             /* [H][W] per-pixel query radius, or NULL (fixed radius) */
+  float c2w[12];                    /* row-major 3x4 pose (mapping only) */
+} psl_frame_view;
+
+typedef struct psl_track_args {
+  psl_cam_intr cam;
+  int32_t edge_h, edge_w;           /* tracking.ignore_edge_H/W */
+  int32_t n_iters, n_pix;           /* tracking.iters, tracking.pixels (n_pix <= 16384) */
+  const int32_t* pix_idx;           /* [n_iters][n_pix] indices into the cropped window, row-major */
+  const float* fallback;            /* [n_iters][2][32] geometry / colour fallback vectors */
+  psl_frame_view frame;
+  float* cam_tensor;                /* [7] quaternion (w,x,y,z) + translation; updated in place */
+  float* adam_state;                /* [14] exp_avg[7], exp_avg_sq[7]; zero at frame start */
+  int32_t step0;                    /* Adam steps already taken on this state */
+  float lr_T, lr_quat;              /* tracking.lr, 0.2*tracking.lr (separate_LR, Tracker.py:305-306) */
+  float w_color;                    /* tracking.w_color_loss */
+  int32_t handle_dynamic, use_color;
+  float sigmoid_coef;
+  const float *geo_feats, *col_feats, *params, *col_embed_B;
+  float* ws;                        /* psl_track_ws_floats(n_pix) floats */
+  float* loss_out;                  /* [n_iters][4] (loss, geo, colour, #active) or NULL */
+  float* best_out;                  /* [8] lowest-loss pose [7] + its loss (candidate_cam_tensor, Tracker.py:347-350) */
+} psl_track_args;
+int64_t psl_track_ws_floats(int n_pix);
+int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stream);
+
+typedef struct psl_map_args {
+  psl_cam_intr cam;
+  int32_t n_frames, pix_per_frame;  /* window size, mapping.pixels // window (n_frames*pix_per_frame <= 16384) */
+  int32_t n_iters, n_geo_iters;     /* iterations; iterations 0..n_geo_iters run stage 'geometry' (Mapper.py:420-423) */
+  const psl_frame_view* frames;     /* [n_frames] HOST array of device frame views */
+  const int32_t* pix_idx;           /* [n_iters][n_frames][pix_per_frame] */
+  const float* fallback;            /* [n_iters][2][32] */
+  float* geo_feats;                 /* [N][32] updated in place at rows sel_rows */
+  float* col_feats;
+  float* params;                    /* master blob; colour group updated in place when train_decoder */
+  const float* col_embed_B;
+  const int32_t* sel_rows;          /* [n_sel] frustum-selected point indices (ascending) */
+  const int32_t* row_map;           /* [N] point index -> compact row or -1 */
+  int32_t n_sel;
+  float *g_geo, *g_col;             /* [n_sel][32] compact gradient accumulators, zero on entry */
+  float *adam_geo, *adam_col;       /* [2][n_sel][32] exp_avg, exp_avg_sq; zero at frame start */
+  float* adam_params;               /* [2][colour floats] */
+  int32_t step0_geo, step0_col;
+  int32_t train_decoder;            /* !mapping.fix_color_decoder */
+  float lr_geo_geo_stage, lr_geo_color_stage, lr_col, lr_decoder;   /* mapping.stage.* learning rates */
+  float w_color, sigmoid_coef;
+  float* ws;                        /* psl_map_ws_floats() floats */
+  float* loss_out;                  /* [n_iters][4] or NULL */
+} psl_map_args;
+int64_t psl_map_ws_floats(int n_rays, int n_frames);
+int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream);
+
+/* Mapper.get_mask_from_c2w (src/Mapper.py:120-168): frustum feature selection.  c2w_host: [16] row-major 4x4
+ * (host memory).  Writes the ascending index list sel_out[<=N] and row_map_out[N]; synchronises and returns
+ * the count.  depth_max = max of the depth image (:161-162). */
+int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host, psl_cam_intr cam, const float* depth, float depth_max,
+                            float edge, int32_t* sel_out, int32_t* row_map_out, int* n_sel_host, void* stream);
+
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);
 /* last kernel-time breakdown collected when profiling is enabled (ms per kernel class) */

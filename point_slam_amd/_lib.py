@@ -38,6 +38,37 @@ class psl_render_grads(C.Structure):
                 ("g_exposure_affine", C.c_void_p)]
 
 
+class psl_cam_intr(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float)]
+
+
+class psl_frame_view(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("r_query", C.c_void_p), ("c2w", C.c_float * 12)]
+
+
+class psl_track_args(C.Structure):
+    _fields_ = [("cam", psl_cam_intr), ("edge_h", C.c_int32), ("edge_w", C.c_int32), ("n_iters", C.c_int32),
+                ("n_pix", C.c_int32), ("pix_idx", C.c_void_p), ("fallback", C.c_void_p), ("frame", psl_frame_view),
+                ("cam_tensor", C.c_void_p), ("adam_state", C.c_void_p), ("step0", C.c_int32), ("lr_T", C.c_float),
+                ("lr_quat", C.c_float), ("w_color", C.c_float), ("handle_dynamic", C.c_int32),
+                ("use_color", C.c_int32), ("sigmoid_coef", C.c_float), ("geo_feats", C.c_void_p),
+                ("col_feats", C.c_void_p), ("params", C.c_void_p), ("col_embed_B", C.c_void_p), ("ws", C.c_void_p),
+                ("loss_out", C.c_void_p), ("best_out", C.c_void_p)]
+
+
+class psl_map_args(C.Structure):
+    _fields_ = [("cam", psl_cam_intr), ("n_frames", C.c_int32), ("pix_per_frame", C.c_int32), ("n_iters", C.c_int32),
+                ("n_geo_iters", C.c_int32), ("frames", C.POINTER(psl_frame_view)), ("pix_idx", C.c_void_p),
+                ("fallback", C.c_void_p), ("geo_feats", C.c_void_p), ("col_feats", C.c_void_p), ("params", C.c_void_p),
+                ("col_embed_B", C.c_void_p), ("sel_rows", C.c_void_p), ("row_map", C.c_void_p), ("n_sel", C.c_int32),
+                ("g_geo", C.c_void_p), ("g_col", C.c_void_p), ("adam_geo", C.c_void_p), ("adam_col", C.c_void_p),
+                ("adam_params", C.c_void_p), ("step0_geo", C.c_int32), ("step0_col", C.c_int32),
+                ("train_decoder", C.c_int32), ("lr_geo_geo_stage", C.c_float), ("lr_geo_color_stage", C.c_float),
+                ("lr_col", C.c_float), ("lr_decoder", C.c_float), ("w_color", C.c_float), ("sigmoid_coef", C.c_float),
+                ("ws", C.c_void_p), ("loss_out", C.c_void_p)]
+
+
 # psl_render_flags
 STAGE_COLOR, PTS_GRAD, PARAM_GRAD, FEAT_GRAD, NO_SIGMOID, HAS_AFFINE = 1, 2, 4, 8, 16, 32
 
@@ -69,6 +100,12 @@ _SIGS = {
                                 C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "psl_adam_step_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "psl_track_ws_floats": (C.c_int64, [C.c_int]),
+    "psl_track_iters": (C.c_int, [C.c_void_p, C.POINTER(psl_track_args), C.c_void_p]),
+    "psl_map_ws_floats": (C.c_int64, [C.c_int, C.c_int]),
+    "psl_map_iters": (C.c_int, [C.c_void_p, C.POINTER(psl_map_args), C.c_void_p]),
+    "psl_frustum_select_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), psl_cam_intr, C.c_void_p, C.c_float,
+                                          C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "psl_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),

@@ -184,15 +184,15 @@ extern "C" int64_t psl_render_ws_floats(int n_rays, int flags) {
   return carve_ws(nullptr, n_rays, flags | 0x10000).total;
 }
 
-extern "C" int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream) {
+namespace psl {
+int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool repack) {
   int rc = check_render_args(ctx, a, "psl_render_fwd");
   if (rc) return rc;
   if (!a->depth || !a->var || !a->rgb) { set_error("psl_render_fwd: missing output pointer"); return PSL_ERR_ARG; }
   if (a->n_rays == 0) return PSL_OK;
-  hipStream_t s = (hipStream_t)stream;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
-  { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
+  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
   { ProfScope ps(ctx, PROF_KNN, s);
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
@@ -205,7 +205,7 @@ extern "C" int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stre
   return PSL_OK;
 }
 
-extern "C" int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, void* stream) {
+int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s) {
   int rc = check_render_args(ctx, a, "psl_render_bwd");
   if (rc) return rc;
   if (!g || !g->g_depth) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
@@ -213,7 +213,6 @@ extern "C" int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_
     set_error("psl_render_bwd: forward was run without any gradient flag"); return PSL_ERR_STATE;
   }
   if (a->n_rays == 0) return PSL_OK;
-  hipStream_t s = (hipStream_t)stream;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
   { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s);
@@ -228,6 +227,14 @@ extern "C" int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_
     if (rc) return rc;
   }
   return PSL_OK;
+}
+}  // namespace psl
+
+extern "C" int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream) {
+  return render_fwd_impl(ctx, a, (hipStream_t)stream, true);
+}
+extern "C" int psl_render_bwd(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, void* stream) {
+  return render_bwd_impl(ctx, a, g, (hipStream_t)stream);
 }
 
 extern "C" int psl_sync(psl_ctx* ctx, void* stream) {

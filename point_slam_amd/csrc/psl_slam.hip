@@ -1,0 +1,609 @@
+// Fused optimisation loops: the bodies of Tracker.optimize_cam_in_batch (src/Tracker.py:89-186, loop :332-371)
+// and of the Mapper.optimize_map inner loop (src/Mapper.py:408-568) as back-to-back kernel launches with NO
+// host synchronisation: pixel gather + ray set-up, depth-outlier mask (lower median), render forward, loss +
+// cotangents, render backward, pose / feature / decoder Adam.  The reference pays ~2000 ATen launches, three
+// .item() syncs and an RPC-ed FAISS search per iteration for the same work.
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "psl_decode.h"
+
+namespace psl {
+
+int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool repack);
+int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s);
+
+// quad2rotation (src/common.py:225-248), same operation order
+__device__ __forceinline__ void quat_to_rot(const float* q, float R[3][3]) {
+  float qr = q[0], qi = q[1], qj = q[2], qk = q[3];
+  float two_s = 2.0f / (((qr * qr + qi * qi) + qj * qj) + qk * qk);
+  R[0][0] = 1.f - two_s * (qj * qj + qk * qk);
+  R[0][1] = two_s * (qi * qj - qk * qr);
+  R[0][2] = two_s * (qi * qk + qj * qr);
+  R[1][0] = two_s * (qi * qj + qk * qr);
+  R[1][1] = 1.f - two_s * (qi * qi + qk * qk);
+  R[1][2] = two_s * (qj * qk - qi * qr);
+  R[2][0] = two_s * (qi * qk - qj * qr);
+  R[2][1] = two_s * (qj * qk + qi * qr);
+  R[2][2] = 1.f - two_s * (qi * qi + qj * qj);
+}
+
+struct FrameDev {            // one RGB-D frame resident in HBM
+  const float* depth;        // [H][W]
+  const float* color;        // [H][W][3]
+  const float* r_query;      // [H][W] or null
+  float c2w[12];             // row-major 3x4
+};
+
+struct RayBufs {             // per-iteration ray batch (n slots, inactive slots masked)
+  float *rays_o, *rays_d, *dirs, *gd, *gc, *rq;
+  int* active;
+  float *depth, *var, *rgb;  // render outputs
+  unsigned char* valid;
+  float *g_depth, *g_rgb, *g_o, *g_d;
+};
+
+// get_samples + get_rays_from_uv (src/common.py:40-89,162-183) for pre-drawn flat pixel indices.
+// cam_tensor != null: pose from (quat, T) (tracker); else from frames[f].c2w (mapper).
+__global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int H1, int W0, int W1,
+                                                   const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
+                                                   const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
+                                                   RayBufs b) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = n_frames * pix_per_frame;
+  if (i >= n) return;
+  int f = i / pix_per_frame;
+  const FrameDev& fr = frames[f];
+  float R[3][3], T[3];
+  if (cam_tensor) {
+    quat_to_rot(cam_tensor, R);
+    T[0] = cam_tensor[4]; T[1] = cam_tensor[5]; T[2] = cam_tensor[6];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { R[a][0] = fr.c2w[a * 4]; R[a][1] = fr.c2w[a * 4 + 1]; R[a][2] = fr.c2w[a * 4 + 2]; T[a] = fr.c2w[a * 4 + 3]; }
+  }
+  int idx = pix_idx[i];
+  int w = W1 - W0;
+  int u = W0 + idx % w, v = H0 + idx / w;
+  float d0 = ((float)u - cam.cx) / cam.fx, d1 = -((float)v - cam.cy) / cam.fy, d2 = -1.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    b.rays_d[i * 3 + a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
+    b.rays_o[i * 3 + a] = T[a];
+  }
+  b.dirs[i * 3] = d0; b.dirs[i * 3 + 1] = d1; b.dirs[i * 3 + 2] = d2;
+  size_t px = (size_t)v * cam.W + u;
+  float dep = fr.depth[px];
+  b.gc[i * 3] = fr.color[px * 3]; b.gc[i * 3 + 1] = fr.color[px * 3 + 1]; b.gc[i * 3 + 2] = fr.color[px * 3 + 2];
+  if (b.rq) b.rq[i] = fr.r_query ? fr.r_query[px] : 0.f;
+  bool act = dep > 0.f;                      // depth_filter (common.py:173-179)
+  b.active[i] = act ? 1 : 0;
+  b.gd[i] = act ? dep : 1.0f;                // inactive slots get a harmless finite depth
+}
+
+// inside_mask = d <= min(10*median(d), 1.2*max(d)) over the ACTIVE rays; torch.median = lower median
+// (Tracker.py:142-144, Mapper.py:507-509).  One workgroup, bitonic sort in LDS (n <= 16384).
+__global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
+  extern __shared__ __attribute__((aligned(16))) float sk[];
+  __shared__ int s_cnt;
+  int npow = 1;
+  while (npow < n) npow <<= 1;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const float INF = __int_as_float(0x7F800000);
+  int local = 0;
+  for (int i = threadIdx.x; i < npow; i += blockDim.x) {
+    bool a = i < n && active[i];
+    sk[i] = a ? gd[i] : INF;
+    local += a ? 1 : 0;
+  }
+  atomicAdd(&s_cnt, local);
+  __syncthreads();
+  for (int k = 2; k <= npow; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow; i += blockDim.x) {
+        int l = i ^ j;
+        if (l > i) {
+          float a = sk[i], c = sk[l];
+          bool up = (i & k) == 0;
+          if ((a > c) == up) { sk[i] = c; sk[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int cnt = s_cnt;
+  if (cnt == 0) return;
+  float med = sk[(cnt - 1) >> 1];
+  float mx = sk[cnt - 1];
+  float thr = fminf(10.0f * med, 1.2f * mx);
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (active[i] && !(gd[i] <= thr)) active[i] = 0;
+}
+
+__device__ __forceinline__ float signf0(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// block-wide sum of doubles (1024 threads)
+__device__ __forceinline__ double block_sum_d(double v, double* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += lds[i];
+  return t;
+}
+
+// Tracker loss + cotangents (Tracker.py:159-180): uncertainty-weighted L1 depth + w*L1 colour,
+// mask = (tmp < 10*mean(tmp)) & (gt>0) & ~nan.  Keeps the best (lowest-loss) pose (Tracker.py:347-350).
+__global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w_color, int handle_dynamic, int use_color,
+                                                       const float* __restrict__ cam_tensor, float* best /*[8]*/,
+                                                       float* loss_out /*[4]*/) {
+  __shared__ double lds[16];
+  __shared__ float s_thr;
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (b.active[i]) {
+      float e = fabsf(b.gd[i] - b.depth[i]);
+      if (handle_dynamic) e = e / sqrtf(b.var[i] + 1e-10f);
+      s += (double)e; c += 1.0;
+    }
+  }
+  double tot = block_sum_d(s, lds);
+  double cnt = block_sum_d(c, lds);
+  // handle_dynamic=False uses the median instead (Tracker.py:167-168): not used by any shipped config
+  if (threadIdx.x == 0) s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f;
+  __syncthreads();
+  float thr = s_thr;
+  double lg = 0.0, lc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (b.active[i]) {
+      float d = b.depth[i], u = b.var[i], gt = b.gd[i];
+      float inv = 1.0f / sqrtf(u + 1e-10f);
+      float diff = fabsf(gt - d);
+      float tmp = handle_dynamic ? diff / sqrtf(u + 1e-10f) : diff;
+      bool m = (tmp < thr) && (gt > 0.f) && (d == d) && (u == u);
+      if (m) {
+        float e = diff / sqrtf(u + 1e-10f);
+        float ec = fminf(fmaxf(e, 0.f), 1e3f);
+        lg += (double)ec;
+        if (e <= 1e3f) gdp = signf0(d - gt) * inv;
+        float r0 = b.rgb[i * 3], r1 = b.rgb[i * 3 + 1], r2 = b.rgb[i * 3 + 2];
+        float c0 = b.gc[i * 3], c1 = b.gc[i * 3 + 1], c2 = b.gc[i * 3 + 2];
+        lc += (double)fabsf(c0 - r0) + (double)fabsf(c1 - r1) + (double)fabsf(c2 - r2);
+        if (use_color) { g0 = w_color * signf0(r0 - c0); g1 = w_color * signf0(r1 - c1); g2 = w_color * signf0(r2 - c2); }
+      }
+    }
+    b.g_depth[i] = gdp;
+    b.g_rgb[i * 3] = g0; b.g_rgb[i * 3 + 1] = g1; b.g_rgb[i * 3 + 2] = g2;
+  }
+  double Lg = block_sum_d(lg, lds);
+  double Lc = block_sum_d(lc, lds);
+  if (threadIdx.x == 0) {
+    double L = use_color ? Lg + (double)w_color * Lc : Lg;
+    loss_out[0] = (float)L; loss_out[1] = (float)Lg; loss_out[2] = (float)Lc; loss_out[3] = (float)cnt;
+    if ((float)L < best[7]) {
+      best[7] = (float)L;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) best[j] = cam_tensor[j];
+    }
+  }
+}
+
+// Mapper loss + cotangents (Mapper.py:524-553): mask = (gt>0) & valid_ray & ~nan(depth); L1 depth (+ w * L1 colour)
+__global__ __launch_bounds__(1024) void k_mapper_loss(RayBufs b, int n, float w_color, int color_stage, float* loss_out) {
+  __shared__ double lds[16];
+  double lg = 0.0, lc = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (b.active[i]) {
+      float d = b.depth[i], gt = b.gd[i];
+      bool m = (gt > 0.f) && b.valid[i] && (d == d);
+      if (m) {
+        lg += (double)fabsf(gt - d);
+        gdp = signf0(d - gt);
+        c += 1.0;
+        if (color_stage) {
+          float r0 = b.rgb[i * 3], r1 = b.rgb[i * 3 + 1], r2 = b.rgb[i * 3 + 2];
+          float c0 = b.gc[i * 3], c1 = b.gc[i * 3 + 1], c2 = b.gc[i * 3 + 2];
+          lc += (double)fabsf(c0 - r0) + (double)fabsf(c1 - r1) + (double)fabsf(c2 - r2);
+          g0 = w_color * signf0(r0 - c0); g1 = w_color * signf0(r1 - c1); g2 = w_color * signf0(r2 - c2);
+        }
+      }
+    }
+    b.g_depth[i] = gdp;
+    b.g_rgb[i * 3] = g0; b.g_rgb[i * 3 + 1] = g1; b.g_rgb[i * 3 + 2] = g2;
+  }
+  double Lg = block_sum_d(lg, lds);
+  double Lc = block_sum_d(lc, lds);
+  double cnt = block_sum_d(c, lds);
+  if (threadIdx.x == 0) {
+    loss_out[0] = (float)(color_stage ? Lg + (double)w_color * Lc : Lg);
+    loss_out[1] = (float)Lg; loss_out[2] = (float)Lc; loss_out[3] = (float)cnt;
+  }
+}
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, int step) {
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  m = m + (1.0f - b1) * (g - m);
+  v = v * b2 + ((1.0f - b2) * g) * g;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  float denom = sqrtf(v) / (float)sqrt(bc2) + eps;
+  p = p + ((-(float)((double)lr / bc1)) * m) / denom;
+}
+
+// d(loss)/d(pose) from the per-ray gradients, analytic quaternion chain, Adam on (T: lr, quat: 0.2 lr)
+// (Tracker.py:305-311,323,183; get_camera_from_tensor common.py:251-267).
+__global__ __launch_bounds__(256) void k_pose_step(RayBufs b, int n, float* cam_tensor, float* adam_mv /*[14]*/, int step,
+                                                   float lr_T, float lr_q) {
+  __shared__ float lds[4][12];
+  float acc[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float d0 = b.dirs[i * 3], d1 = b.dirs[i * 3 + 1], d2 = b.dirs[i * 3 + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float g = b.g_d[i * 3 + a];
+      acc[a * 3 + 0] += d0 * g; acc[a * 3 + 1] += d1 * g; acc[a * 3 + 2] += d2 * g;   // dL/dR[a][k]
+      acc[9 + a] += b.g_o[i * 3 + a];                                                  // dL/dT[a]
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+  }
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) lds[w][j] = acc[j];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float G[3][3], gT[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) G[a][k] = lds[0][a * 3 + k] + lds[1][a * 3 + k] + lds[2][a * 3 + k] + lds[3][a * 3 + k];
+    gT[a] = lds[0][9 + a] + lds[1][9 + a] + lds[2][9 + a] + lds[3][9 + a];
+  }
+  float qr = cam_tensor[0], qi = cam_tensor[1], qj = cam_tensor[2], qk = cam_tensor[3];
+  float nn = qr * qr + qi * qi + qj * qj + qk * qk;
+  float s = 2.0f / nn;
+  // R = I + s*M(q)
+  float M[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr},
+                   {qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr},
+                   {qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)}};
+  float GM = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) GM += G[a][k] * M[a][k];
+  float dMr = G[0][1] * (-qk) + G[0][2] * qj + G[1][0] * qk + G[1][2] * (-qi) + G[2][0] * (-qj) + G[2][1] * qi;
+  float dMi = G[0][1] * qj + G[0][2] * qk + G[1][0] * qj + G[1][1] * (-2.f * qi) + G[1][2] * (-qr) + G[2][0] * qk +
+              G[2][1] * qr + G[2][2] * (-2.f * qi);
+  float dMj = G[0][0] * (-2.f * qj) + G[0][1] * qi + G[0][2] * qr + G[1][0] * qi + G[1][2] * qk + G[2][0] * (-qr) +
+              G[2][1] * qk + G[2][2] * (-2.f * qj);
+  float dMk = G[0][0] * (-2.f * qk) + G[0][1] * (-qr) + G[0][2] * qi + G[1][0] * qr + G[1][1] * (-2.f * qk) +
+              G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
+  float ds = -s * s;   // d s / d q_x = -s^2 q_x
+  float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, step);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, step);
+}
+
+// ------------------------------------------------------------------ frustum feature selection
+// Mapper.get_mask_from_c2w (src/Mapper.py:120-168): project every neural point with the frame pose, bilinear
+// sensor-depth lookup (cv2.remap INTER_LINEAR, constant-0 border), keep points inside the (edge-enlarged) image
+// whose camera depth lies in [0, depth+0.5].  Zero depths are replaced by the image maximum (:161-162).
+__global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
+                                                       psl_cam_intr cam, const float* __restrict__ depth, float depth_max,
+                                                       float edge, int* __restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pos[i];
+  double x = (double)w2c[0] * p.x + (double)w2c[1] * p.y + (double)w2c[2] * p.z + (double)w2c[3];
+  double y = (double)w2c[4] * p.x + (double)w2c[5] * p.y + (double)w2c[6] * p.z + (double)w2c[7];
+  double zc = (double)w2c[8] * p.x + (double)w2c[9] * p.y + (double)w2c[10] * p.z + (double)w2c[11];
+  x = -x;                                  // cam_cord[:, 0] *= -1
+  double z = zc + 1e-5;
+  float u = (float)(((double)cam.fx * x + (double)cam.cx * zc) / z);
+  float v = (float)(((double)cam.fy * y + (double)cam.cy * zc) / z);
+  float u0 = floorf(u), v0 = floorf(v);
+  float fu = u - u0, fv = v - v0;
+  float d = 0.f;
+#pragma unroll
+  for (int dv = 0; dv < 2; ++dv)
+#pragma unroll
+    for (int du = 0; du < 2; ++du) {
+      int uu = (int)u0 + du, vv = (int)v0 + dv;
+      bool ok = uu >= 0 && uu < cam.W && vv >= 0 && vv < cam.H;
+      float val = ok ? depth[(size_t)vv * cam.W + uu] : 0.f;
+      d += val * (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
+    }
+  if (d == 0.f) d = depth_max;
+  bool inb = (u < (float)cam.W - edge) && (u > edge) && (v < (float)cam.H - edge) && (v > edge);
+  float mz = (float)(-z);
+  flags[i] = (inb && mz >= 0.f && mz <= d + 0.5f) ? 1 : 0;
+}
+
+// ordered compaction of flags -> sel[n_sel] (ascending point index) and row_map[n] (-1 = not selected)
+__global__ __launch_bounds__(256) void k_flag_block_sums(const int* __restrict__ flags, int n, int* block_sums) {
+  int base = blockIdx.x * 1024;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { int i = base + threadIdx.x * 4 + j; if (i < n) s += flags[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ int l[4];
+  if ((threadIdx.x & 63) == 0) l[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = l[0] + l[1] + l[2] + l[3];
+}
+
+__global__ __launch_bounds__(1024) void k_flag_scan_top(int* block_sums, int nblocks, int* total_out) {
+  // sequential-in-chunks exclusive scan by one workgroup (nblocks <= 16384)
+  __shared__ int carry;
+  __shared__ int wsum[16];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = (i < nblocks) ? block_sums[i] : 0;
+    int x = v;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int off = carry;
+    for (int j = 0; j < w; ++j) off += wsum[j];
+    if (i < nblocks) block_sums[i] = off + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = off + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_flag_compact(const int* __restrict__ flags, int n, const int* __restrict__ block_off,
+                                                      int* __restrict__ sel, int* __restrict__ row_map) {
+  __shared__ int l[4];
+  int base = blockIdx.x * 1024;
+  int f[4]; int s = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { int i = base + threadIdx.x * 4 + j; f[j] = (i < n) ? flags[i] : 0; s += f[j]; }
+  int x = s;
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int y = __shfl_up(x, o); if (lane >= o) x += y; }
+  if (lane == 63) l[w] = x;
+  __syncthreads();
+  int off = block_off[blockIdx.x];
+  for (int j = 0; j < w; ++j) off += l[j];
+  off += x - s;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int i = base + threadIdx.x * 4 + j;
+    if (i < n) {
+      if (f[j]) { sel[off] = i; row_map[i] = off; ++off; }
+      else row_map[i] = -1;
+    }
+  }
+}
+
+}  // namespace psl
+
+using namespace psl;
+
+// ---------------------------------------------------------------------------------------------- C ABI
+static RayBufs carve_rays(float*& p, int n) {
+  RayBufs b;
+  auto take = [&](size_t k) { float* r = p; p += (k + 3) / 4 * 4; return r; };
+  b.rays_o = take(3 * (size_t)n); b.rays_d = take(3 * (size_t)n); b.dirs = take(3 * (size_t)n);
+  b.gd = take(n); b.gc = take(3 * (size_t)n); b.rq = take(n); b.active = (int*)take(n);
+  b.depth = take(n); b.var = take(n); b.rgb = take(3 * (size_t)n); b.valid = (unsigned char*)take(n);
+  b.g_depth = take(n); b.g_rgb = take(3 * (size_t)n); b.g_o = take(3 * (size_t)n); b.g_d = take(3 * (size_t)n);
+  return b;
+}
+static int64_t rays_floats(int n) { float* p = nullptr; (void)carve_rays(p, n); return (int64_t)(p - (float*)nullptr); }
+
+extern "C" int64_t psl_track_ws_floats(int n_pix) {
+  if (n_pix < 0) return PSL_ERR_ARG;
+  return rays_floats(n_pix) + psl_render_ws_floats(n_pix, PSL_STAGE_COLOR | PSL_PTS_GRAD) + 64 +
+         (int64_t)((sizeof(FrameDev) + 3) / 4) + 16;
+}
+
+extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stream) {
+  if (!ctx || !t || !t->pix_idx || !t->cam_tensor || !t->adam_state || !t->ws || !t->frame.depth || !t->frame.color ||
+      !t->fallback || !t->best_out) { set_error("psl_track_iters: missing argument"); return PSL_ERR_ARG; }
+  if (!t->handle_dynamic) { set_error("psl_track_iters: tracking.handle_dynamic=False (median mask) is not built; every shipped config uses True"); return PSL_ERR_UNSUPPORTED; }
+  if (t->n_pix <= 0 || t->n_pix > 16384) { set_error("psl_track_iters: n_pix must be in [1,16384]"); return PSL_ERR_ARG; }
+  if (ctx->index_points != ctx->n_points) { set_error("psl_track_iters: index is stale"); return PSL_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = t->n_pix;
+  float* p = t->ws;
+  RayBufs b = carve_rays(p, n);
+  if (!t->frame.r_query) b.rq = nullptr;
+  float* loss_scratch = p; p += 64;
+  FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) + 3) / 4 + 4;
+  float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  FrameDev fh;
+  memset(&fh, 0, sizeof(fh));
+  fh.depth = t->frame.depth; fh.color = t->frame.color; fh.r_query = t->frame.r_query;
+  PSL_HIP(hipMemcpyAsync(fdev, &fh, sizeof(fh), hipMemcpyHostToDevice, s));
+  // best[0..6] pose, best[7] loss = +big
+  {
+    float init[8] = {0, 0, 0, 0, 0, 0, 0, 1e20f};
+    PSL_HIP(hipMemcpyAsync(t->best_out, init, sizeof(init), hipMemcpyHostToDevice, s));
+  }
+  psl_render_args ra;
+  memset(&ra, 0, sizeof(ra));
+  ra.n_rays = n; ra.flags = PSL_STAGE_COLOR | PSL_PTS_GRAD; ra.sigmoid_coef = t->sigmoid_coef;
+  ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
+  ra.geo_feats = t->geo_feats; ra.col_feats = t->col_feats; ra.params = t->params; ra.col_embed_B = t->col_embed_B;
+  ra.ws = rws; ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
+  psl_render_grads rg;
+  memset(&rg, 0, sizeof(rg));
+  rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_rays_o = b.g_o; rg.g_rays_d = b.g_d;
+  int npow = 1; while (npow < n) npow <<= 1;
+  for (int it = 0; it < t->n_iters; ++it) {
+    { ProfScope ps(ctx, PROF_MISC, s);
+      hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, t->edge_h, t->cam.H - t->edge_h,
+                         t->edge_w, t->cam.W - t->edge_w, fdev, 1, n, t->pix_idx + (size_t)it * n, t->cam_tensor, b);
+      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), sizeof(float) * npow, s, b.gd, b.active, n);
+      PSL_LAUNCH_CHECK(); }
+    ra.fallback_geo = t->fallback + (size_t)it * 64;
+    ra.fallback_col = t->fallback + (size_t)it * 64 + 32;
+    int rc = render_fwd_impl(ctx, &ra, s, it == 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
+                       t->cam_tensor, t->best_out, t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch);
+    PSL_LAUNCH_CHECK();
+    rc = render_bwd_impl(ctx, &ra, &rg, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
+                       t->lr_T, t->lr_quat);
+    PSL_LAUNCH_CHECK();
+  }
+  return PSL_OK;
+}
+
+extern "C" int64_t psl_map_ws_floats(int n_rays, int n_frames) {
+  if (n_rays < 0 || n_frames < 0) return PSL_ERR_ARG;
+  return rays_floats(n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
+         (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 16 + psl_param_master_floats();
+}
+
+extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) {
+  if (!ctx || !m || !m->frames || !m->pix_idx || !m->ws || !m->fallback || !m->geo_feats || !m->col_feats || !m->params ||
+      !m->sel_rows || !m->row_map || !m->adam_geo || !m->adam_col || !m->adam_params || !m->g_geo || !m->g_col) {
+    set_error("psl_map_iters: missing argument"); return PSL_ERR_ARG;
+  }
+  const int n = m->n_frames * m->pix_per_frame;
+  if (n <= 0 || n > 16384) { set_error("psl_map_iters: n_frames*pix_per_frame must be in [1,16384]"); return PSL_ERR_ARG; }
+  if (ctx->index_points != ctx->n_points) { set_error("psl_map_iters: index is stale"); return PSL_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  float* p = m->ws;
+  RayBufs b = carve_rays(p, n);
+  bool any_rq = false;
+  for (int f = 0; f < m->n_frames; ++f) any_rq |= m->frames[f].r_query != nullptr;
+  if (!any_rq) b.rq = nullptr;
+  float* loss_scratch = p; p += 64;
+  FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) * m->n_frames + 3) / 4 + 4;
+  float* g_params = p; p += psl_param_master_floats();
+  float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  {
+    std::vector<FrameDev> fh(m->n_frames);
+    for (int f = 0; f < m->n_frames; ++f) {
+      fh[f].depth = m->frames[f].depth; fh[f].color = m->frames[f].color; fh[f].r_query = m->frames[f].r_query;
+      memcpy(fh[f].c2w, m->frames[f].c2w, sizeof(float) * 12);
+    }
+    PSL_HIP(hipMemcpyAsync(fdev, fh.data(), sizeof(FrameDev) * m->n_frames, hipMemcpyHostToDevice, s));
+    PSL_HIP(hipStreamSynchronize(s));   // fh goes out of scope; once per mapped frame
+  }
+  psl_render_args ra;
+  memset(&ra, 0, sizeof(ra));
+  ra.n_rays = n; ra.sigmoid_coef = m->sigmoid_coef;
+  ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
+  ra.geo_feats = m->geo_feats; ra.col_feats = m->col_feats; ra.params = m->params; ra.col_embed_B = m->col_embed_B;
+  ra.ws = rws; ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
+  psl_render_grads rg;
+  memset(&rg, 0, sizeof(rg));
+  rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_geo_feats = m->g_geo; rg.g_col_feats = m->g_col;
+  rg.feat_row_map = m->row_map; rg.g_params = g_params;
+  int npow = 1; while (npow < n) npow <<= 1;
+  const int ncol = psl::kColorFloats;
+  for (int it = 0; it < m->n_iters; ++it) {
+    // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
+    const bool color_stage = it > m->n_geo_iters;
+    { ProfScope ps(ctx, PROF_MISC, s);
+      hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W, fdev,
+                         m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, b);
+      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), sizeof(float) * npow, s, b.gd, b.active, n);
+      PSL_LAUNCH_CHECK(); }
+    ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
+    ra.fallback_geo = m->fallback + (size_t)it * 64;
+    ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
+    int rc = render_fwd_impl(ctx, &ra, s, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mapper_loss, dim3(1), dim3(1024), 0, s, b, n, m->w_color, color_stage ? 1 : 0,
+                       m->loss_out ? m->loss_out + 4 * (size_t)it : loss_scratch);
+    PSL_LAUNCH_CHECK();
+    rc = render_bwd_impl(ctx, &ra, &rg, s);
+    if (rc) return rc;
+    // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
+    // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
+    const float lr_geo = color_stage ? m->lr_geo_color_stage : m->lr_geo_geo_stage;
+    rc = psl_adam_step_rows((float*)m->geo_feats, m->sel_rows, m->g_geo, m->adam_geo,
+                            m->adam_geo + (size_t)m->n_sel * C, m->n_sel, m->step0_geo + it + 1, lr_geo, 0.9f, 0.999f,
+                            1e-8f, 1, s);
+    if (rc) return rc;
+    if (color_stage) {
+      const int st = m->step0_col + (it - m->n_geo_iters);
+      rc = psl_adam_step_rows((float*)m->col_feats, m->sel_rows, m->g_col, m->adam_col,
+                              m->adam_col + (size_t)m->n_sel * C, m->n_sel, st, m->lr_col, 0.9f, 0.999f, 1e-8f, 1, s);
+      if (rc) return rc;
+      if (m->train_decoder) {
+        rc = psl_adam_step((float*)m->params, g_params, m->adam_params, m->adam_params + ncol, ncol, st, m->lr_decoder,
+                           0.9f, 0.999f, 1e-8f, 0, s);
+        if (rc) return rc;
+      }
+    }
+  }
+  return PSL_OK;
+}
+
+extern "C" int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host /*[16] row-major 4x4*/, psl_cam_intr cam,
+                                       const float* depth, float depth_max, float edge, int32_t* sel_out,
+                                       int32_t* row_map_out, int* n_sel_host, void* stream) {
+  if (!ctx || !c2w_host || !depth || !sel_out || !row_map_out || !n_sel_host) { set_error("psl_frustum_select_sync: bad argument"); return PSL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = ctx->n_points;
+  *n_sel_host = 0;
+  if (n == 0) return PSL_OK;
+  // w2c = inverse of the rigid c2w in double
+  double R[3][3], T[3];
+  for (int a = 0; a < 3; ++a) { for (int k = 0; k < 3; ++k) R[a][k] = c2w_host[a * 4 + k]; T[a] = c2w_host[a * 4 + 3]; }
+  // general 3x3 inverse (the pose is rigid up to rounding; np.linalg.inv in the reference)
+  double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+               R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+  double inv[3][3];
+  inv[0][0] = (R[1][1] * R[2][2] - R[1][2] * R[2][1]) / det; inv[0][1] = (R[0][2] * R[2][1] - R[0][1] * R[2][2]) / det;
+  inv[0][2] = (R[0][1] * R[1][2] - R[0][2] * R[1][1]) / det; inv[1][0] = (R[1][2] * R[2][0] - R[1][0] * R[2][2]) / det;
+  inv[1][1] = (R[0][0] * R[2][2] - R[0][2] * R[2][0]) / det; inv[1][2] = (R[0][2] * R[1][0] - R[0][0] * R[1][2]) / det;
+  inv[2][0] = (R[1][0] * R[2][1] - R[1][1] * R[2][0]) / det; inv[2][1] = (R[0][1] * R[2][0] - R[0][0] * R[2][1]) / det;
+  inv[2][2] = (R[0][0] * R[1][1] - R[0][1] * R[1][0]) / det;
+  float w2c[12];
+  for (int a = 0; a < 3; ++a) {
+    for (int k = 0; k < 3; ++k) w2c[a * 4 + k] = (float)inv[a][k];
+    w2c[a * 4 + 3] = (float)(-(inv[a][0] * T[0] + inv[a][1] * T[1] + inv[a][2] * T[2]));
+  }
+  // scratch: reuse cell_of (int[max_points]) for flags, scan_tmp-like block sums in scan_flags
+  const int nblk = (n + 1023) / 1024;
+  if (ctx->scan_flags_cap < nblk + 64) {
+    if (ctx->scan_flags) (void)hipFree(ctx->scan_flags);
+    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * (size_t)(nblk + 64) * 4));
+    ctx->scan_flags_cap = (nblk + 64) * 4;
+  }
+  float* w2c_dev = ctx->d_small;   // 12 floats
+  PSL_HIP(hipMemcpyAsync(w2c_dev, w2c, sizeof(w2c), hipMemcpyHostToDevice, s));
+  int* flags = ctx->cell_of;   // free between index builds
+  hipLaunchKernelGGL(k_frustum_flags, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth,
+                     depth_max, edge, flags);
+  hipLaunchKernelGGL(k_flag_block_sums, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags);
+  hipLaunchKernelGGL(k_flag_scan_top, dim3(1), dim3(1024), 0, s, ctx->scan_flags, nblk, ctx->d_counter);
+  hipLaunchKernelGGL(k_flag_compact, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags, sel_out, row_map_out);
+  PSL_LAUNCH_CHECK();
+  int tot = 0;
+  PSL_HIP(hipMemcpyAsync(&tot, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, s));
+  PSL_HIP(hipStreamSynchronize(s));
+  *n_sel_host = tot;
+  return PSL_OK;
+}

@@ -72,7 +72,10 @@ class _RenderFn(torch.autograd.Function):
             g_d = torch.empty(R, 3, device=dev)
         if flags & _lib.FEAT_GRAD:
             g_geo = torch.zeros(ctx.n_feat, 32, device=dev)
-            g_col = torch.zeros(ctx.n_feat, 32, device=dev)
+            # stage 'geometry' never touches the colour features (decoder.py:497-505): their gradient must stay
+            # None, not zeros -- torch.optim.Adam skips None but would advance its step count on zeros
+            if flags & _lib.STAGE_COLOR:
+                g_col = torch.zeros(ctx.n_feat, 32, device=dev)
         if flags & _lib.PARAM_GRAD:
             g_theta = torch.empty(P_.master_floats(), device=dev)
         if flags & _lib.HAS_AFFINE:

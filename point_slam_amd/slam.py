@@ -1,0 +1,344 @@
+"""Per-frame tracking / mapping loops on top of the HIP hot path.
+
+`HipSLAM` plays the role of the reference's Tracker.run / Mapper.run bodies
+(src/Tracker.py:203-394, src/Mapper.py:237-640) for ONE device: same
+iteration counts, pixel budgets, stage / learning-rate schedule, point adding
+and frustum feature selection, driven from Python but with two engines:
+
+  engine="native": psl_track_iters / psl_map_iters -- the whole iteration loop runs as
+                   back-to-back HIP kernels with no host synchronisation (fast path);
+  engine="dropin": the reference's own loop structure in torch (sampling, loss, torch.optim.Adam)
+                   calling HipRenderer.render_batch_ray -- what a user gets by swapping only the
+                   Renderer / NeuralPointCloud classes (parity path).
+
+Keyframe selection uses the reference's 'global' rule (random keyframes + the last
+one + the current frame, Mapper.py:263-276); the 'overlap' rule and BA are host
+logic outside the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from . import _lib, host_ops as H, params as P_
+from .decoders import PointDecoders
+from .neural_point import HipNeuralPointCloud
+from .renderer import HipRenderer
+
+
+class Frame:
+    """One RGB-D frame resident on the device."""
+
+    def __init__(self, idx, depth, color, r_add=None, r_query=None, c2w=None):
+        self.idx = idx
+        self.depth = depth.float().contiguous()
+        self.color = color.float().contiguous()
+        self.r_add = r_add.float().contiguous() if r_add is not None else None
+        self.r_query = r_query.float().contiguous() if r_query is not None else None
+        self.c2w = c2w            # [4,4] estimated pose (device tensor)
+
+    def view(self) -> _lib.psl_frame_view:
+        v = _lib.psl_frame_view()
+        v.depth = self.depth.data_ptr()
+        v.color = self.color.data_ptr()
+        v.r_query = self.r_query.data_ptr() if self.r_query is not None else None
+        if self.c2w is not None:
+            flat = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
+            for i in range(12):
+                v.c2w[i] = flat[i]
+        return v
+
+
+def camera_tensor_from_c2w(c2w: torch.Tensor) -> torch.Tensor:
+    """get_tensor_from_camera (src/common.py:270-295): [quat(w,x,y,z), T]; host-side (scipy in the reference)."""
+    from scipy.spatial.transform import Rotation
+    import numpy as np
+    m = c2w.detach().cpu().double().numpy()
+    q = np.roll(Rotation.from_matrix(m[:3, :3]).as_quat(), 1)
+    return torch.from_numpy(np.concatenate([q, m[:3, 3]])).float()
+
+
+class HipSLAM:
+    def __init__(self, cfg, cam: dict, device="cuda:0", max_points=2_500_000, engine="native", decoders=None):
+        self.cfg, self.cam, self.device, self.engine = cfg, cam, torch.device(device), engine
+        cfgd = dict(cfg)
+        cfgd["mapping"] = dict(cfg["mapping"], device=str(device))
+        self.npc = HipNeuralPointCloud(cfgd, max_points=max_points, device=str(device))
+        import types
+        self.renderer = HipRenderer(cfg, None, types.SimpleNamespace(**cam))
+        if decoders is None:
+            torch.manual_seed(cfg["setup_seed"])
+            decoders = PointDecoders(cfg)
+        self.decoders = decoders.to(self.device)
+        self.theta = P_.pack_master(self.decoders).detach().clone().contiguous()       # native engine's master blob
+        self.Bcol = P_.color_embed_B(self.decoders).to(self.device).float().contiguous()
+        self.keyframes: List[Frame] = []
+        self.cam_intr = _lib.psl_cam_intr(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"],
+                                          cy=cam["cy"])
+        self._ws_track = None
+        self._ws_map = None
+        self.last_losses = None
+        self.map_step = dict(geo=0, col=0)
+
+    # ------------------------------------------------------------------ state
+    def seed_points(self, pos: torch.Tensor, seed=1219):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        n = pos.shape[0]
+        geo = torch.zeros(n, 32).normal_(0, 0.1, generator=g)
+        col = torch.zeros(n, 32).normal_(0, 0.1, generator=g)
+        self.npc.set_points(pos.to(self.device), geo.to(self.device), col.to(self.device))
+
+    def sync_decoders_from_theta(self):
+        """Write the native blob back into the nn.Module (checkpoint surface, Logger.py:22-40)."""
+        with torch.no_grad():
+            named = dict(self.decoders.named_parameters())
+            for name, t in P_.unpack_master(self.theta).items():
+                named[name].copy_(t)
+
+    # ------------------------------------------------------------------ tracking
+    def track(self, frame: Frame, cam0: torch.Tensor, n_iters=None, n_pix=None) -> torch.Tensor:
+        """Optimise the pose of `frame` from the initial camera tensor cam0 [7]; returns the lowest-loss
+        camera tensor (candidate_cam_tensor, Tracker.py:347-350)."""
+        tr = self.cfg["tracking"]
+        n_iters = n_iters or tr["iters"]
+        n_pix = n_pix or tr["pixels"]
+        if self.engine == "native":
+            return self._track_native(frame, cam0, n_iters, n_pix)
+        return self._track_dropin(frame, cam0, n_iters, n_pix)
+
+    def _draws(self, n_iters, n_idx, hi):
+        idx = torch.randint(hi, (n_iters, n_idx), device=self.device, dtype=torch.int32)
+        fb = torch.zeros(n_iters, 2, 32, device=self.device).normal_(mean=0, std=0.01)
+        return idx, fb
+
+    def _track_native(self, frame, cam0, n_iters, n_pix):
+        L = _lib.lib()
+        tr, cam = self.cfg["tracking"], self.cam
+        eh, ew = tr["ignore_edge_H"], tr["ignore_edge_W"]
+        idx, fb = self._draws(n_iters, n_pix, (cam["H"] - 2 * eh) * (cam["W"] - 2 * ew))
+        need = int(L.psl_track_ws_floats(n_pix))
+        if self._ws_track is None or self._ws_track.numel() < need:
+            self._ws_track = torch.empty(need, device=self.device)
+        cam_t = cam0.to(self.device).float().clone().contiguous()
+        adam = torch.zeros(14, device=self.device)
+        losses = torch.empty(n_iters, 4, device=self.device)
+        best = torch.empty(8, device=self.device)
+        a = _lib.psl_track_args()
+        a.cam = self.cam_intr
+        a.edge_h, a.edge_w, a.n_iters, a.n_pix = eh, ew, n_iters, n_pix
+        a.pix_idx, a.fallback = idx.data_ptr(), fb.data_ptr()
+        a.frame = frame.view()
+        a.cam_tensor, a.adam_state, a.step0 = cam_t.data_ptr(), adam.data_ptr(), 0
+        a.lr_T = tr["lr"]
+        a.lr_quat = tr["lr"] * 0.2 if tr["separate_LR"] else tr["lr"]
+        a.w_color, a.handle_dynamic, a.use_color = tr["w_color_loss"], int(tr["handle_dynamic"]), \
+            int(tr["use_color_in_tracking"])
+        a.sigmoid_coef = self.cfg["rendering"]["sigmoid_coef_tracker"]
+        a.geo_feats, a.col_feats = self.npc.geo_feats.data_ptr(), self.npc.col_feats.data_ptr()
+        a.params, a.col_embed_B = self.theta.data_ptr(), self.Bcol.data_ptr()
+        a.ws, a.loss_out, a.best_out = self._ws_track.data_ptr(), losses.data_ptr(), best.data_ptr()
+        _lib.check(L.psl_track_iters(self.npc.handle, C.byref(a), _lib.stream_ptr()), "psl_track_iters")
+        self._keep = (idx, fb, cam_t, adam)          # alive until the stream has consumed them
+        self.last_losses = losses
+        self.last_cam = cam_t
+        return best[:7]
+
+    def _track_dropin(self, frame, cam0, n_iters, n_pix, draws=None):
+        """Tracker.run inner loop (Tracker.py:296-350) with HipRenderer in place of Renderer."""
+        tr, cam, dev = self.cfg["tracking"], self.cam, self.device
+        eh, ew = tr["ignore_edge_H"], tr["ignore_edge_W"]
+        idx, fb = draws if draws is not None else self._draws(n_iters, n_pix, (cam["H"] - 2 * eh) * (cam["W"] - 2 * ew))
+        cam_t = cam0.to(dev).float()
+        quad = cam_t[:4].clone().requires_grad_(True)
+        T = cam_t[4:].clone().requires_grad_(True)
+        lr = tr["lr"]
+        opt = torch.optim.Adam([{"params": [T], "lr": lr}, {"params": [quad], "lr": lr * 0.2 if tr["separate_LR"] else lr}])
+        self.renderer.sigmoid_coefficient = self.cfg["rendering"]["sigmoid_coef_tracker"]
+        self.renderer.skip_decoder_grads = True
+        best, best_loss, losses = None, float("inf"), []
+        for it in range(n_iters):
+            camera_tensor = torch.cat([quad, T], 0)
+            opt.zero_grad()
+            c2w = H.get_camera_from_tensor(camera_tensor)
+            u, v = H.pixels_from_flat_index(idx[it].long(), eh, cam["H"] - eh, ew, cam["W"] - ew)
+            ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+            ui, vi = u.long(), v.long()
+            gd, gc = frame.depth[vi, ui], frame.color[vi, ui]
+            rq = frame.r_query[vi, ui] if self.cfg["use_dynamic_radius"] else None
+            keep = gd > 0
+            ro, rd, gd, gc = ro[keep], rd[keep], gd[keep], gc[keep]
+            rq = rq[keep] if rq is not None else None
+            inl = H.depth_inlier_mask(gd)
+            ro, rd, gd, gc = ro[inl], rd[inl], gd[inl], gc[inl]
+            rq = rq[inl] if rq is not None else None
+            self.renderer.fixed_fallback = (fb[it, 0], fb[it, 1])
+            d, var, rgb, _ = self.renderer.render_batch_ray(
+                self.npc, self.decoders, rd, ro, dev, "color", gt_depth=gd, npc_geo_feats=self.npc.geo_feats,
+                npc_col_feats=self.npc.col_feats, is_tracker=True, dynamic_r_query=rq)
+            loss, geo, col, mask = H.tracker_loss(d, var, rgb, gd, gc, tr["handle_dynamic"],
+                                                  tr["use_color_in_tracking"], tr["w_color_loss"])
+            loss.backward()
+            opt.step()
+            lv = float(loss)
+            losses.append(lv)
+            if lv < best_loss:
+                best_loss, best = lv, camera_tensor.detach().clone()
+        self.renderer.fixed_fallback = None
+        self.last_losses = losses
+        self.last_cam = torch.cat([quad, T]).detach()
+        return best
+
+    # ------------------------------------------------------------------ mapping
+    def add_points(self, frame: Frame, c2w: torch.Tensor, n_pixels=None):
+        """Point adding of Mapper.optimize_map (Mapper.py:306-320): uniformly sampled pixels, dedupe radius
+        from the per-pixel dynamic r_add map."""
+        mp, cam, dev = self.cfg["mapping"], self.cam, self.device
+        n = n_pixels or mp["pixels_adding"]
+        idx = torch.randint(cam["H"] * cam["W"], (n,), device=dev)
+        u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
+        ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        ui, vi = u.long(), v.long()
+        gd, gc = frame.depth[vi, ui], frame.color[vi, ui]
+        rad = frame.r_add[vi, ui] if self.cfg["use_dynamic_radius"] else None
+        return int(self.npc.add_neural_points(ro.contiguous(), rd.contiguous(), gd, gc, dynamic_radius=rad))
+
+    def frustum_select(self, frame: Frame, c2w: torch.Tensor):
+        """Mapper.get_mask_from_c2w (Mapper.py:120-168) on the device: returns (sel int32[n_sel], row_map int32[N])."""
+        L = _lib.lib()
+        N = self.npc.pts_num()
+        sel = torch.empty(N, dtype=torch.int32, device=self.device)
+        row_map = torch.empty(N, dtype=torch.int32, device=self.device)
+        c2w_h = (C.c_float * 16)(*c2w.detach().float().cpu().reshape(-1).tolist())
+        n_sel = C.c_int(0)
+        dmax = float(frame.depth.max())
+        _lib.check(L.psl_frustum_select_sync(self.npc.handle, c2w_h, self.cam_intr, _lib.ptr(frame.depth), dmax,
+                                             float(self.cfg["mapping"]["frustum_edge"]), _lib.ptr(sel),
+                                             _lib.ptr(row_map), C.byref(n_sel), _lib.stream_ptr()),
+                   "psl_frustum_select_sync")
+        return sel[:n_sel.value], row_map
+
+    def select_window(self, frame: Frame) -> List[Frame]:
+        """'global' keyframe selection (Mapper.py:263-276): window-2 random keyframes + last keyframe + current."""
+        k = self.cfg["mapping"]["mapping_window_size"] - 2
+        win: List[Frame] = []
+        if len(self.keyframes) > 0:
+            if len(self.keyframes) > 1:
+                perm = torch.randperm(len(self.keyframes) - 1)[:k].tolist()
+                win += [self.keyframes[i] for i in perm]
+            win.append(self.keyframes[-1])
+        win.append(frame)
+        return win
+
+    def map(self, frame: Frame, c2w: torch.Tensor, n_iters=None, add=True):
+        mp = self.cfg["mapping"]
+        frame.c2w = c2w
+        added = self.add_points(frame, c2w) if add else 0
+        n_iters = n_iters or mp["iters"]
+        sel, row_map = self.frustum_select(frame, c2w)
+        window = self.select_window(frame)
+        pix_per_frame = mp["pixels"] // len(window)
+        if self.engine == "native":
+            self._map_native(window, sel, row_map, n_iters, pix_per_frame)
+        else:
+            self._map_dropin(window, sel, n_iters, pix_per_frame)
+        return added, int(sel.shape[0])
+
+    def _map_native(self, window, sel, row_map, n_iters, ppf, draws=None):
+        L = _lib.lib()
+        mp, cam, dev = self.cfg["mapping"], self.cam, self.device
+        W = len(window)
+        n = W * ppf
+        idx, fb = draws if draws is not None else self._draws(n_iters, n, cam["H"] * cam["W"])
+        need = int(L.psl_map_ws_floats(n, W))
+        if self._ws_map is None or self._ws_map.numel() < need:
+            self._ws_map = torch.empty(need, device=dev)
+        n_sel = int(sel.shape[0])
+        ncol = P_.color_floats()
+        g_geo = torch.zeros(n_sel, 32, device=dev)
+        g_col = torch.zeros(n_sel, 32, device=dev)
+        adam_geo = torch.zeros(2, n_sel, 32, device=dev)
+        adam_col = torch.zeros(2, n_sel, 32, device=dev)
+        adam_par = torch.zeros(2, ncol, device=dev)
+        losses = torch.empty(n_iters, 4, device=dev)
+        views = (_lib.psl_frame_view * W)(*[f.view() for f in window])
+        st = mp["stage"]
+        a = _lib.psl_map_args()
+        a.cam = self.cam_intr
+        a.n_frames, a.pix_per_frame, a.n_iters = W, ppf, n_iters
+        a.n_geo_iters = int(n_iters * mp["geo_iter_ratio"])
+        a.frames = views
+        a.pix_idx, a.fallback = idx.data_ptr(), fb.data_ptr()
+        a.geo_feats, a.col_feats = self.npc.geo_feats.data_ptr(), self.npc.col_feats.data_ptr()
+        a.params, a.col_embed_B = self.theta.data_ptr(), self.Bcol.data_ptr()
+        a.sel_rows, a.row_map, a.n_sel = sel.data_ptr(), row_map.data_ptr(), n_sel
+        a.g_geo, a.g_col = g_geo.data_ptr(), g_col.data_ptr()
+        a.adam_geo, a.adam_col, a.adam_params = adam_geo.data_ptr(), adam_col.data_ptr(), adam_par.data_ptr()
+        a.step0_geo, a.step0_col = 0, 0
+        a.train_decoder = 0 if mp["fix_color_decoder"] else 1
+        a.lr_geo_geo_stage, a.lr_geo_color_stage = st["geometry"]["geometry_lr"], st["color"]["geometry_lr"]
+        a.lr_col, a.lr_decoder = st["color"]["color_lr"], st["color"]["decoders_lr"]
+        a.w_color, a.sigmoid_coef = mp["w_color_loss"], self.cfg["rendering"]["sigmoid_coef_mapper"]
+        a.ws, a.loss_out = self._ws_map.data_ptr(), losses.data_ptr()
+        _lib.check(L.psl_map_iters(self.npc.handle, C.byref(a), _lib.stream_ptr()), "psl_map_iters")
+        self._keep_map = (idx, fb, g_geo, g_col, adam_geo, adam_col, adam_par, views, sel, row_map)
+        self.last_losses = losses
+
+    def _map_dropin(self, window, sel, n_iters, ppf, draws=None):
+        """Mapper.optimize_map joint_iter loop (Mapper.py:408-568) in torch, HipRenderer for the render."""
+        mp, cam, dev = self.cfg["mapping"], self.cam, self.device
+        W = len(window)
+        idx, fb = draws if draws is not None else self._draws(n_iters, W * ppf, cam["H"] * cam["W"])
+        sel_l = sel.long()
+        npc_geo, npc_col = self.npc.get_geo_feats(), self.npc.get_col_feats()
+        geo_p = npc_geo[sel_l].detach().clone().requires_grad_(True)
+        col_p = npc_col[sel_l].detach().clone().requires_grad_(True)
+        for p in self.decoders.parameters():
+            p.requires_grad_(False)
+        dec_params = [p for n, p in self.decoders.color_decoder.named_parameters() if "mlp_exposure" not in n]
+        if not mp["fix_color_decoder"]:
+            for p in dec_params:
+                p.requires_grad_(True)
+        opt = torch.optim.Adam([{"params": dec_params if not mp["fix_color_decoder"] else [], "lr": 0},
+                                {"params": [geo_p], "lr": 0}, {"params": [col_p], "lr": 0}])
+        self.renderer.sigmoid_coefficient = self.cfg["rendering"]["sigmoid_coef_mapper"]
+        self.renderer.skip_decoder_grads = False
+        n_geo = int(n_iters * mp["geo_iter_ratio"])
+        losses = []
+        for it in range(n_iters):
+            npc_geo = npc_geo.detach().index_put((sel_l,), geo_p)
+            npc_col = npc_col.detach().index_put((sel_l,), col_p)
+            stage = "geometry" if it <= n_geo else "color"
+            st = mp["stage"][stage]
+            opt.param_groups[0]["lr"], opt.param_groups[1]["lr"], opt.param_groups[2]["lr"] = \
+                st["decoders_lr"], st["geometry_lr"], st["color_lr"]
+            opt.zero_grad()
+            ros, rds, gds, gcs, rqs = [], [], [], [], []
+            for f, fr in enumerate(window):
+                u, v = H.pixels_from_flat_index(idx[it, f * ppf:(f + 1) * ppf].long(), 0, cam["H"], 0, cam["W"])
+                ro, rd = H.get_rays_from_uv(u, v, fr.c2w.to(dev), cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+                ui, vi = u.long(), v.long()
+                gd = fr.depth[vi, ui]
+                keep = gd > 0
+                ros.append(ro[keep]); rds.append(rd[keep]); gds.append(gd[keep]); gcs.append(fr.color[vi, ui][keep])
+                if self.cfg["use_dynamic_radius"]:
+                    rqs.append(fr.r_query[vi, ui][keep])
+            ro, rd, gd, gc = torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs)
+            rq = torch.cat(rqs) if rqs else None
+            inl = H.depth_inlier_mask(gd)
+            ro, rd, gd, gc = ro[inl], rd[inl], gd[inl], gc[inl]
+            rq = rq[inl] if rq is not None else None
+            self.renderer.fixed_fallback = (fb[it, 0], fb[it, 1])
+            d, var, rgb, valid = self.renderer.render_batch_ray(
+                self.npc, self.decoders, rd, ro, dev, stage, gt_depth=gd, npc_geo_feats=npc_geo, npc_col_feats=npc_col,
+                is_tracker=False, dynamic_r_query=rq)
+            loss, geo, col, m = H.mapper_loss(d, rgb, valid, gd, gc, stage, mp["w_color_loss"])
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        self.renderer.fixed_fallback = None
+        self.npc.update_geo_feats(geo_p, indices=sel_l)
+        self.npc.update_col_feats(col_p, indices=sel_l)
+        self.theta = P_.pack_master(self.decoders).detach().clone().contiguous()
+        self.last_losses = losses

@@ -1,0 +1,243 @@
+"""GPU tests of the fused native loops (psl_track_iters / psl_map_iters / psl_frustum_select_sync) against
+the reference golden tracker step and against the drop-in torch loops driven with identical random draws."""
+import pytest
+import torch
+
+from tests.helpers import base_cfg, load_decoders, load_npz
+from tests.test_hip_parity import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _slam(cfg, cam, engine, dev, fx=None, n_seed=0):
+    from point_slam_amd.decoders import PointDecoders
+    from point_slam_amd.slam import HipSLAM
+    dec = PointDecoders(cfg).load_reference_state(load_decoders("replica"))
+    s = HipSLAM(cfg, cam, device="cuda:0", max_points=400000, engine=engine, decoders=dec)
+    if fx is not None:
+        s.npc.set_points(fx["cloud"].to(dev), fx["geo"].to(dev), fx["col"].to(dev))
+    return s
+
+
+def test_track_native_one_iter_matches_reference_golden():
+    """One psl_track_iters iteration == the reference's Tracker.optimize_cam_in_batch step (fixture)."""
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    fx = load_npz("tracker_iter_replica")
+    cfg = base_cfg()
+    cam = syn.intrinsics(160, 120)
+    s = _slam(cfg, cam, "native", dev, fx)
+    frame = Frame(0, fx["depth_img"].to(dev), fx["color_img"].to(dev), r_query=fx["rq_img"].to(dev))
+    n = int(fx["n_rays"])
+    idx = fx["pix_idx"].to(dev).int().reshape(1, n).contiguous()
+    fb = torch.stack([fx["fb_geo"], fx["fb_col"]]).reshape(1, 2, 32).to(dev).contiguous()
+    s._draws = lambda n_iters, n_idx, hi: (idx, fb)
+    best = s.track(frame, fx["cam0"], n_iters=1, n_pix=n)
+    torch.cuda.synchronize()
+    loss = float(s.last_losses[0, 0])
+    rel = abs(loss - fx["ref_loss"]) / fx["ref_loss"]
+    after = s.last_cam.cpu()
+    dq = float((after[:4] - fx["ref_quad_after"]).abs().max())
+    dT = float((after[4:] - fx["ref_T_after"]).abs().max())
+    report(test="track_native_golden", loss_rel=rel, dq=dq, dT=dT)
+    assert rel < 1e-4
+    assert dq < 1e-6 and dT < 1e-6
+    assert torch.allclose(best.cpu(), fx["cam0"], atol=1e-7)      # the evaluated (pre-step) pose is the candidate
+
+
+def _scene(dev, n_pts=60000, W=320, H=240):
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.slam import Frame
+    cfg = base_cfg()
+    cam = syn.intrinsics(W, H)
+    frames = []
+    for t in (10.0, 12.0, 14.0):
+        c2w = syn.pose(t, dev)
+        depth, color = syn.render_frame(cam, c2w)
+        r_add, r_q = syn.dynamic_radii(color, cfg)
+        frames.append(Frame(int(t), depth, color, r_add, r_q, c2w))
+    pts = syn.seed_cloud(cam, n_pts, n_views=6, seed=5)
+    # move the seed views next to the test frames
+    pts = []
+    g = torch.Generator().manual_seed(4)
+    tt = torch.linspace(0.0, 1.0, 3)
+    for t in (9.0, 11.0, 13.0, 15.0):
+        c2w = syn.pose(t)
+        u = torch.rand(n_pts // 12, generator=g) * (cam["W"] - 1)
+        v = torch.rand(n_pts // 12, generator=g) * (cam["H"] - 1)
+        dirs = torch.stack([(u - cam["cx"]) / cam["fx"], -(v - cam["cy"]) / cam["fy"], -torch.ones_like(u)], -1)
+        rd = (dirs[:, None, :] * c2w[:3, :3]).sum(-1)
+        ro = c2w[:3, 3].expand_as(rd)
+        d = syn.box_depth(ro, rd)
+        z = 0.98 * d[:, None] * (1 - tt) + 1.02 * d[:, None] * tt
+        pts.append((ro[:, None] + rd[:, None] * z[..., None]).reshape(-1, 3))
+    return cfg, cam, frames, torch.cat(pts).float()
+
+
+def test_track_native_matches_dropin():
+    from point_slam_amd.slam import camera_tensor_from_c2w
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    cam0 = camera_tensor_from_c2w(frames[1].c2w) + torch.tensor([0.002, -0.001, 0.0015, 0.001, 0.01, -0.008, 0.006])
+    outs = {}
+    draws = None
+    for engine in ("dropin", "native"):
+        s = _slam(cfg, cam, engine, dev)
+        s.seed_points(pts)
+        if draws is None:
+            torch.manual_seed(11)
+            draws = s._draws(6, 300, (cam["H"] - 40) * (cam["W"] - 40))
+        s._draws = lambda *a, **k: draws
+        best = s.track(frames[1], cam0, n_iters=6, n_pix=300)
+        torch.cuda.synchronize()
+        ls = s.last_losses
+        ls = torch.tensor(ls) if isinstance(ls, list) else ls[:, 0].cpu()
+        outs[engine] = (best.cpu(), s.last_cam.cpu(), ls)
+    # calibrate the fp32 noise floor of this chaotic objective: the drop-in loop against ITSELF with
+    # the initial pose moved by one ulp
+    s = _slam(cfg, cam, "dropin", dev)
+    s.seed_points(pts)
+    s._draws = lambda *a, **k: draws
+    cam0_ulp = torch.nextafter(cam0, torch.full_like(cam0, 10.0))
+    s.track(frames[1], cam0_ulp, n_iters=6, n_pix=300)
+    self_noise = float((s.last_cam.cpu() - outs["dropin"][1]).abs().max())
+    dl = float(((outs["native"][2] - outs["dropin"][2]).abs() / outs["dropin"][2].abs()).max())
+    dc = float((outs["native"][1] - outs["dropin"][1]).abs().max())
+    db = float((outs["native"][0] - outs["dropin"][0]).abs().max())
+    step = cfg["tracking"]["lr"]
+    report(test="track_native_vs_dropin", loss_rel_max=dl, cam_abs=dc, best_abs=db, dropin_self_noise_1ulp=self_noise,
+           adam_step=step, losses=[float(x) for x in outs["native"][2]])
+    assert dl < 3e-4
+    # after 6 Adam steps of size ~lr the two engines agree to a fraction of ONE step, and no worse than a few times
+    # the drop-in loop's own sensitivity to a 1-ulp change of its input
+    assert dc < max(0.25 * step, 4 * self_noise) and db < max(0.25 * step, 4 * self_noise)
+
+
+def test_frustum_select_matches_oracle():
+    from oracle import pointslam_oracle as O
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(pts)
+    fr = frames[1]
+    sel, row_map = s.frustum_select(fr, fr.c2w)
+    ref = O.frustum_select(pts, fr.c2w.cpu(), fr.depth.cpu(), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
+                           cam["cy"], cfg["mapping"]["frustum_edge"])
+    got = sel.cpu().long()
+    # fp differences at the frustum border may flip a handful of points
+    a, b = set(got.tolist()), set(ref.tolist())
+    diff = len(a ^ b)
+    report(test="frustum", n_sel=len(a), n_ref=len(b), sym_diff=diff)
+    assert diff <= max(3, len(b) // 2000)
+    rm = row_map.cpu()
+    assert torch.equal(rm[got], torch.arange(got.shape[0], dtype=torch.int32))
+    assert int((rm >= 0).sum()) == got.shape[0]
+    assert torch.equal(got, torch.sort(got).values)
+
+
+def test_map_native_matches_dropin():
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    res = {}
+    draws = None
+    for engine in ("dropin", "native"):
+        s = _slam(cfg, cam, engine, dev)
+        s.seed_points(pts)
+        s.keyframes = [frames[0], frames[1]]
+        fr = frames[2]
+        sel, row_map = s.frustum_select(fr, fr.c2w)
+        window = [frames[0], frames[1], fr]
+        if draws is None:
+            torch.manual_seed(12)
+            draws = s._draws(8, 3 * 200, cam["H"] * cam["W"])
+        geo0, col0 = s.npc.geo_feats.clone(), s.npc.col_feats.clone()
+        if engine == "native":
+            s._map_native(window, sel, row_map, 8, 200, draws=draws)
+        else:
+            s._map_dropin(window, sel, 8, 200, draws=draws)
+        torch.cuda.synchronize()
+        ls = s.last_losses
+        ls = torch.tensor(ls) if isinstance(ls, list) else ls[:, 0].cpu()
+        res[engine] = (s.npc.geo_feats.cpu(), s.npc.col_feats.cpu(), s.theta.cpu(), ls, geo0.cpu(), col0.cpu(), sel.cpu())
+    n, d = res["native"], res["dropin"]
+    moved_geo = float((d[0] - d[4]).abs().max())
+    moved_col = float((d[1] - d[5]).abs().max())
+    rep = dict(test="map_native_vs_dropin", loss_rel_max=float(((n[3] - d[3]).abs() / d[3].abs()).max()),
+               geo_abs=float((n[0] - d[0]).abs().max()), col_abs=float((n[1] - d[1]).abs().max()),
+               theta_abs=float((n[2] - d[2]).abs().max()), moved_geo=moved_geo, moved_col=moved_col,
+               n_sel=int(n[6].shape[0]), losses=[float(x) for x in n[3]])
+    report(**rep)
+    # Adam normalises every step to ~lr*sign(g): entries whose gradient is at the rounding-noise level take O(lr)
+    # steps in a direction decided by noise, in the reference too.  So compare distributions, not the max.
+    sel_l = n[6].long()
+    dg = (n[0][sel_l] - d[0][sel_l]).abs().flatten()
+    dcol = (n[1][sel_l] - d[1][sel_l]).abs().flatten()
+    dth = (n[2] - d[2]).abs()
+    mv = (d[0][sel_l] - d[4][sel_l]).abs().flatten()
+    rep2 = dict(test="map_native_vs_dropin_dist", geo_median=float(dg.median()), geo_p99=float(dg.kthvalue(int(0.99 * dg.numel())).values),
+                geo_frac_gt_1e3=float((dg > 1e-3).float().mean()), col_frac_gt_1e3=float((dcol > 1e-3).float().mean()),
+                theta_frac_gt_1e3=float((dth > 1e-3).float().mean()), moved_frac=float((mv > 1e-3).float().mean()))
+    report(**rep2)
+    assert moved_geo > 1e-3 and moved_col > 1e-4          # the optimisation did something
+    assert rep["loss_rel_max"] < 3e-4                     # 8 iterations of losses agree, incl. after the updates
+    assert rep2["geo_frac_gt_1e3"] < 0.02 * max(rep2["moved_frac"], 1e-3) + 1e-4
+    assert rep2["col_frac_gt_1e3"] < 5e-3 and rep2["theta_frac_gt_1e3"] < 2e-2
+    # untouched rows stay bit-identical
+    mask = torch.ones(n[0].shape[0], dtype=torch.bool); mask[n[6].long()] = False
+    assert torch.equal(n[0][mask], n[4][mask]) and torch.equal(n[1][mask], n[5][mask])
+
+
+def test_compact_feature_gradients_match_dense():
+    """psl_render_bwd with feat_row_map (compact [n_sel,32] accumulators) == dense [N,32] gradients[sel]."""
+    import ctypes as C
+    from point_slam_amd import _lib, params as P_
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev, n_pts=24000)
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(pts)
+    fr = frames[1]
+    sel, row_map = s.frustum_select(fr, fr.c2w)
+    from point_slam_amd import host_ops as H
+    g = torch.Generator(device="cpu").manual_seed(3)
+    idx = torch.randint(cam["H"] * cam["W"], (400,), generator=g).to(dev)
+    u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
+    ro, rd = H.get_rays_from_uv(u, v, fr.c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    ro, rd = ro.contiguous(), rd.contiguous()
+    gd = fr.depth[v.long(), u.long()].contiguous()
+    rq = fr.r_query[v.long(), u.long()].contiguous()
+    L = _lib.lib()
+    R = 400
+    flags = _lib.STAGE_COLOR | _lib.FEAT_GRAD
+    outs = []
+    for use_map in (False, True):
+        ws = torch.empty(int(L.psl_render_ws_floats(R, flags)), device=dev)
+        depth = torch.empty(R, device=dev); var = torch.empty(R, device=dev); rgb = torch.empty(R, 3, device=dev)
+        valid = torch.empty(R, device=dev, dtype=torch.uint8)
+        fb = torch.zeros(2, 32, device=dev)
+        a = _lib.psl_render_args(n_rays=R, flags=flags, sigmoid_coef=0.1, rays_o=ro.data_ptr(), rays_d=rd.data_ptr(),
+                                 gt_depth=gd.data_ptr(), r_query=rq.data_ptr(), geo_feats=s.npc.geo_feats.data_ptr(),
+                                 col_feats=s.npc.col_feats.data_ptr(), params=s.theta.data_ptr(),
+                                 col_embed_B=s.Bcol.data_ptr(), fallback_geo=fb[0].data_ptr(),
+                                 fallback_col=fb[1].data_ptr(), exposure_affine=None, ws=ws.data_ptr(),
+                                 depth=depth.data_ptr(), var=var.data_ptr(), rgb=rgb.data_ptr(), valid_ray=valid.data_ptr())
+        _lib.check(L.psl_render_fwd(s.npc.handle, C.byref(a), _lib.stream_ptr()))
+        gdp = torch.ones(R, device=dev); grgb = torch.full((R, 3), 0.3, device=dev)
+        N = s.npc.pts_num()
+        rows = sel.shape[0] if use_map else N
+        gg = torch.zeros(rows, 32, device=dev); gc = torch.zeros(rows, 32, device=dev)
+        gr = _lib.psl_render_grads(g_depth=gdp.data_ptr(), g_var=None, g_rgb=grgb.data_ptr(), g_geo_feats=gg.data_ptr(),
+                                   g_col_feats=gc.data_ptr(), feat_row_map=row_map.data_ptr() if use_map else None,
+                                   g_params=None, g_rays_o=None, g_rays_d=None, g_exposure_affine=None)
+        _lib.check(L.psl_render_bwd(s.npc.handle, C.byref(a), C.byref(gr), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((gg.cpu(), gc.cpu()))
+    sl = sel.cpu().long()
+    dense_g, dense_c = outs[0]
+    assert float(dense_g.abs().max()) > 0
+    # atomics: summation order differs between runs -> tiny fp noise only
+    assert torch.allclose(outs[1][0], dense_g[sl], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(outs[1][1], dense_c[sl], rtol=1e-4, atol=1e-7)
+    # gradient mass outside the frustum selection is dropped by the map (those rows are constants in the reference)
+    mask = torch.ones(dense_g.shape[0], dtype=torch.bool); mask[sl] = False
+    report(test="compact_grads", n_sel=int(sl.shape[0]), outside_mass=float(dense_g[mask].abs().sum()))
