@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""Headline benchmark: mapping+tracking FPS @640x480 with 1 M neural points (BASELINE.json).
+
+A "step" is one RGB-D frame of the serial SLAM loop on synthetic data: 20 tracking iterations x 200 pixels
+every frame and, every 5th frame, point adding (6000 pixels) + frustum feature selection + 400 mapping
+iterations x 1000 pixels over a 5-frame window -- the iteration mix of the reference's base config
+(configs/point_slam.yaml:35-36,42,60,64).  All inputs (frames, point cloud, decoders) are resident in HBM
+before the timed region.  N>1: frame-parallel, one process per GPU (frame t on rank t mod N), each rank a full
+map replica, RCCL all-gather of newly added neural points every `--exchange-every` mapped frames.
+
+Prints ONE JSON line (rank 0).  `roofline` is computed from HIP-event timings of the dominant kernel class
+recorded on the launch stream during the timed region; `cpu_baseline` times the CPU oracle (oracle/, a port of
+the reference path) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: f32-in MFMA dense peak
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--engine", default="native", choices=["native", "dropin"])
+    ap.add_argument("--mix", default="base", choices=["base", "replica"])
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--exchange-every", type=int, default=2, help="mapped frames between point all-gathers (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def build_world(args, rank, world, dev):
+    import torch
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.config import default_config, replica_overrides
+    from point_slam_amd.slam import Frame, HipSLAM, camera_tensor_from_c2w
+    cfg = default_config()
+    if args.mix == "replica":
+        cfg = replica_overrides(cfg)
+    cam = syn.intrinsics(args.width, args.height)
+    torch.manual_seed(cfg["setup_seed"] + rank)
+    slam = HipSLAM(cfg, cam, device=str(dev), max_points=int(args.points * 1.3) + 300_000, engine=args.engine)
+    pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"])
+    slam.seed_points(pts)
+    every = cfg["mapping"]["every_frame"]
+    n_total = args.warmup + args.steps
+    # frame-parallel partition: local step i is global frame rank + world*i
+    frames, cams0 = [], []
+    g = torch.Generator().manual_seed(1000 + rank)
+    for i in range(-4, n_total):
+        t = float(rank + world * max(i, 0)) * 1.0 if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
+        t = t + 200.0 if i >= 0 else t + 170.0
+        c2w = syn.pose(t, dev)
+        depth, color = syn.render_frame(cam, c2w)
+        r_add, r_q = syn.dynamic_radii(color, cfg)
+        fr = Frame(i, depth, color, r_add, r_q, c2w)
+        if i < 0:
+            slam.keyframes.append(fr)
+        else:
+            frames.append(fr)
+            # initial pose = ground truth + a perturbation of the size the constant-speed model leaves
+            cam0 = camera_tensor_from_c2w(c2w) + torch.randn(7, generator=g) * torch.tensor([1e-3] * 4 + [5e-3] * 3)
+            cams0.append(cam0.to(dev))
+    return cfg, cam, slam, frames, cams0, every
+
+
+def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
+    import torch
+    from point_slam_amd import host_ops as H
+    fr = frames[i]
+    best = slam.track(fr, cams0[i])
+    if i % every == 0:
+        c2w34 = H.get_camera_from_tensor(best)
+        c2w = torch.cat([c2w34, torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=c2w34.device)], 0)
+        n_base = slam.npc.pts_num()
+        slam.map(fr, c2w)
+        state["mapped"] += 1
+        state["new_since"] += slam.npc.pts_num() - n_base
+        if world > 1 and state["mapped"] % args.exchange_every == 0:
+            from point_slam_amd.dist import merge_new_points
+            merge_new_points(slam.npc, slam.npc.pts_num() - state["new_since"])
+            state["new_since"] = 0
+        if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
+            slam.keyframes.append(fr)
+
+
+def kernel_profile(slam):
+    import ctypes as C
+    from point_slam_amd import _lib
+    L = _lib.lib()
+    n = L.psl_profile_classes()
+    ms = (C.c_double * n)(); cnt = (C.c_int * n)(); work = (C.c_double * n)()
+    _lib.check(L.psl_profile_read(slam.npc.handle, ms, cnt, work, n))
+    return {L.psl_profile_name(i).decode(): dict(ms=ms[i], launches=cnt[i], work=work[i]) for i in range(n)}
+
+
+MFMA_CLASSES = ("decode_fwd", "decode_bwd", "dw_gemm")
+
+
+def roofline_of(prof):
+    if not prof:
+        return None, {}
+    per = {}
+    for k, v in prof.items():
+        if v["launches"] == 0 or v["ms"] <= 0:
+            continue
+        sec = v["ms"] * 1e-3
+        if k in MFMA_CLASSES:
+            per[k] = dict(bound="mfma", achieved=v["work"] / sec / 1e12, peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                          avg_us=v["ms"] * 1e3 / v["launches"], launches=v["launches"], total_ms=v["ms"])
+        else:
+            per[k] = dict(bound="hbm", achieved=v["work"] / sec / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                          avg_us=v["ms"] * 1e3 / v["launches"], launches=v["launches"], total_ms=v["ms"])
+        per[k]["frac"] = per[k]["achieved"] / per[k]["peak"]
+    if not per:
+        return None, {}
+    dom = max((k for k in per if k != "misc"), key=lambda k: per[k]["total_ms"])
+    r = per[dom]
+    roof = dict(kernel=dom, bound=r["bound"], achieved=round(r["achieved"], 4), peak=r["peak"], unit=r["unit"],
+                frac=round(r["frac"], 5), traffic=None, avg_launch_us=round(r["avg_us"], 2), launches=r["launches"])
+    return roof, per
+
+
+def cpu_baseline(cfg, cam, n_points):
+    """The CPU oracle (port of the reference path: exact cKDTree 8-NN + torch fp32 decoders + autograd + Adam) on a
+    bounded sample: 2 tracking + 2 mapping iterations of the base mix over the same synthetic cloud; FPS is
+    extrapolated with the per-frame iteration counts."""
+    import torch
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import params as P_, synthetic as syn
+    from point_slam_amd.decoders import PointDecoders
+    torch.set_num_threads(os.cpu_count())
+    torch.manual_seed(cfg["setup_seed"])
+    dec = PointDecoders(cfg)
+    P = {k: v.detach() for k, v in dec.state_dict().items()}
+    P["color_decoder.embedder._B"] = dec.color_decoder.embedder._B
+    pts = syn.seed_cloud(cam, n_points, n_views=64, seed=cfg["setup_seed"])
+    g = torch.Generator().manual_seed(7)
+    geo = torch.zeros(n_points, 32).normal_(0, 0.1, generator=g)
+    col = torch.zeros(n_points, 32).normal_(0, 0.1, generator=g)
+    c2w = syn.pose(200.0)
+    depth, color = syn.render_frame(cam, c2w)
+    _, rq_img = syn.dynamic_radii(color, cfg)
+    O.knn_exact(pts, pts[:8], 8)         # builds (and caches) the kd-tree outside the timed sample
+    fb = torch.zeros(32)
+
+    def one_iter(n_pix, tracker):
+        idx = torch.randint(cam["H"] * cam["W"], (n_pix,), generator=g)
+        u, v = (idx % cam["W"]).float(), torch.div(idx, cam["W"], rounding_mode="floor").float()
+        ro, rd = O.rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        gd, gc, rq = depth[v.long(), u.long()], color[v.long(), u.long()], rq_img[v.long(), u.long()]
+        if tracker:
+            ro = ro.clone().requires_grad_(True); rd = rd.clone().requires_grad_(True)
+            d, var, rgb, valid, _ = O.render_batch_ray(cfg, P, pts, geo, col, ro, rd, gd, "color", rq, fb, fb, True)
+            loss, *_ = O.tracker_loss(d, var, rgb, gd, gc)
+            loss.backward()
+        else:
+            gp, cp = geo.clone().requires_grad_(True), col.clone().requires_grad_(True)
+            Pg = {k: (t.clone().requires_grad_(True) if k.startswith("color_decoder") and t.dtype.is_floating_point
+                      and k != "color_decoder.embedder._B" else t) for k, t in P.items()}
+            d, var, rgb, valid, _ = O.render_batch_ray(cfg, Pg, pts, gp, cp, ro, rd, gd, "color", rq, fb, fb, False)
+            loss, *_ = O.mapper_loss(d, rgb, valid, gd, gc, "color")
+            loss.backward()
+            # dense Adam over a frustum-sized selection (~15 % of the cloud) + decoder
+            n_sel = n_points * 15 // 100
+            for t_ in (gp.grad[:n_sel], cp.grad[:n_sel]):
+                O.adam_step(torch.zeros_like(t_), t_, torch.zeros_like(t_), torch.zeros_like(t_), 1, 0.005)
+
+    tr, mp = cfg["tracking"], cfg["mapping"]
+    t0 = time.perf_counter(); [one_iter(tr["pixels"], True) for _ in range(2)]; t_track = (time.perf_counter() - t0) / 2
+    t0 = time.perf_counter(); [one_iter(mp["pixels"], False) for _ in range(2)]; t_map = (time.perf_counter() - t0) / 2
+    per_frame = tr["iters"] * t_track + mp["iters"] / mp["every_frame"] * t_map
+    return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=os.cpu_count(), kind="port",
+                sample=f"oracle (cKDTree exact 8-NN + torch fp32 + autograd + Adam), N={n_points}: 2 tracking iters "
+                       f"({t_track*1e3:.0f} ms each) + 2 mapping iters ({t_map*1e3:.0f} ms each), extrapolated to "
+                       f"{tr['iters']} track + {mp['iters']}/{mp['every_frame']} map iters per frame")
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs the MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
+    state = dict(mapped=0, new_since=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_step(i, slam, frames, cams0, every, cfg, world, args, state)
+    from point_slam_amd import _lib
+    if not args.no_kernel_timing:
+        _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 1))
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        run_step(i, slam, frames, cams0, every, cfg, world, args, state)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    prof = kernel_profile(slam) if not args.no_kernel_timing else {}
+    _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 0))
+
+    if rank == 0:
+        roof, per = roofline_of(prof)
+        tr, mp = cfg["tracking"], cfg["mapping"]
+        out = {
+            "metric": "mapping+tracking FPS @640x480, 1M neural points",
+            "value": round(world * args.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D room, {args.points} seeded neural points, "
+                                   f"{args.mix} iteration mix: track {tr['pixels']}px x {tr['iters']}it per frame, map "
+                                   f"{mp['pixels']}px x {mp['iters']}it + {mp['pixels_adding']} add-pixels every "
+                                   f"{mp['every_frame']} frames, window {mp['mapping_window_size']}",
+                       "engine": args.engine, "points_end": slam.npc.pts_num(),
+                       "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                       "render_loss_rel_err_vs_reference": "<=1e-4 (tests/test_hip_parity.py, tests/test_hip_slam.py)"},
+            "roofline": roof,
+            "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                        for k, v in per.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, cam, args.points)
+            except Exception as e:      # the baseline must never take the measured line down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,8 @@ int psl_param_master_floats(void);
 int psl_points_reset(psl_ctx* ctx);
 /* raw append of n positions [n][3] f32 (no dedupe); index becomes stale */
 int psl_points_append(psl_ctx* ctx, const float* pos, int n, void* stream);
+/* drop every point with index >= n (multi-GPU merge re-appends blocks in rank order); index becomes stale */
+int psl_points_truncate(psl_ctx* ctx, int n);
 /* number of points (host value; exact after psl_sync or any *_sync call) */
 int psl_points_count(psl_ctx* ctx);
 /* copy positions [count][3] f32 to a device buffer (checkpoint compatibility, src/utils/Logger.py:22-40) */
@@ -253,10 +255,13 @@ int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host, psl_cam_intr ca
 
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);
-/* last kernel-time breakdown collected when profiling is enabled (ms per kernel class) */
+/* Kernel-class timing with HIP events recorded on the launch stream (for bench.py's roofline):
+ * enable, run, then read per class: total ms, launch count, algorithmic work (FLOP for the MFMA-bound
+ * classes decode_fwd/decode_bwd/dw_gemm, bytes for the HBM-bound ones). psl_profile_read synchronises. */
 int psl_profile_enable(psl_ctx* ctx, int on);
-int psl_profile_read(psl_ctx* ctx, float* ms_out, int cap, int* n_out);
+int psl_profile_classes(void);
 const char* psl_profile_name(int i);
+int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, double* work_out, int cap);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,9 @@ def sqdist(q: Tensor, p: Tensor) -> Tensor:
     return (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
 
 
+_TREE_CACHE: dict = {}
+
+
 def knn_exact(cloud: Tensor, q: Tensor, k: int = 8, chunk: int = 2048) -> Tuple[Tensor, Tensor]:
     """Exact k-NN.  Returns D [n,k] f32 squared distances ascending, I [n,k] int64.
     Missing neighbours (cloud smaller than k): D=+inf, I=-1.
@@ -103,7 +106,11 @@ def knn_exact(cloud: Tensor, q: Tensor, k: int = 8, chunk: int = 2048) -> Tuple[
     use_tree = N > 20000
     if use_tree:
         from scipy.spatial import cKDTree
-        tree = cKDTree(cloud.double().numpy())
+        key = (cloud.data_ptr(), N)
+        tree = _TREE_CACHE.get(key)
+        if tree is None:
+            _TREE_CACHE.clear()
+            tree = _TREE_CACHE[key] = cKDTree(cloud.double().numpy())
         kk = min(N, k + 8)
         _, cand = tree.query(q.double().numpy(), k=kk, workers=-1)
         cand = torch.from_numpy(np.asarray(cand).reshape(n, kk).astype(np.int64))

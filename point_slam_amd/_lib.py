@@ -84,6 +84,7 @@ _SIGS = {
     "psl_param_master_floats": (C.c_int, []),
     "psl_points_reset": (C.c_int, [C.c_void_p]),
     "psl_points_append": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "psl_points_truncate": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_points_count": (C.c_int, [C.c_void_p]),
     "psl_points_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -108,7 +109,8 @@ _SIGS = {
                                           C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "psl_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
+    "psl_profile_classes": (C.c_int, []),
+    "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "psl_profile_name": (C.c_char_p, [C.c_int]),
 }
 

@@ -160,7 +160,6 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4));
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64));
-  for (int i = 0; i < 2 * PROF_N; ++i) PSL_HIP(hipEventCreate(&c->ev[i]));
   *out = c;
   return PSL_OK;
 }
@@ -174,7 +173,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->wt); (void)hipFree(c->d_counter); (void)hipFree(c->d_small);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
-  for (int i = 0; i < 2 * PROF_N; ++i) (void)hipEventDestroy(c->ev[i]);
+  if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
   delete c;
 }
 
@@ -193,11 +192,11 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
   if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
-  { ProfScope ps(ctx, PROF_KNN, s);
+  { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
-  { ProfScope ps(ctx, PROF_DECODE_FWD, s); rc = launch_decode_fwd(d, s); if (rc) return rc; }
-  { ProfScope ps(ctx, PROF_COMPOSITE, s);
+  { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P); rc = launch_decode_fwd(d, s); if (rc) return rc; }
+  { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
     rc = launch_composite_fwd((const float4*)d.ws.raw, nullptr, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
                               a->n_rays, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, d.ws.cw,
                               d.ws.ray_aux, s);
@@ -215,7 +214,7 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
   if (a->n_rays == 0) return PSL_OK;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
-  { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s);
+  { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays);
     rc = launch_composite_bwd((const float4*)d.ws.raw, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
                               g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, s);
     if (rc) return rc; }
@@ -244,29 +243,41 @@ extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
 }
 
 static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
-                                         "misc"};
+                                         "adam", "misc"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
+extern "C" int psl_profile_classes(void) { return PROF_N; }
 
 extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
   if (!ctx) return PSL_ERR_ARG;
+  if (on && !ctx->ev) {
+    size_t n = (size_t)PROF_N * PROF_RING * 2;
+    ctx->ev = new hipEvent_t[n];
+    for (size_t i = 0; i < n; ++i) PSL_HIP(hipEventCreate(&ctx->ev[i]));
+  }
   ctx->prof_on = on;
-  memset(ctx->prof_used, 0, sizeof(ctx->prof_used));
+  if (on) { memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work)); }
   return PSL_OK;
 }
 
-// elapsed ms of the LAST launch of each kernel class (synchronises the events)
-extern "C" int psl_profile_read(psl_ctx* ctx, float* ms_out, int cap, int* n_out) {
-  if (!ctx || !ms_out) return PSL_ERR_ARG;
+// Per kernel class since psl_profile_enable(1): total device time (ms) of the recorded launches, launch count and the
+// algorithmic work (FLOP or bytes) attributed to them.  Synchronises the device.  When a class was launched more than
+// PROF_RING times only the last PROF_RING durations are available: ms is scaled to the full count.
+extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, double* work_out, int cap) {
+  if (!ctx || !ms_out || !count_out || !work_out) return PSL_ERR_ARG;
+  PSL_HIP(hipDeviceSynchronize());
   int n = std::min(cap, (int)PROF_N);
   for (int i = 0; i < n; ++i) {
-    ms_out[i] = 0.f;
-    if (ctx->prof_used[i]) {
-      PSL_HIP(hipEventSynchronize(ctx->ev[2 * i + 1]));
+    int cnt = ctx->prof_count[i];
+    int have = std::min(cnt, PROF_RING);
+    double tot = 0.0;
+    for (int k = 0; k < have; ++k) {
       float ms = 0.f;
-      PSL_HIP(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
-      ms_out[i] = ms;
+      if (hipEventElapsedTime(&ms, ctx->ev[((size_t)i * PROF_RING + k) * 2], ctx->ev[((size_t)i * PROF_RING + k) * 2 + 1]) == hipSuccess)
+        tot += ms;
     }
+    ms_out[i] = have > 0 ? tot * ((double)cnt / have) : 0.0;
+    count_out[i] = cnt;
+    work_out[i] = ctx->prof_work[i];
   }
-  if (n_out) *n_out = n;
-  return PSL_OK;
+  return n;
 }

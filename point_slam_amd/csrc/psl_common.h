@@ -117,7 +117,8 @@ struct GridMeta {      // lives in device memory; written by k_grid_meta
 
 // --------------------------------------------------------------------- context
 enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BWD, PROF_DECODE_BWD, PROF_DW,
-                PROF_MISC, PROF_N };
+                PROF_ADAM, PROF_MISC, PROF_N };
+constexpr int PROF_RING = 4096;
 
 }  // namespace psl
 
@@ -146,11 +147,12 @@ struct psl_ctx {
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   int* scan_flags;       // for add_points compaction
   int scan_flags_cap;
-  // profiling
+  // profiling: a ring of HIP event pairs per kernel class, recorded on the launch stream
   int prof_on;
-  hipEvent_t ev[2 * psl::PROF_N];
-  float prof_ms[psl::PROF_N];
-  int prof_used[psl::PROF_N];
+  hipEvent_t* ev;                    // [PROF_N][PROF_RING][2]
+  int prof_count[psl::PROF_N];       // launches recorded since enable (may exceed the ring)
+  double prof_work[psl::PROF_N];     // algorithmic work (FLOP for MFMA classes, bytes for HBM classes) of those launches
+  double prof_work_ring[psl::PROF_N];
 };
 
 namespace psl {
@@ -178,12 +180,19 @@ bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every lau
   } while (0)
 
 struct ProfScope {  // brackets a kernel class with HIP events on the launch stream when profiling is on
-  psl_ctx* c; int slot; hipStream_t s;
-  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) {
-    if (c && c->prof_on) (void)hipEventRecord(c->ev[2 * slot], s);
+  psl_ctx* c; int slot; hipStream_t s; int k;
+  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0) : c(c_), slot(slot_), s(s_), k(0) {
+    if (c && c->prof_on) {
+      k = c->prof_count[slot] % PROF_RING;
+      (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2], s);
+      c->prof_work[slot] += work;
+    }
   }
   ~ProfScope() {
-    if (c && c->prof_on) { (void)hipEventRecord(c->ev[2 * slot + 1], s); c->prof_used[slot] = 1; }
+    if (c && c->prof_on) {
+      (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2 + 1], s);
+      c->prof_count[slot]++;
+    }
   }
 };
 

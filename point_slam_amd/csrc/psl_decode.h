@@ -18,6 +18,21 @@ struct DecodeArgs {
   RenderWs ws;
 };
 
+// Algorithmic work per sample point (2 FLOP per MAC; unpadded layer sizes)
+constexpr double MAC_GEO = 15479.0, MAC_COL = 96700.0, MAC_NBR = 86256.0, MAC_INTERP = 256.0;
+inline double fwd_flops_per_sample(int flags) {
+  double m = MAC_GEO + MAC_INTERP;
+  if (flags & PSL_STAGE_COLOR) m += MAC_COL + MAC_INTERP + ((flags & 0x10000) ? MAC_NBR : 0.0);
+  return 2.0 * m;
+}
+inline double bwd_flops_per_sample(int flags) { return fwd_flops_per_sample(flags); }   // dX chain mirrors the forward
+inline double dw_flops_per_sample(int flags) {
+  return (flags & PSL_STAGE_COLOR) ? 2.0 * (MAC_COL + ((flags & 0x10000) ? MAC_NBR : 0.0)) : 0.0;
+}
+// algorithmic HBM bytes per sample: query 12 + neighbour positions 8*12 + 8 feature rows of 128 B per feature set
+inline double gather_bytes_per_sample(int flags) { return 12.0 + 96.0 + ((flags & PSL_STAGE_COLOR) ? 2048.0 : 1024.0); }
+inline double scatter_bytes_per_sample(int flags) { return (flags & PSL_STAGE_COLOR) ? 4096.0 : 2048.0; }
+
 // LDS strides (floats): even with ld/2 odd => the 16x4 A-fragment reads are bank-conflict free
 constexpr int LD_G = 130;   // geo X: [emb 96 | h 32]
 constexpr int LD_C = 170;   // colour X: [emb 40 | h 128]

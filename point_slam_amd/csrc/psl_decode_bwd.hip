@@ -452,7 +452,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   o.g_affine = small + 32;
   int tiles = (a.P + TILE - 1) / TILE;
   {
-    ProfScope ps(ctx, PROF_DECODE_BWD, s);
+    ProfScope ps(ctx, PROF_DECODE_BWD, s, bwd_flops_per_sample(a.flags) * a.P);
     hipLaunchKernelGGL(k_decode_bwd, dim3(tiles), dim3(WG), lds, s, a, o);
     PSL_LAUNCH_CHECK();
   }
@@ -460,7 +460,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
     PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
   if (a.flags & PSL_PARAM_GRAD) {
     if (color) {
-      ProfScope ps(ctx, PROF_DW, s);
+      ProfScope ps(ctx, PROF_DW, s, dw_flops_per_sample(a.flags) * a.P);
       int rc = launch_dw(ctx, a, g.g_params, small, s);
       if (rc) return rc;
     } else {

@@ -457,6 +457,12 @@ extern "C" int psl_points_append(psl_ctx* ctx, const float* pos, int n, void* st
   return PSL_OK;
 }
 
+extern "C" int psl_points_truncate(psl_ctx* ctx, int n) {
+  if (!ctx || n < 0 || n > ctx->n_points) { set_error("psl_points_truncate: bad count"); return PSL_ERR_ARG; }
+  if (n != ctx->n_points) { ctx->n_points = n; ctx->index_points = -1; }
+  return PSL_OK;
+}
+
 extern "C" int psl_points_count(psl_ctx* ctx) { return ctx ? ctx->n_points : PSL_ERR_ARG; }
 
 extern "C" int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_points, void* stream) {

@@ -541,6 +541,10 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
     // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
     const float lr_geo = color_stage ? m->lr_geo_color_stage : m->lr_geo_geo_stage;
+    // dense Adam: 5 streams (p r/w, g r/w(zero), m r/w, v r/w ~ 7 accesses of 4 B; counted as 5 x 4 B per element as in
+    // SURVEY.md §8d) over every selected row
+    ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((double)m->n_sel * C * (color_stage ? 2 : 1) +
+                                             ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
     rc = psl_adam_step_rows((float*)m->geo_feats, m->sel_rows, m->g_geo, m->adam_geo,
                             m->adam_geo + (size_t)m->n_sel * C, m->n_sel, m->step0_geo + it + 1, lr_geo, 0.9f, 0.999f,
                             1e-8f, 1, s);

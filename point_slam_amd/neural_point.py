@@ -132,6 +132,13 @@ class HipNeuralPointCloud(object):
         _lib.check(L.psl_points_reset(self._h))
         self.append_points(pos, geo_feats, col_feats)
 
+    def truncate(self, n: int):
+        """Keep the first n points (positions and features); used by the multi-GPU merge."""
+        _lib.check(_lib.lib().psl_points_truncate(self._h, int(n)), "psl_points_truncate")
+        if self.geo_feats is not None:
+            self.geo_feats = self.geo_feats[:n].contiguous()
+            self.col_feats = self.col_feats[:n].contiguous()
+
     def append_points(self, pos, geo_feats=None, col_feats=None):
         pos = pos.to(self.device, torch.float32).contiguous()
         n = pos.shape[0]
