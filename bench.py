@@ -145,7 +145,9 @@ def cpu_baseline(cfg, cam, n_points):
     from oracle import pointslam_oracle as O
     from point_slam_amd import params as P_, synthetic as syn
     from point_slam_amd.decoders import PointDecoders
-    torch.set_num_threads(os.cpu_count())
+    n_thr = min(os.cpu_count(), 16)     # more threads only add contention on these small ops
+    torch.set_num_threads(n_thr)
+    O.KNN_WORKERS = n_thr
     torch.manual_seed(cfg["setup_seed"])
     dec = PointDecoders(cfg)
     P = {k: v.detach() for k, v in dec.state_dict().items()}
@@ -186,7 +188,7 @@ def cpu_baseline(cfg, cam, n_points):
     t0 = time.perf_counter(); [one_iter(tr["pixels"], True) for _ in range(2)]; t_track = (time.perf_counter() - t0) / 2
     t0 = time.perf_counter(); [one_iter(mp["pixels"], False) for _ in range(2)]; t_map = (time.perf_counter() - t0) / 2
     per_frame = tr["iters"] * t_track + mp["iters"] / mp["every_frame"] * t_map
-    return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=os.cpu_count(), kind="port",
+    return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=n_thr, kind="port",
                 sample=f"oracle (cKDTree exact 8-NN + torch fp32 + autograd + Adam), N={n_points}: 2 tracking iters "
                        f"({t_track*1e3:.0f} ms each) + 2 mapping iters ({t_map*1e3:.0f} ms each), extrapolated to "
                        f"{tr['iters']} track + {mp['iters']}/{mp['every_frame']} map iters per frame")

@@ -91,6 +91,7 @@ def sqdist(q: Tensor, p: Tensor) -> Tensor:
 
 
 _TREE_CACHE: dict = {}
+KNN_WORKERS = -1
 
 
 def knn_exact(cloud: Tensor, q: Tensor, k: int = 8, chunk: int = 2048) -> Tuple[Tensor, Tensor]:
@@ -112,7 +113,7 @@ def knn_exact(cloud: Tensor, q: Tensor, k: int = 8, chunk: int = 2048) -> Tuple[
             _TREE_CACHE.clear()
             tree = _TREE_CACHE[key] = cKDTree(cloud.double().numpy())
         kk = min(N, k + 8)
-        _, cand = tree.query(q.double().numpy(), k=kk, workers=-1)
+        _, cand = tree.query(q.double().numpy(), k=kk, workers=KNN_WORKERS)
         cand = torch.from_numpy(np.asarray(cand).reshape(n, kk).astype(np.int64))
         dc = sqdist(q[:, None, :], cloud[cand])                # [n,kk] fp32 re-evaluation
         key_order = _lexsort_rows(dc, cand)

@@ -62,18 +62,17 @@ RenderWs carve_ws(float* base, int n_rays, int flags) {
     w.dp = take(Pp * 4);
     if (color) {
       w.c_y = take(Pp * 5 * HC);
-      w.c_hin = take(Pp * 5 * HC);
-      w.c_emb = take(Pp * EC);
       w.d_out3 = take(Pp * 4);
       if (relpos) {
         w.n_h1 = take(Pp * K * HC);
-        w.n_out = take(Pp * K * C);
-        w.n_x = take(Pp * K * NX);
+        if (flags & PSL_PTS_GRAD) w.n_out = take(Pp * K * C);     // only dL/dw -> dL/dp needs F_theta's outputs
       }
-      if (pgrad) {
+      if (pgrad) {      // operands of the parameter-gradient GEMM
+        w.c_hin = take(Pp * 5 * HC);
+        w.c_emb = take(Pp * EC);
         w.c_dz = take(Pp * 5 * HC);
         w.c_g = take(Pp * 5 * HC);
-        if (relpos) { w.n_dz1 = take(Pp * K * HC); w.n_dnf = take(Pp * K * C); }
+        if (relpos) { w.n_x = take(Pp * K * NX); w.n_dz1 = take(Pp * K * HC); w.n_dnf = take(Pp * K * C); }
       }
     }
   }

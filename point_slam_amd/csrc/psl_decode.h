@@ -16,7 +16,10 @@ struct DecodeArgs {
   const float* Bcol;     // [3][20]
   const float *fb_geo, *fb_col, *affine;
   RenderWs ws;
+  int spt;                   // real samples per workgroup tile (set by the launcher)
+  unsigned long long* dbg;   // optional phase timestamps (PSL_DEBUG_PHASES=1)
 };
+#define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
 
 // Algorithmic work per sample point (2 FLOP per MAC; unpadded layer sizes)
 constexpr double MAC_GEO = 15479.0, MAC_COL = 96700.0, MAC_NBR = 86256.0, MAC_INTERP = 256.0;
@@ -65,6 +68,8 @@ __device__ __forceinline__ float fourier_phase(float x, float y, float z, const 
   return fmaf(z2, B[2 * F + f], fmaf(y2, B[F + f], __fmul_rn(x2, B[f])));
 }
 
+void choose_tile(int P, int& mt, int& spt);
+
 // NT output column tiles at once: the A fragment is read from LDS once per k-step
 template <int KDIM, int NT>
 __device__ __forceinline__ void gemm16_multi(const float* Xs, int ldx, const float* __restrict__ W, int ldw,
@@ -74,11 +79,25 @@ __device__ __forceinline__ void gemm16_multi(const float* Xs, int ldx, const flo
   const float* wp = W + (size_t)(lane >> 4) * ldw + (lane & 15);
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int ks = 0; ks < KDIM / 4; ++ks) {
-    float xa = xp[4 * ks];
+  // B fragments are fetched KB k-steps ahead as one batch of NT*KB independent loads
+  constexpr int NK = KDIM / 4;
+  constexpr int KB = (NT >= 8) ? 4 : 16;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = mfma16(xa, wp[(size_t)(4 * ks) * ldw + 16 * t], acc[t]);
+  for (int k0 = 0; k0 < NK; k0 += KB) {
+    float wv[KB][NT];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        wv[kk][t] = (k0 + kk < NK) ? wp[(size_t)(4 * (k0 + kk)) * ldw + 16 * t] : 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+      if (k0 + kk < NK) {
+        float xa = xp[4 * (k0 + kk)];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16(xa, wv[kk][t], acc[t]);
+      }
+    }
   }
 }
 

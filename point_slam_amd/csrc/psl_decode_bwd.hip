@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
   if (t < 16) sAff[t] = 0.f;
   for (int e = t; e < 16 * LD_DE; e += WG) sDEg[e] = 0.f;
   for (int e = t; e < 16 * LD_DEC; e += WG) sDEc[e] = 0.f;
-  __syncthreads();
+  lds_barrier();
 
   // ================================================================== colour decoder
   if (color) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       }
       sDO[t * 4] = d0; sDO[t * 4 + 1] = d1; sDO[t * 4 + 2] = d2; sDO[t * 4 + 3] = 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- G = d_out3 * W_out  (output_linear.weight [3][128])
     {
       const float* wo = M + MO(PI_C_OUT);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         sG[s * LD_C + k] = sDO[s * 4] * wo[k] + sDO[s * 4 + 1] * wo[HC + k] + sDO[s * 4 + 2] * wo[2 * HC + k];
       }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};   // waves 0,1: dL/dc_col column slice
     const int n0 = 16 * wave;
 #pragma unroll
@@ -143,17 +143,17 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int p = p0 + g4 + r;
-        float y = (p < a.P) ? a.ws.c_y[((size_t)p * 5 + i) * HC + n0 + colw] : 0.f;
+        float y = (p < a.P) ? a.ws.c_y[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] : 0.f;
         dz[r] = (p < a.P) ? gv[r] * softplus100_grad_from_out(y) : 0.f;
         if (parg && p < a.P) {
-          a.ws.c_dz[((size_t)p * 5 + i) * HC + n0 + colw] = dz[r];
-          a.ws.c_g[((size_t)p * 5 + i) * HC + n0 + colw] = gv[r];
+          a.ws.c_dz[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] = dz[r];
+          a.ws.c_g[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] = gv[r];
         }
       }
       frag_store(sDZ, LD_HN, n0, dz);
       // step B: dL/dc += G * Wc_i   (fc_c.i.weight [128][32])
       if (wave < 2) dcacc += gemm16<HC>(sG, LD_C, M + MO(PI_C_FCC + 2 * i), C, n0);
-      __syncthreads();
+      lds_barrier();
       // step C: dL/d(input of layer i) = dz * W_i   (pts_linears.i.weight [128][Kin])
       f32x4 gn = {0.f, 0.f, 0.f, 0.f}, ge = {0.f, 0.f, 0.f, 0.f};
       const float* Wi = M + MO(PI_C_L + 2 * i);
@@ -165,19 +165,19 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       } else {
         gn = gemm16<HC>(sDZ, LD_HN, Wi, HC, n0);
       }
-      __syncthreads();
+      lds_barrier();
       if (i > 0) frag_store(sG, LD_C, n0, gn);
       if ((i == 3 || i == 0) && ptsg && wave < 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (n0 + colw < EC) sDEc[(g4 + r) * LD_DEC + n0 + colw] += ge[r];
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (wave < 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sDCc[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     if (!relpos) {
       // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           if (ch == 0) sGW[s * K + k] += v;     // one writer per (s,k): this wave owns rows 16w..16w+15
         }
       }
-      __syncthreads();
+      lds_barrier();
       // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1)
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
@@ -239,14 +239,14 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         }
         frag_store(sDz1, LD_HN, 16 * nt, dz);
       }
-      __syncthreads();
+      lds_barrier();
       // dX1 = dz1 * W1 (linear1.weight [128][52]): columns [sin 10 | cos 10 | feat 32]
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         f32x4 dx = gemm16<HC>(sDz1, LD_HN, M + MO(PI_C_N1), NX, 16 * kt);
         frag_store(sDx, LD_DXN, 16 * kt, dx);
       }
-      __syncthreads();
+      lds_barrier();
       // feature part -> scatter into the colour feature rows
       if (featg) {
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // ================================================================== geometry decoder
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       float docc = (p < a.P) ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
       sG[s * LD_C + k] = docc * M[MO(PI_G_OUT) + k];
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};
     const int n0 = 16 * wave;
 #pragma unroll
@@ -309,13 +309,13 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int p = p0 + g4 + r;
-          float y = (p < a.P) ? a.ws.g_y[((size_t)p * 5 + i) * HG + n0 + colw] : 0.f;
+          float y = (p < a.P) ? a.ws.g_y[((size_t)i * a.ws.Ppad + p) * HG + n0 + colw] : 0.f;
           dz[r] = (p < a.P && y > 0.f) ? gv[r] : 0.f;       // ReLU
         }
         frag_store(sDZ, LD_HN, n0, dz);
         dcacc += gemm16<HG>(sG, LD_C, M + MO(PI_G_FCC + 2 * i), C, n0);   // fc_c.i.weight [32][32]
       }
-      __syncthreads();
+      lds_barrier();
       const float* Wi = M + MO(PI_G_L + 2 * i);
       f32x4 gx = {0.f, 0.f, 0.f, 0.f};
       const int Kin = (i == 0) ? EG : (i == 3 ? EG + HG : HG);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       if (i == 3) { act = ptsg || n0 + 15 >= EG; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, EG + HG, n0); }   // 8 slices of [32][125]
       else if (i == 0) { act = ptsg && wave < 6; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, EG, n0); }
       else { act = wave < 2; if (act) gx = gemm16<HG>(sDZ, LD_HN, Wi, HG, n0); }
-      __syncthreads();
+      lds_barrier();
       if (act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -338,13 +338,13 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (wave < 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sDCg[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // scatter into the geometry feature rows, collect dL/dw
     {
       const int s = t >> 5, ch = t & 31;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 
   // ================================================================== position gradient
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       }
       if (l32 == 0) { atomic_add_f32(&sDP[s * 4], ax); atomic_add_f32(&sDP[s * 4 + 1], ay); atomic_add_f32(&sDP[s * 4 + 2], az); }
     }
-    __syncthreads();
+    lds_barrier();
     if (t < TILE && p0 + t < a.P)
       reinterpret_cast<float4*>(a.ws.dp)[p0 + t] = make_float4(sDP[t * 4], sDP[t * 4 + 1], sDP[t * 4 + 2], 0.f);
   }

@@ -10,43 +10,90 @@
 //     the 8 waves split the 128 output columns (colour trunk) or the 8 neighbour row-tiles (F_theta);
 //   * bias, activation, the `+ fc_c(c)` skip term and the activation save for the backward pass are
 //     fused into the MFMA epilogue.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include "psl_decode.h"
 
 namespace psl {
 
-constexpr int FWD_LDS_FLOATS = 128 + 128 + 384 + 64 + 16 + 16 * LD_CF * 2 + 16 * LD_G + 16 * LD_C + 16 + 64 +
-                               128 * LD_XN + 8 * 16 * LD_HN;
+// MT = number of 16-row MFMA M-tiles per workgroup tile (TM = 16*MT sample slots, of which the first a.spt are
+// real).  MT=2 halves the weight traffic and the exposed L2 latencies per sample; the host picks the smallest
+// MT that puts the whole batch on the chip in ONE round of workgroups (256 CUs, 1 workgroup per CU).
+template <int MT>
+struct FwdLds {
+  static constexpr int TM = 16 * MT;
+  static constexpr int oI = 0, oW = oI + TM * K, oRel = oW + TM * K, oPts = oRel + TM * K * 3, oHas = oPts + TM * 4,
+                       oCg = oHas + TM, oCc = oCg + TM * LD_CF, oXg = oCc + TM * LD_CF, oXc = oXg + TM * LD_G,
+                       oOcc = oXc + TM * LD_C, oOut = oOcc + TM, oXn = oOut + TM * 4, oHn = oXn + 128 * LD_XN,
+                       total = oHn + 8 * 16 * LD_HN;
+};
 
+// acc[mt](16 x 16 slice at column n0) = X[mt*16 .. +16][K] * W[K][N]; the B fragments are fetched once and shared
+// by the MT row tiles; all of them are requested before the first MFMA (one exposed L2 latency per product).
+template <int KDIM, int MT>
+__device__ __forceinline__ void gemm16m(const float* Xs, int ldx, const float* __restrict__ W, int ldw, int n0,
+                                        f32x4 (&acc)[MT]) {
+  const int lane = threadIdx.x & 63;
+  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
+  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
+  constexpr int NK = KDIM / 4;
+  float wv[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
+  if constexpr (MT == 1) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // two chains hide the 40-cycle dependent latency
+#pragma unroll
+    for (int ks = 0; ks + 1 < NK; ks += 2) { a0 = mfma16(xp[4 * ks], wv[ks], a0); a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1); }
+    if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
+    acc[0] = a0 + a1;
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma16(xp[m * 16 * ldx + 4 * ks], wv[ks], acc[m]);
+    }
+  }
+}
+
+template <int MT>
 __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
+  using L = FwdLds<MT>;
+  constexpr int TM = L::TM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* sI = (int*)smem;                     // [16][8]
-  float* sW = smem + 128;                   // [16][8]
-  float* sRel = sW + 128;                   // [16][8][3]
-  float* sPts = sRel + 384;                 // [16][4]
-  int* sHas = (int*)(sPts + 64);            // [16]
-  float* sCg = (float*)(sHas + 16);         // [16][34]
-  float* sCc = sCg + 16 * LD_CF;            // [16][34]
-  float* sXg = sCc + 16 * LD_CF;            // [16][130]
-  float* sXc = sXg + 16 * LD_G;             // [16][170]
-  float* sOcc = sXc + 16 * LD_C;            // [16]
-  float* sOut = sOcc + 16;                  // [16][4]
-  float* sXn = sOut + 64;                   // [128][54]
-  float* sHn = sXn + 128 * LD_XN;           // [8][16][130]
+  int* sI = (int*)(smem + L::oI);           // [TM][8]
+  float* sW = smem + L::oW;                 // [TM][8]
+  float* sRel = smem + L::oRel;             // [TM][8][3]
+  float* sPts = smem + L::oPts;             // [TM][4]
+  int* sHas = (int*)(smem + L::oHas);       // [TM]
+  float* sCg = smem + L::oCg;               // [TM][34]
+  float* sCc = smem + L::oCc;               // [TM][34]
+  float* sXg = smem + L::oXg;               // [TM][130]
+  float* sXc = smem + L::oXc;               // [TM][170]
+  float* sOcc = smem + L::oOcc;             // [TM]
+  float* sOut = smem + L::oOut;             // [TM][4]
+  float* sXn = smem + L::oXn;               // [128][54]   (one 16-sample sub-tile at a time)
+  float* sHn = smem + L::oHn;               // [8][16][130]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tile = blockIdx.x;
-  const int p0 = tile * TILE;
+  const int spt = a.spt;
+  const int p0 = blockIdx.x * spt;
   const bool color = (a.flags & PSL_STAGE_COLOR) != 0;
   const bool relpos = color && (a.flags & 0x10000) != 0;  // internal bit: encode_rel_pos
   const float* __restrict__ M = a.master;
   const float* __restrict__ WT = a.wt;
+  auto live = [&](int s) { return s < spt && p0 + s < a.P; };
+  auto pidx = [&](int s) { return min(p0 + min(s, spt - 1), a.P - 1); };
 
+  PSL_STAMP(0);
   // ---------------------------------------------------------------- phase 0: neighbours, weights
-  if (t < 128) {
+  if (t < TM * K) {
     const int s = t >> 3, k = t & 7;
-    const int p = min(p0 + s, a.P - 1);
+    const int p = pidx(s);
     SampleGeom g = sample_geom(a, p);
     int i = a.ws.I[p * K + k];
     float nx = 0.f, ny = 0.f, nz = 0.f, D = __int_as_float(0x7F800000);
@@ -65,18 +112,18 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
     sRel[(s * K + k) * 3 + 0] = (i >= 0) ? __fsub_rn(nx, g.x) : 0.f;
     sRel[(s * K + k) * 3 + 1] = (i >= 0) ? __fsub_rn(ny, g.y) : 0.f;
     sRel[(s * K + k) * 3 + 2] = (i >= 0) ? __fsub_rn(nz, g.z) : 0.f;
-    if (p0 + s < a.P) a.ws.w[p * K + k] = w;
+    if (live(s)) a.ws.w[p * K + k] = w;
     if (k == 0) {
       sPts[s * 4 + 0] = g.x; sPts[s * 4 + 1] = g.y; sPts[s * 4 + 2] = g.z; sPts[s * 4 + 3] = g.r2;
       sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;   // has_neighbors (decoder.py:150)
     }
   }
-  __syncthreads();
+  lds_barrier();
 
-  // ---------------------------------------------------------------- phase 1: gathers
-  {
-    const int s = t >> 5, ch = t & 31;
-    const int p = p0 + s;
+  PSL_STAMP(1);
+  // ---------------------------------------------------------------- phase 1: gathers (plain interpolation)
+  for (int e = t; e < TM * C; e += WG) {
+    const int s = e >> 5, ch = e & 31;
     // geometry feature: c = sum_k w_k f[I_k]; no-neighbour samples get the fallback vector (decoder.py:162-171)
     float acc = 0.f;
 #pragma unroll
@@ -86,7 +133,7 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
     }
     if (!sHas[s]) acc = a.fb_geo[ch];
     sCg[s * LD_CF + ch] = acc;
-    if (p < a.P) a.ws.cg[(size_t)p * C + ch] = acc;
+    if (live(s)) a.ws.cg[(size_t)(p0 + s) * C + ch] = acc;
     if (color && !relpos) {
       float ac = 0.f;
 #pragma unroll
@@ -96,93 +143,76 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
       }
       if (!sHas[s]) ac = a.fb_col[ch];
       sCc[s * LD_CF + ch] = ac;
-      if (p < a.P) a.ws.cc[(size_t)p * C + ch] = ac;
+      if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + ch] = ac;
     }
   }
-  if (relpos) {
-    // F_theta input rows [sin(10) cos(10) | feat(32)] for the 128 (sample, neighbour) pairs (decoder.py:371-378)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int e = t + WG * j;
-      int row = e >> 5, ch = e & 31;
-      int i = sI[row];
-      float v = (i >= 0) ? a.col_feats[(size_t)i * C + ch] : 0.f;
-      sXn[row * LD_XN + ER + ch] = v;
-    }
-    const float* Brel = M + MO(PI_C_BREL);
-    for (int e = t; e < 128 * ERF; e += WG) {
-      int row = e / ERF, f = e - row * ERF;
-      float ph = fourier_phase(sRel[row * 3], sRel[row * 3 + 1], sRel[row * 3 + 2], Brel, ERF, f);
-      float sn, cs;
-      sincosf(ph, &sn, &cs);
-      sXn[row * LD_XN + f] = sn;
-      sXn[row * LD_XN + ERF + f] = cs;
-    }
-  }
+  PSL_STAMP(2);
   // ---------------------------------------------------------------- phase 2: Fourier embeddings of p
   {
     const float* Bg = M + MO(PI_G_B);
-    for (int e = t; e < TILE * EGP; e += WG) {
+    for (int e = t; e < TM * EGP; e += WG) {
       int s = e / EGP, f = e - s * EGP;
       float v = 0.f;
       if (f < EG) v = sinf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], Bg, EG, f));
       sXg[s * LD_G + f] = v;
     }
-    if (color && t < TILE * ECF) {
-      int s = t / ECF, f = t - s * ECF;
-      float sn, cs;
-      sincosf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], a.Bcol, ECF, f), &sn, &cs);
-      sXc[s * LD_C + f] = sn;
-      sXc[s * LD_C + ECF + f] = cs;
-      int p = p0 + s;
-      if (p < a.P && a.ws.c_emb) { a.ws.c_emb[(size_t)p * EC + f] = sn; a.ws.c_emb[(size_t)p * EC + ECF + f] = cs; }
+    if (color) {
+      for (int e = t; e < TM * ECF; e += WG) {
+        int s = e / ECF, f = e - s * ECF;
+        float sn, cs;
+        sincosf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], a.Bcol, ECF, f), &sn, &cs);
+        sXc[s * LD_C + f] = sn;
+        sXc[s * LD_C + ECF + f] = cs;
+        if (live(s) && a.ws.c_emb) {
+          a.ws.c_emb[(size_t)(p0 + s) * EC + f] = sn; a.ws.c_emb[(size_t)(p0 + s) * EC + ECF + f] = cs;
+        }
+      }
     }
   }
-  __syncthreads();
-  if (relpos && a.ws.n_x) {
-    for (int e = t; e < 128 * NX; e += WG) {
-      int row = e / NX, c = e - row * NX;
-      int p = p0 + (row >> 3);
-      if (p < a.P) a.ws.n_x[((size_t)p0 * K + row) * NX + c] = sXn[row * LD_XN + c];
-    }
-  }
+  lds_barrier();
 
+  PSL_STAMP(3);
   // ---------------------------------------------------------------- phase 3: geometry MLP (waves 0,1)
   // h = relu(W_i h + b_i) + (Wc_i c + bc_i); after block 2 the embedding is re-attached (decoder.py:207-219)
   {
     const int g4 = 4 * (lane >> 4), colw = lane & 15;
+    const int n0 = 16 * wave;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      f32x4 y = {0.f, 0.f, 0.f, 0.f}, h = {0.f, 0.f, 0.f, 0.f};
-      const int n0 = 16 * wave;
+      f32x4 y[MT], h[MT];
       if (wave < 2) {
-        f32x4 acc;
-        if (i == 0) acc = gemm16<EGP>(sXg, LD_G, WT + wtoff(WT_G_L + 0), HG, n0);
-        else if (i == 3) acc = gemm16<EGP + HG>(sXg, LD_G, WT + wtoff(WT_G_L + 3), HG, n0);
-        else acc = gemm16<HG>(sXg + EGP, LD_G, WT + wtoff(WT_G_L + i), HG, n0);
-        f32x4 u = gemm16<C>(sCg, LD_CF, WT + wtoff(WT_G_FCC + i), HG, n0);
+        f32x4 acc[MT], u[MT];
+        if (i == 0) gemm16m<EGP, MT>(sXg, LD_G, WT + wtoff(WT_G_L + 0), HG, n0, acc);
+        else if (i == 3) gemm16m<EGP + HG, MT>(sXg, LD_G, WT + wtoff(WT_G_L + 3), HG, n0, acc);
+        else gemm16m<HG, MT>(sXg + EGP, LD_G, WT + wtoff(WT_G_L + i), HG, n0, acc);
+        gemm16m<C, MT>(sCg, LD_CF, WT + wtoff(WT_G_FCC + i), HG, n0, u);
         float b = M[MO(PI_G_L + 2 * i + 1) + n0 + colw];
         float bc = M[MO(PI_G_FCC + 2 * i + 1) + n0 + colw];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[r] = fmaxf(acc[r] + b, 0.f);
-          h[r] = y[r] + (u[r] + bc);
-        }
-      }
-      __syncthreads();
-      if (wave < 2) {
-        frag_store(sXg + EGP, LD_G, n0, h);
-        if (a.ws.g_y) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            int p = p0 + g4 + r;
-            if (p < a.P) a.ws.g_y[((size_t)p * 5 + i) * HG + n0 + colw] = y[r];
+            y[m][r] = fmaxf(acc[m][r] + b, 0.f);
+            h[m][r] = y[m][r] + (u[m][r] + bc);
+          }
+      }
+      lds_barrier();
+      if (wave < 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          frag_store(sXg + m * 16 * LD_G + EGP, LD_G, n0, h[m]);
+          if (a.ws.g_y) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int s = 16 * m + g4 + r;
+              if (live(s)) a.ws.g_y[((size_t)i * a.ws.Ppad + p0 + s) * HG + n0 + colw] = y[m][r];
+            }
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
     }
-    if (t < TILE) {  // output_linear 32 -> 1
+    if (t < TM) {  // output_linear 32 -> 1
       const float* wo = M + MO(PI_G_OUT);
       float o = 0.f;
 #pragma unroll
@@ -191,90 +221,134 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
     }
   }
 
+  PSL_STAMP(4);
   if (color) {
-    // -------------------------------------------------------------- phase 4: F_theta per neighbour
+    // -------------------------------------------------------------- phase 4: F_theta per neighbour, 16 samples at a time
     if (relpos) {
-      float* Hw = sHn + wave * 16 * LD_HN;
-      const float* Xw = sXn + wave * 16 * LD_XN;
-      const int g = lane >> 4, colw = lane & 15;
-      {
-        f32x4 acc[8];
-        gemm16_multi<NX, 8>(Xw, LD_XN, WT + wtoff(WT_C_N1), HC, acc);
+      const float* Brel = M + MO(PI_C_BREL);
+      for (int sub = 0; sub < MT; ++sub) {
+        if (16 * sub >= spt) break;
+        const int sb = 16 * sub;                  // first sample slot of this sub-tile
+        // launder the weight pointers: they are loop-invariant, and LICM would hoist ALL weight loads of both
+        // products out of the sub-tile loop (170 live registers -> scratch spills)
+        const float* WTs = WT; const float* Ms = M;
+        asm volatile("" : "+s"(WTs), "+s"(Ms));
+        // F_theta input rows [sin(10) cos(10) | feat(32)] for the 128 (sample, neighbour) pairs (decoder.py:371-378)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          float b = M[MO(PI_C_N1 + 1) + 16 * nt + colw];
-          f32x4 hv;
+        for (int j = 0; j < 8; ++j) {
+          int e = t + WG * j;
+          int row = e >> 5, ch = e & 31;
+          int i = sI[sb * K + row];
+          float v = (i >= 0) ? a.col_feats[(size_t)i * C + ch] : 0.f;
+          sXn[row * LD_XN + ER + ch] = v;
+        }
+        for (int e = t; e < 128 * ERF; e += WG) {
+          int row = e / ERF, f = e - row * ERF;
+          const float* rl = sRel + (sb * K + row) * 3;
+          float sn, cs;
+          sincosf(fourier_phase(rl[0], rl[1], rl[2], Brel, ERF, f), &sn, &cs);
+          sXn[row * LD_XN + f] = sn;
+          sXn[row * LD_XN + ERF + f] = cs;
+        }
+        lds_barrier();
+        if (a.ws.n_x) {
+          for (int e = t; e < 128 * NX; e += WG) {
+            int row = e / NX, c = e - row * NX;
+            if (live(sb + (row >> 3))) a.ws.n_x[((size_t)(p0 + sb) * K + row) * NX + c] = sXn[row * LD_XN + c];
+          }
+        }
+        float* Hw = sHn + wave * 16 * LD_HN;
+        const float* Xw = sXn + wave * 16 * LD_XN;
+        const int g = lane >> 4, colw = lane & 15;
+        {
+          f32x4 acc[8];
+          gemm16_multi<NX, 8>(Xw, LD_XN, WTs + wtoff(WT_C_N1), HC, acc);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = softplus100(acc[nt][r] + b);
-          frag_store(Hw, LD_HN, 16 * nt, hv);
-          if (a.ws.n_h1) {
+          for (int nt = 0; nt < 8; ++nt) {
+            float b = Ms[MO(PI_C_N1 + 1) + 16 * nt + colw];
+            f32x4 hv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int row = 16 * wave + 4 * g + r;
-              if (p0 + (row >> 3) < a.P) a.ws.n_h1[((size_t)p0 * K + row) * HC + 16 * nt + colw] = hv[r];
+            for (int r = 0; r < 4; ++r) hv[r] = softplus100(acc[nt][r] + b);
+            frag_store(Hw, LD_HN, 16 * nt, hv);
+            if (a.ws.n_h1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int row = 16 * wave + 4 * g + r;
+                if (live(sb + (row >> 3))) a.ws.n_h1[((size_t)(p0 + sb) * K + row) * HC + 16 * nt + colw] = hv[r];
+              }
             }
           }
         }
-      }
-      __syncthreads();
-      {
-        f32x4 acc[2];
-        gemm16_multi<HC, 2>(Hw, LD_HN, WT + wtoff(WT_C_N2), C, acc);
-        const int s = 2 * wave + (g >> 1);
+        lds_barrier();
+        {
+          f32x4 acc[2];
+          gemm16_multi<HC, 2>(Hw, LD_HN, WTs + wtoff(WT_C_N2), C, acc);
+          const int s = sb + 2 * wave + (g >> 1);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          float b = M[MO(PI_C_N2 + 1) + 16 * nt + colw];
-          float part = 0.f;
+          for (int nt = 0; nt < 2; ++nt) {
+            float b = Ms[MO(PI_C_N2 + 1) + 16 * nt + colw];
+            float part = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float nf = acc[nt][r] + b;
-            int row = 16 * wave + 4 * g + r;
-            if (a.ws.n_out && p0 + (row >> 3) < a.P) a.ws.n_out[((size_t)p0 * K + row) * C + 16 * nt + colw] = nf;
-            part = __fadd_rn(part, __fmul_rn(sW[s * K + 4 * (g & 1) + r], nf));
-          }
-          float tot = part + __shfl_xor(part, 16);
-          if ((g & 1) == 0) {
-            float c = sHas[s] ? tot : a.fb_col[16 * nt + colw];
-            sCc[s * LD_CF + 16 * nt + colw] = c;
-            if (p0 + s < a.P) a.ws.cc[(size_t)(p0 + s) * C + 16 * nt + colw] = c;
+            for (int r = 0; r < 4; ++r) {
+              float nf = acc[nt][r] + b;
+              int row = 16 * wave + 4 * g + r;
+              if (a.ws.n_out && live(sb + (row >> 3))) a.ws.n_out[((size_t)(p0 + sb) * K + row) * C + 16 * nt + colw] = nf;
+              part = __fadd_rn(part, __fmul_rn(sW[s * K + 4 * (g & 1) + r], nf));
+            }
+            float tot = part + __shfl_xor(part, 16);
+            if ((g & 1) == 0) {
+              float c = sHas[s] ? tot : a.fb_col[16 * nt + colw];
+              sCc[s * LD_CF + 16 * nt + colw] = c;
+              if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + 16 * nt + colw] = c;
+            }
           }
         }
+        lds_barrier();        // sXn / sHn are reused by the next sub-tile
+      }
+      if (MT * 16 > spt) {    // slots of sub-tiles that were skipped: defined (zero) colour features
+        for (int e = t; e < TM * C; e += WG) { int s = e >> 5; if (s >= ((spt + 15) & ~15)) sCc[s * LD_CF + (e & 31)] = 0.f; }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    PSL_STAMP(5);
     // -------------------------------------------------------------- phase 5: colour trunk, 8 waves x 16 columns
     {
       const int n0 = 16 * wave, g4 = 4 * (lane >> 4), colw = lane & 15;
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        f32x4 acc;
-        if (i == 0) acc = gemm16<EC>(sXc, LD_C, WT + wtoff(WT_C_L + 0), HC, n0);
-        else if (i == 3) acc = gemm16<EC + HC>(sXc, LD_C, WT + wtoff(WT_C_L + 3), HC, n0);
-        else acc = gemm16<HC>(sXc + EC, LD_C, WT + wtoff(WT_C_L + i), HC, n0);
-        f32x4 u = gemm16<C>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0);
+        f32x4 acc[MT], u[MT];
+        if (i == 0) gemm16m<EC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 0), HC, n0, acc);
+        else if (i == 3) gemm16m<EC + HC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 3), HC, n0, acc);
+        else gemm16m<HC, MT>(sXc + EC, LD_C, WT + wtoff(WT_C_L + i), HC, n0, acc);
+        gemm16m<C, MT>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0, u);
         float b = M[MO(PI_C_L + 2 * i + 1) + n0 + colw];
         float bc = M[MO(PI_C_FCC + 2 * i + 1) + n0 + colw];
-        f32x4 y, h;
+        f32x4 y[MT], h[MT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          y[r] = softplus100(acc[r] + b);
-          h[r] = y[r] + (u[r] + bc);
-        }
-        __syncthreads();
-        frag_store(sXc + EC, LD_C, n0, h);
-        if (a.ws.c_y) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            int p = p0 + g4 + r;
-            if (p < a.P) {
-              a.ws.c_y[((size_t)p * 5 + i) * HC + n0 + colw] = y[r];
-              a.ws.c_hin[((size_t)p * 5 + i) * HC + n0 + colw] = h[r];
+            y[m][r] = softplus100(acc[m][r] + b);
+            h[m][r] = y[m][r] + (u[m][r] + bc);
+          }
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          frag_store(sXc + m * 16 * LD_C + EC, LD_C, n0, h[m]);
+          if (a.ws.c_y) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int s = 16 * m + g4 + r;
+              if (live(s)) {
+                a.ws.c_y[((size_t)i * a.ws.Ppad + p0 + s) * HC + n0 + colw] = y[m][r];
+                if (a.ws.c_hin) a.ws.c_hin[((size_t)i * a.ws.Ppad + p0 + s) * HC + n0 + colw] = h[m][r];
+              }
             }
           }
         }
-        __syncthreads();
+        lds_barrier();
       }
-      if (t < TILE * 3) {  // output_linear 128 -> 3
+      if (t < TM * 3) {  // output_linear 128 -> 3
         int s = t / 3, j = t - 3 * s;
         const float* wo = M + MO(PI_C_OUT) + j * HC;
         float o = 0.f;
@@ -284,29 +358,28 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
+  PSL_STAMP(6);
   // ------------------------------------------------------------------ raw = [rgb, occ]
-  if (t < TILE) {
+  if (t < TM && live(t)) {
     int p = p0 + t;
-    if (p < a.P) {
-      float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-      if (color) {
-        float r0 = sOut[t * 4], r1 = sOut[t * 4 + 1], r2 = sOut[t * 4 + 2];
-        a.ws.out3[(size_t)p * 4 + 0] = r0; a.ws.out3[(size_t)p * 4 + 1] = r1; a.ws.out3[(size_t)p * 4 + 2] = r2;
-        if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
-          const float* A = a.affine;
-          float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
-          float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
-          float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
-          r0 = q0; r1 = q1; r2 = q2;
-        }
-        if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
-        o0 = r0; o1 = r1; o2 = r2;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (color) {
+      float r0 = sOut[t * 4], r1 = sOut[t * 4 + 1], r2 = sOut[t * 4 + 2];
+      a.ws.out3[(size_t)p * 4 + 0] = r0; a.ws.out3[(size_t)p * 4 + 1] = r1; a.ws.out3[(size_t)p * 4 + 2] = r2;
+      if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
+        const float* A = a.affine;
+        float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
+        float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
+        float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
+        r0 = q0; r1 = q1; r2 = q2;
       }
-      // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
-      float occ = sHas[t] ? sOcc[t] : -100.0f;
-      reinterpret_cast<float4*>(a.ws.raw)[p] = make_float4(o0, o1, o2, occ);
+      if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
+      o0 = r0; o1 = r1; o2 = r2;
     }
+    // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
+    float occ = sHas[t] ? sOcc[t] : -100.0f;
+    reinterpret_cast<float4*>(a.ws.raw)[p] = make_float4(o0, o1, o2, occ);
   }
 }
 
@@ -334,17 +407,49 @@ int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s) {
   return PSL_OK;
 }
 
-int launch_decode_fwd(const DecodeArgs& a, hipStream_t s) {
+// Tile geometry: the smallest samples-per-tile (<= 32) that fits the whole batch in one round of workgroups
+// on the 256 CUs (1 workgroup per CU: the LDS footprint exceeds half of the 160 KiB).
+void choose_tile(int P, int& mt, int& spt) {
+  const int kCUs = 256;
+  if ((P + 15) / 16 <= kCUs) { mt = 1; spt = 16; return; }
+  mt = 2;
+  spt = std::min(32, std::max(17, (P + kCUs - 1) / kCUs));
+}
+
+template <int MT>
+static int launch_fwd_t(const DecodeArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = sizeof(float) * FWD_LDS_FLOATS;
+  const size_t lds = sizeof(float) * FwdLds<MT>::total;
   if (!attr_set) {
-    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  int tiles = (a.P + TILE - 1) / TILE;
-  if (tiles == 0) return PSL_OK;
-  hipLaunchKernelGGL(k_decode_fwd, dim3(tiles), dim3(WG), lds, s, a);
+  int tiles = (a.P + a.spt - 1) / a.spt;
+  hipLaunchKernelGGL(k_decode_fwd<MT>, dim3(tiles), dim3(WG), lds, s, a);
   PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int launch_decode_fwd(const DecodeArgs& a, hipStream_t s) {
+  if (a.P <= 0) return PSL_OK;
+  static unsigned long long* dbg = nullptr;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  DecodeArgs a2 = a;
+  int mt;
+  choose_tile(a.P, mt, a2.spt);
+  if (dbg_on) {
+    if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long)));
+    a2.dbg = dbg;
+  }
+  int rc = (mt == 1) ? launch_fwd_t<1>(a2, s) : launch_fwd_t<2>(a2, s);
+  if (rc) return rc;
+  if (dbg_on) {
+    unsigned long long h[8];
+    PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[psl fwd P=%d flags=%x spt=%d] cycles: p0 %llu p1 %llu p2 %llu geo %llu nbr %llu trunk %llu | total %llu\n",
+            a.P, a.flags, a2.spt, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
+  }
   return PSL_OK;
 }
 

@@ -53,16 +53,19 @@ __device__ __forceinline__ f32x4 gemm16(const float* Xs, int ldx, const float* _
   const int lane = threadIdx.x & 63;
   const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
   const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   constexpr int NK = KDIM / 4;
-#pragma unroll 8
+  // all B fragments of this product are requested before the first MFMA: ONE exposed L2 latency per product
+  // instead of one per unrolled chunk (the weights are L2-resident; a tile is latency-, not bandwidth-bound)
+  float wv[NK];
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
   for (int ks = 0; ks + 1 < NK; ks += 2) {
-    float xa = xp[4 * ks], xb = xp[4 * ks + 4];
-    float wa = wp[(size_t)(4 * ks) * ldw], wb = wp[(size_t)(4 * ks + 4) * ldw];
-    a0 = mfma16(xa, wa, a0);
-    a1 = mfma16(xb, wb, a1);
+    a0 = mfma16(xp[4 * ks], wv[ks], a0);
+    a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1);
   }
-  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wp[(size_t)(4 * (NK - 1)) * ldw], a0);
+  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
   return a0 + a1;
 }
 
@@ -71,6 +74,13 @@ __device__ __forceinline__ void frag_store(float* dst, int ld, int n0, f32x4 v) 
   const int lane = threadIdx.x & 63;
   float* p = dst + (4 * (lane >> 4)) * ld + n0 + (lane & 15);
   p[0] = v[0]; p[ld] = v[1]; p[2 * ld] = v[2]; p[3 * ld] = v[3];
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: hipcc drains
+// vmcnt(0) in front of it, i.e. every barrier would wait for the global STORES of saved activations (HBM write
+// latency, ~1-2 us each) although no wave ever reads them back inside the kernel.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // wave-level sums

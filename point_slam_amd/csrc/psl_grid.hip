@@ -173,10 +173,12 @@ int grid_build(psl_ctx* ctx, hipStream_t s) {
   int n = ctx->n_points;
   hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, ctx->bounds);
   if (n > 0) {
-    int nb = min((n + 255) / 256, 1024);
+    int nb = min((n + 255) / 256, 128);   // few blocks: every wave ends in 6 same-address atomics
     hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(256), 0, s, ctx->pos, n, ctx->bounds);
   }
-  hipLaunchKernelGGL(k_grid_meta, dim3(1), dim3(1), 0, s, ctx->bounds, n, ctx->cfg.max_query_radius, ctx->meta);
+  // cell = a quarter of the largest query radius: ~10-20 points per occupied cell at 10^4 points/m^2, so that the first
+  // (one-cell) ring of the expanding search already holds the 8 nearest neighbours
+  hipLaunchKernelGGL(k_grid_meta, dim3(1), dim3(1), 0, s, ctx->bounds, n, 0.25f * ctx->cfg.max_query_radius, ctx->meta);
   PSL_HIP(hipMemsetAsync(ctx->cell_fill, 0, sizeof(int) * kMaxCells, s));
   const int nblk = kMaxCells / SCAN_B;
   if (n > 0) {
@@ -219,140 +221,142 @@ __device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, floa
   bx.lo[2] = cell_coord(z - rr, m.oz, m.inv_cell, m.nz); bx.hi[2] = cell_coord(z + rr, m.oz, m.inv_cell, m.nz);
 }
 
-// One wavefront scans every cell of `bx` and keeps, for each of its NS queries, the 8 smallest
-// (d2, index) keys with d2 <= r2.  q* and r2 are wave-uniform.
-template <int NS>
+// One wavefront answers one query with an EXPANDING search: scan the cells overlapping the cube [q-rho, q+rho]
+// (rho starts at one cell), keep the 8 smallest (d2, index) keys with d2 <= rho^2; if 8 were found, every
+// unscanned point is farther than rho (some coordinate differs by more than rho) and the result is final;
+// otherwise double rho, until rho reaches the query radius r (final pass admits d2 <= r2 exactly).  At 1 M points
+// (~10^4 points/m^2) the first pass -- <= 27 cells, ~10^2 candidates -- almost always suffices, where a fixed
+// r-sized neighbourhood holds several thousand candidates.
+// The (cz,cy) rows of the cube are x-runs of cells = contiguous ranges of `spos`; their [begin,end) pairs are
+// fetched 64 rows at a time, one row per lane, then walked with coalesced 16 B/lane candidate loads.
 __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
-                                         const int* __restrict__ cell_start, const float (&qx)[NS],
-                                         const float (&qy)[NS], const float (&qz)[NS], float r2, const CellBox& bx,
-                                         u64 (&best)[NS][K]) {
+                                         const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
+                                         float r2, u64 (&best)[K]) {
   const int lane = threadIdx.x & 63;
-  const u64 sentinel = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
+  float rho = m.cell;
+  for (;;) {
+    const bool last = rho >= r;
+    const float re = last ? r : rho;
+    const float t2 = last ? r2 : __fmul_rn(rho, rho);
+    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[s][j] = sentinel;
-  for (int cz = bx.lo[2]; cz <= bx.hi[2]; ++cz) {
-    for (int cy = bx.lo[1]; cy <= bx.hi[1]; ++cy) {
-      const int rowbase = (cz * m.ny + cy) * m.nx;
-      const int beg = cell_start[rowbase + bx.lo[0]];
-      const int end = cell_start[rowbase + bx.hi[0] + 1];
-      for (int j0 = beg; j0 < end; j0 += 64) {
-        const int j = j0 + lane;
-        const bool valid = j < end;
-        float4 c = valid ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const unsigned idx = __float_as_uint(c.w);
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          float d2 = dist2(c.x, c.y, c.z, qx[s], qy[s], qz[s]);
+    for (int j = 0; j < K; ++j) best[j] = sentinel;
+    CellBox bx;
+    box_of(m, qx, qy, qz, re, bx);
+    const int ny_b = bx.hi[1] - bx.lo[1] + 1;
+    const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
+    for (int rb = 0; rb < nrows; rb += 64) {
+      int beg = 0, end = 0;
+      const int row = rb + lane;
+      if (row < nrows) {
+        const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+        const int rowbase = (cz * m.ny + cy) * m.nx;
+        beg = cell_start[rowbase + bx.lo[0]];
+        end = cell_start[rowbase + bx.hi[0] + 1];
+      }
+      const int nr = min(64, nrows - rb);
+      for (int ri = 0; ri < nr; ++ri) {
+        const int b0 = __builtin_amdgcn_readlane(beg, ri), e0 = __builtin_amdgcn_readlane(end, ri);
+        for (int j0 = b0; j0 < e0; j0 += 64) {
+          const int j = j0 + lane;
+          const bool valid = j < e0;
+          float4 c = valid ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const unsigned idx = __float_as_uint(c.w);
+          float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
           u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
-          u64 mask = __ballot(valid && key < best[s][K - 1]);
+          u64 mask = __ballot(valid && key < best[K - 1]);
           while (mask) {
             int l = __builtin_ctzll(mask);
             unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
             unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
-            topk_insert(best[s], ((u64)khi << 32) | klo);
+            topk_insert(best, ((u64)khi << 32) | klo);
             mask &= mask - 1;
-            if (mask) mask &= __ballot(valid && key < best[s][K - 1]);
+            if (mask) mask &= __ballot(valid && key < best[K - 1]);
           }
         }
       }
     }
+    if (last || best[K - 1] != sentinel) break;
+    rho *= 2.0f;
   }
 }
 
-// ray mode: wave per ray, its 5 samples; I_out [R*5][8] int32, cnt_out [R*5]
+__device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lane, unsigned& ib_out, unsigned& db_out,
+                                         int& cnt_out) {
+  // after an early exit the sentinel threshold was rho^2 <= r2: every kept entry has d2 <= rho^2 <= r2
+  const unsigned r2b = __float_as_uint(r2);
+  u64 mine = 0xFFFFFFFFull; int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (lane == j) mine = best[j];
+    unsigned db = (unsigned)(best[j] >> 32), ib = (unsigned)(best[j] & 0xFFFFFFFFull);
+    cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
+  }
+  ib_out = (unsigned)(mine & 0xFFFFFFFFull);
+  db_out = (unsigned)(mine >> 32);
+  cnt_out = cnt;
+}
+
+// ray mode: one wave per SAMPLE (5 per ray); I_out [R*5][8] int32, cnt_out [R*5]
 __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                   const int* __restrict__ cell_start,
                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                   const float* __restrict__ depth, const float* __restrict__ r_query,
-                                                  float r_fixed, float near_s, float far_s, int n_rays,
+                                                  float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                   int* __restrict__ I_out, int* __restrict__ cnt_out) {
-  const int ray = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (ray >= n_rays) return;
+  const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (p >= n_rays * S) return;
+  const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
   const GridMeta m = *meta;
-  const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
-  const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
   const float dep = depth[ray];
-  const float r = r_query ? r_query[ray] : r_fixed;
-  const float r2 = r * r;
-  float qx[S], qy[S], qz[S];
-  CellBox bx;
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    float z = sample_z(dep, s, near_s, far_s);
-    sample_point(ox, oy, oz, dx, dy, dz, z, qx[s], qy[s], qz[s]);
-    CellBox b1;
-    box_of(m, qx[s], qy[s], qz[s], r, b1);
-    if (s == 0) bx = b1;
-    else {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { bx.lo[a] = min(bx.lo[a], b1.lo[a]); bx.hi[a] = max(bx.hi[a], b1.hi[a]); }
-    }
-  }
-  u64 best[S][K];
-  wave_knn<S>(m, spos, cell_start, qx, qy, qz, r2, bx, best);
-  const unsigned r2b = __float_as_uint(r2);
-#pragma unroll
-  for (int s = 0; s < S; ++s) {
-    u64 mine = 0; int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (lane == j) mine = best[s][j];
-      unsigned db = (unsigned)(best[s][j] >> 32), ib = (unsigned)(best[s][j] & 0xFFFFFFFFull);
-      cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
-    }
-    if (lane < K) {
-      unsigned ib = (unsigned)(mine & 0xFFFFFFFFull);
-      I_out[(ray * S + s) * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-    }
-    if (lane == 0) cnt_out[ray * S + s] = cnt;
-  }
+  float r, r2;
+  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  float qx, qy, qz;
+  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+               rays_d[ray * 3 + 2], sample_z(dep, si, near_s, far_s), qx, qy, qz);
+  u64 best[K];
+  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best);
+  unsigned ib, db; int cnt;
+  knn_emit(best, r2, lane, ib, db, cnt);
+  if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
+  if (lane == 0) cnt_out[p] = cnt;
 }
 
 // free-query mode: wave per query; outputs follow find_neighbors_faiss (D f32, I int64, cnt int32)
 __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict__ meta,
                                                      const float4* __restrict__ spos,
                                                      const int* __restrict__ cell_start, const float* __restrict__ q,
-                                                     const float* __restrict__ r_per_query, float r_fixed, int nq,
-                                                     float* __restrict__ D_out, long long* __restrict__ I_out,
+                                                     const float* __restrict__ r_per_query, float r_fixed, float r2_fixed,
+                                                     int nq, float* __restrict__ D_out, long long* __restrict__ I_out,
                                                      int* __restrict__ cnt_out) {
   const int qi = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (qi >= nq) return;
   const int lane = threadIdx.x & 63;
   const GridMeta m = *meta;
-  float qx[1] = {q[qi * 3 + 0]}, qy[1] = {q[qi * 3 + 1]}, qz[1] = {q[qi * 3 + 2]};
-  const float r = r_per_query ? r_per_query[qi] : r_fixed;
-  const float r2 = r * r;
-  CellBox bx;
-  box_of(m, qx[0], qy[0], qz[0], r, bx);
-  u64 best[1][K];
-  wave_knn<1>(m, spos, cell_start, qx, qy, qz, r2, bx, best);
-  const unsigned r2b = __float_as_uint(r2);
-  u64 mine = 0; int cnt = 0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    if (lane == j) mine = best[0][j];
-    unsigned db = (unsigned)(best[0][j] >> 32), ib = (unsigned)(best[0][j] & 0xFFFFFFFFull);
-    cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
-  }
+  float r, r2;
+  if (r_per_query) { r = r_per_query[qi]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  u64 best[K];
+  wave_knn(m, spos, cell_start, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], r, r2, best);
+  unsigned ib, db; int cnt;
+  knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) {
-    unsigned ib = (unsigned)(mine & 0xFFFFFFFFull);
     bool empty = ib == 0xFFFFFFFFu;
     if (I_out) I_out[(long long)qi * K + lane] = empty ? -1ll : (long long)ib;
-    if (D_out) D_out[(long long)qi * K + lane] = empty ? __int_as_float(0x7F800000) : __uint_as_float((unsigned)(mine >> 32));
+    if (D_out) D_out[(long long)qi * K + lane] = empty ? __int_as_float(0x7F800000) : __uint_as_float(db);
   }
   if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
 }
 
+static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
+
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  int blocks = (n_rays + 3) / 4;
+  int blocks = (n_rays * S + 3) / 4;
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                     rays_d, depth, r_query, ctx->cfg.radius_query, ctx->cfg.near_end_surface,
-                     ctx->cfg.far_end_surface, n_rays, I_out, cnt_out);
+                     rays_d, depth, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
@@ -362,7 +366,7 @@ int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_
   if (nq <= 0) return PSL_OK;
   int blocks = (nq + 3) / 4;
   hipLaunchKernelGGL(k_knn_queries, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, q,
-                     r_per_query, r_scalar, nq, D_out, (long long*)I_out, cnt_out);
+                     r_per_query, r_scalar, r2_of(r_scalar), nq, D_out, (long long*)I_out, cnt_out);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

@@ -82,41 +82,70 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
 }
 
 // inside_mask = d <= min(10*median(d), 1.2*max(d)) over the ACTIVE rays; torch.median = lower median
-// (Tracker.py:142-144, Mapper.py:507-509).  One workgroup, bitonic sort in LDS (n <= 16384).
+// (Tracker.py:142-144, Mapper.py:507-509).  One workgroup.  n <= 4096: every thread ranks its own element
+// against all others held in LDS (n^2/1024 compares per thread, no sort, two barriers); larger batches use a
+// 4-pass byte-wise radix select over the float bit patterns (positive floats order like their bits).
 __global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
-  extern __shared__ __attribute__((aligned(16))) float sk[];
-  __shared__ int s_cnt;
-  int npow = 1;
-  while (npow < n) npow <<= 1;
-  if (threadIdx.x == 0) s_cnt = 0;
+  __shared__ unsigned keys[4096];
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_med;
+  if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; s_prefix = 0; s_med = 0; }
   __syncthreads();
-  const float INF = __int_as_float(0x7F800000);
-  int local = 0;
-  for (int i = threadIdx.x; i < npow; i += blockDim.x) {
-    bool a = i < n && active[i];
-    sk[i] = a ? gd[i] : INF;
-    local += a ? 1 : 0;
+  unsigned lc = 0, lm = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    bool a = active[i] != 0;
+    unsigned b = a ? __float_as_uint(gd[i]) : 0xFFFFFFFFu;
+    if (n <= 4096) keys[i] = b;
+    if (a) { lc++; lm = max(lm, b); }
   }
-  atomicAdd(&s_cnt, local);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lm = max(lm, (unsigned)__shfl_xor((int)lm, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, lc); atomicMax(&s_max, lm); }
   __syncthreads();
-  for (int k = 2; k <= npow; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npow; i += blockDim.x) {
-        int l = i ^ j;
-        if (l > i) {
-          float a = sk[i], c = sk[l];
-          bool up = (i & k) == 0;
-          if ((a > c) == up) { sk[i] = c; sk[l] = a; }
+  const unsigned cnt = s_cnt;
+  if (cnt == 0) return;
+  const unsigned want = (cnt - 1) >> 1;
+  if (n <= 4096) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned mine = keys[i];
+      if (mine == 0xFFFFFFFFu) continue;
+      unsigned rank = 0;
+      for (int j = 0; j < n; ++j) {
+        unsigned o = keys[j];
+        rank += (o < mine || (o == mine && j < i)) ? 1u : 0u;
+      }
+      if (rank == want) s_med = mine;
+    }
+    __syncthreads();
+  } else {
+    if (threadIdx.x == 0) s_rank = want;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+      __syncthreads();
+      const unsigned prefix = s_prefix;
+      const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (active[i]) {
+          unsigned b = __float_as_uint(gd[i]);
+          if ((b & himask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
         }
       }
       __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned r = s_rank, acc = 0; int bkt = 0;
+        for (; bkt < 256; ++bkt) { if (acc + hist[bkt] > r) break; acc += hist[bkt]; }
+        s_rank = r - acc;
+        s_prefix = prefix | ((unsigned)bkt << shift);
+      }
+      __syncthreads();
     }
+    if (threadIdx.x == 0) s_med = s_prefix;
+    __syncthreads();
   }
-  int cnt = s_cnt;
-  if (cnt == 0) return;
-  float med = sk[(cnt - 1) >> 1];
-  float mx = sk[cnt - 1];
-  float thr = fminf(10.0f * med, 1.2f * mx);
+  const float med = __uint_as_float(s_med);
+  const float mx = __uint_as_float(s_max);
+  const float thr = fminf(10.0f * med, 1.2f * mx);
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     if (active[i] && !(gd[i] <= thr)) active[i] = 0;
 }
@@ -424,7 +453,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   if (!ctx || !t || !t->pix_idx || !t->cam_tensor || !t->adam_state || !t->ws || !t->frame.depth || !t->frame.color ||
       !t->fallback || !t->best_out) { set_error("psl_track_iters: missing argument"); return PSL_ERR_ARG; }
   if (!t->handle_dynamic) { set_error("psl_track_iters: tracking.handle_dynamic=False (median mask) is not built; every shipped config uses True"); return PSL_ERR_UNSUPPORTED; }
-  if (t->n_pix <= 0 || t->n_pix > 16384) { set_error("psl_track_iters: n_pix must be in [1,16384]"); return PSL_ERR_ARG; }
+  if (t->n_pix <= 0 || t->n_pix > 65536) { set_error("psl_track_iters: n_pix must be in [1,65536]"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_track_iters: index is stale"); return PSL_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   const int n = t->n_pix;
@@ -452,12 +481,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   psl_render_grads rg;
   memset(&rg, 0, sizeof(rg));
   rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_rays_o = b.g_o; rg.g_rays_d = b.g_d;
-  int npow = 1; while (npow < n) npow <<= 1;
   for (int it = 0; it < t->n_iters; ++it) {
     { ProfScope ps(ctx, PROF_MISC, s);
       hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, t->edge_h, t->cam.H - t->edge_h,
                          t->edge_w, t->cam.W - t->edge_w, fdev, 1, n, t->pix_idx + (size_t)it * n, t->cam_tensor, b);
-      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), sizeof(float) * npow, s, b.gd, b.active, n);
+      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), 0, s, b.gd, b.active, n);
       PSL_LAUNCH_CHECK(); }
     ra.fallback_geo = t->fallback + (size_t)it * 64;
     ra.fallback_col = t->fallback + (size_t)it * 64 + 32;
@@ -487,7 +515,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     set_error("psl_map_iters: missing argument"); return PSL_ERR_ARG;
   }
   const int n = m->n_frames * m->pix_per_frame;
-  if (n <= 0 || n > 16384) { set_error("psl_map_iters: n_frames*pix_per_frame must be in [1,16384]"); return PSL_ERR_ARG; }
+  if (n <= 0 || n > 65536) { set_error("psl_map_iters: n_frames*pix_per_frame must be in [1,65536]"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_map_iters: index is stale"); return PSL_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   float* p = m->ws;
@@ -518,7 +546,6 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   memset(&rg, 0, sizeof(rg));
   rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_geo_feats = m->g_geo; rg.g_col_feats = m->g_col;
   rg.feat_row_map = m->row_map; rg.g_params = g_params;
-  int npow = 1; while (npow < n) npow <<= 1;
   const int ncol = psl::kColorFloats;
   for (int it = 0; it < m->n_iters; ++it) {
     // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
@@ -526,7 +553,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     { ProfScope ps(ctx, PROF_MISC, s);
       hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W, fdev,
                          m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, b);
-      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), sizeof(float) * npow, s, b.gd, b.active, n);
+      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), 0, s, b.gd, b.active, n);
       PSL_LAUNCH_CHECK(); }
     ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
     ra.fallback_geo = m->fallback + (size_t)it * 64;
