@@ -88,22 +88,29 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
 __global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
   __shared__ unsigned keys[4096];
   __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_med;
-  if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; s_prefix = 0; s_med = 0; }
+  __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_min, s_med;
+  if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; s_min = 0xFFFFFFFFu; s_prefix = 0; s_med = 0; }
   __syncthreads();
-  unsigned lc = 0, lm = 0;
+  unsigned lc = 0, lm = 0, ln = 0xFFFFFFFFu;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     bool a = active[i] != 0;
     unsigned b = a ? __float_as_uint(gd[i]) : 0xFFFFFFFFu;
     if (n <= 4096) keys[i] = b;
-    if (a) { lc++; lm = max(lm, b); }
+    if (a) { lc++; lm = max(lm, b); ln = min(ln, b); }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lm = max(lm, (unsigned)__shfl_xor((int)lm, o)); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, lc); atomicMax(&s_max, lm); }
+  for (int o = 32; o > 0; o >>= 1) {
+    lc += __shfl_xor(lc, o);
+    lm = max(lm, (unsigned)__shfl_xor((int)lm, o));
+    ln = min(ln, (unsigned)__shfl_xor((int)ln, o));
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, lc); atomicMax(&s_max, lm); atomicMin(&s_min, ln); }
   __syncthreads();
   const unsigned cnt = s_cnt;
   if (cnt == 0) return;
+  // median >= min, so 10*min >= 1.2*max implies thr = 1.2*max >= every depth: nothing to mask and no median
+  // needed (the usual indoor case); the result is identical to evaluating the reference expression
+  if (10.0f * __uint_as_float(s_min) >= 1.2f * __uint_as_float(s_max)) return;
   const unsigned want = (cnt - 1) >> 1;
   if (n <= 4096) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {

@@ -241,3 +241,36 @@ def test_compact_feature_gradients_match_dense():
     # gradient mass outside the frustum selection is dropped by the map (those rows are constants in the reference)
     mask = torch.ones(dense_g.shape[0], dtype=torch.bool); mask[sl] = False
     report(test="compact_grads", n_sel=int(sl.shape[0]), outside_mass=float(dense_g[mask].abs().sum()))
+
+
+def test_depth_outlier_mask_native_matches_dropin():
+    """Depth readings beyond min(10*median, 1.2*max) are dropped before rendering (Tracker.py:142-149): forces the
+    median branch of k_depth_inlier (the common indoor case short-circuits it)."""
+    from point_slam_amd.slam import Frame, camera_tensor_from_c2w
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    fr = frames[1]
+    depth = fr.depth.clone()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    bad = torch.randint(0, depth.numel(), (depth.numel() // 50,), generator=g).to(dev)
+    depth.view(-1)[bad] = 60.0                      # > 10 * median (~2-4 m), <= 1.2 * max
+    depth.view(-1)[bad[:50]] = 0.0                  # and some missing readings
+    fr2 = Frame(1, depth, fr.color, fr.r_add, fr.r_query, fr.c2w)
+    cam0 = camera_tensor_from_c2w(fr.c2w) + torch.tensor([0.001, -0.001, 0.001, 0.0, 0.004, -0.003, 0.002])
+    outs, draws = {}, None
+    for engine in ("dropin", "native"):
+        s = _slam(cfg, cam, engine, dev)
+        s.seed_points(pts)
+        if draws is None:
+            torch.manual_seed(21)
+            draws = s._draws(2, 1500, (cam["H"] - 40) * (cam["W"] - 40))
+        s._draws = lambda *a, **k: draws
+        s.track(fr2, cam0, n_iters=2, n_pix=1500)
+        torch.cuda.synchronize()
+        ls = s.last_losses
+        outs[engine] = torch.tensor(ls) if isinstance(ls, list) else ls.cpu()
+    n_act = outs["native"][:, 3]
+    rel = float(((outs["native"][:, 0] - outs["dropin"]).abs() / outs["dropin"].abs()).max())
+    report(test="depth_outlier_mask", loss_rel=rel, active=[float(x) for x in n_act])
+    assert float(n_act.max()) < 1500 * 0.995            # outliers and holes really were removed
+    assert rel < 3e-4
