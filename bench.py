@@ -204,12 +204,20 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X (no CPU fallback for the product path)")
+    # PSL_BENCH_SHARE_GPU=1 (debug only): all ranks on cuda:0 with the gloo backend, to exercise the N>1 code path
+    # on a one-GPU box; RCCL refuses two ranks on one device
+    share = os.environ.get("PSL_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
     state = dict(mapped=0, new_since=0)

@@ -8,6 +8,7 @@
 // Same tiling as the forward: 16 samples per 512-thread workgroup, every dX = dZ * W product is an
 // exact-fp32 MFMA whose B operand is the torch-layout weight itself ([out][in] row-major).
 #include <cstdio>
+#include <cstdlib>
 #include "psl_decode.h"
 
 namespace psl {
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
   const bool parg = (a.flags & PSL_PARAM_GRAD) != 0 && color;
   const float* __restrict__ M = a.master;
 
+  PSL_STAMP(0);
   // ---------------------------------------------------------------- phase 0: reload per-sample state, zero accumulators
   if (t < 128) {
     const int s = t >> 3, k = t & 7;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
   for (int e = t; e < 16 * LD_DEC; e += WG) sDEc[e] = 0.f;
   lds_barrier();
 
+  PSL_STAMP(1);
   // ================================================================== colour decoder
   if (color) {
     // ---- d(logits): sigmoid and exposure-affine backward (decoder.py:432-448)
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       for (int r = 0; r < 4; ++r) sDCc[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
     }
     lds_barrier();
+    PSL_STAMP(2);
 
     if (!relpos) {
       // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
@@ -225,26 +229,41 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         }
       }
       lds_barrier();
-      // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1)
+      // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1).
+      // All 8 column tiles at once: the saved h1 values (32 loads) and the W2 fragments are requested up front,
+      // so the wave pays one memory latency here instead of one per tile.
+      {
+        float h1v[8][4];
 #pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-        f32x4 dh = gemm16<C>(sDnf, LD_CF, M + MO(PI_C_N2), HC, 16 * nt), dz;
+        for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = 16 * wave + g4 + r;
-          bool live = (p0 + (row >> 3)) < a.P;
-          float h1 = live ? a.ws.n_h1[((size_t)p0 * K + row) * HC + 16 * nt + colw] : 0.f;
-          dz[r] = live ? dh[r] * softplus100_grad_from_out(h1) : 0.f;
-          if (parg && live) a.ws.n_dz1[((size_t)p0 * K + row) * HC + 16 * nt + colw] = dz[r];
+          for (int r = 0; r < 4; ++r) {
+            int row = 16 * wave + g4 + r;
+            bool live = (p0 + (row >> 3)) < a.P;
+            h1v[nt][r] = live ? a.ws.n_h1[((size_t)p0 * K + row) * HC + 16 * nt + colw] : 0.f;
+          }
+        f32x4 dh[8];
+        gemm16_multi<C, 8>(sDnf, LD_CF, M + MO(PI_C_N2), HC, dh);
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+          f32x4 dz;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int row = 16 * wave + g4 + r;
+            bool live = (p0 + (row >> 3)) < a.P;
+            dz[r] = live ? dh[nt][r] * softplus100_grad_from_out(h1v[nt][r]) : 0.f;
+            if (parg && live) a.ws.n_dz1[((size_t)p0 * K + row) * HC + 16 * nt + colw] = dz[r];
+          }
+          frag_store(sDz1, LD_HN, 16 * nt, dz);
         }
-        frag_store(sDz1, LD_HN, 16 * nt, dz);
       }
       lds_barrier();
-      // dX1 = dz1 * W1 (linear1.weight [128][52]): columns [sin 10 | cos 10 | feat 32]
+      // dX1 = dz1 * W1 (linear1.weight [128][52]): columns [sin 10 | cos 10 | feat 32]; 4 column tiles at once
+      {
+        f32x4 dx[4];
+        gemm16_multi<HC, 4>(sDz1, LD_HN, M + MO(PI_C_N1), NX, dx);
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        f32x4 dx = gemm16<HC>(sDz1, LD_HN, M + MO(PI_C_N1), NX, 16 * kt);
-        frag_store(sDx, LD_DXN, 16 * kt, dx);
+        for (int kt = 0; kt < 4; ++kt) frag_store(sDx, LD_DXN, 16 * kt, dx[kt]);
       }
       lds_barrier();
       // feature part -> scatter into the colour feature rows
@@ -261,28 +280,30 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           }
         }
       }
-      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]
-      if (lane < 16 && (parg || ptsg)) {
-        int rl = lane, row = 16 * wave + rl, s = row >> 3;
-        bool live = (p0 + s) < a.P && sI[row] >= 0;
+      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]; one (row, frequency) pair per lane
+      if (parg || ptsg) {
         const float* Brel = M + MO(PI_C_BREL);
-        float rx = sRel[row * 3], ry = sRel[row * 3 + 1], rz = sRel[row * 3 + 2];
-        float ax = 0.f, ay = 0.f, az = 0.f;
-        if (live) {
-#pragma unroll
-          for (int f = 0; f < ERF; ++f) {
-            float sn, cs;
+        for (int e = lane; e < 16 * ERF; e += 64) {
+          int rl = e / ERF, f = e - rl * ERF;
+          int row = 16 * wave + rl, s = row >> 3;
+          bool live = (p0 + s) < a.P && sI[row] >= 0;
+          if (!live) continue;
+          float rx = sRel[row * 3], ry = sRel[row * 3 + 1], rz = sRel[row * 3 + 2];
+          float sn, cs;
+          if (a.ws.n_x) {     // the forward pass saved [sin | cos] in the first 20 columns of F_theta's input
+            const float* xr = a.ws.n_x + ((size_t)p0 * K + row) * NX;
+            sn = xr[f]; cs = xr[ERF + f];
+          } else {
             sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), &sn, &cs);
-            float dy = sDx[rl * LD_DXN + f] * cs - sDx[rl * LD_DXN + ERF + f] * sn;
-            float dy2 = TWO_PI * dy;
-            ax += dy2 * Brel[f]; ay += dy2 * Brel[ERF + f]; az += dy2 * Brel[2 * ERF + f];
-            if (parg) {
-              atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
-              atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
-            }
+          }
+          float dy2 = TWO_PI * (sDx[rl * LD_DXN + f] * cs - sDx[rl * LD_DXN + ERF + f] * sn);
+          if (parg) {
+            atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
+            atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
           }
           if (ptsg) {   // rel = x_k - p  =>  dp -= d_rel
-            atomic_add_f32(&sDP[s * 4], -ax); atomic_add_f32(&sDP[s * 4 + 1], -ay); atomic_add_f32(&sDP[s * 4 + 2], -az);
+            atomic_add_f32(&sDP[s * 4], -dy2 * Brel[f]); atomic_add_f32(&sDP[s * 4 + 1], -dy2 * Brel[ERF + f]);
+            atomic_add_f32(&sDP[s * 4 + 2], -dy2 * Brel[2 * ERF + f]);
           }
         }
       }
@@ -290,6 +311,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
     lds_barrier();
   }
 
+  PSL_STAMP(3);
   // ================================================================== geometry decoder
   {
     // G = d_occ * w_out (output_linear.weight [1][32]); d_occ flows for masked samples too (straight-through)
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
     lds_barrier();
   }
 
+  PSL_STAMP(4);
   // ================================================================== position gradient
   if (ptsg) {
     // (1) interpolation weights: w = a/S, a = [D<=r2]/(D+1e-10), D = |x_k - p|^2   (decoder.py:143-160)
@@ -423,6 +446,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
     if (t < TILE && p0 + t < a.P)
       reinterpret_cast<float4*>(a.ws.dp)[p0 + t] = make_float4(sDP[t * 4], sDP[t * 4 + 1], sDP[t * 4 + 2], 0.f);
   }
+  PSL_STAMP(5);
   // tile-level reductions that go out with a handful of global atomics
   if (parg && relpos && t < 3 * ERF && o.g_brel) atomic_add_f32(&o.g_brel[t], sDB[t]);
   if ((a.flags & PSL_HAS_AFFINE) && color && t < 12 && o.g_affine) atomic_add_f32(&o.g_affine[t], sAff[t]);
@@ -451,10 +475,21 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   o.g_brel = small;
   o.g_affine = small + 32;
   int tiles = (a.P + TILE - 1) / TILE;
+  static unsigned long long* dbg = nullptr;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  DecodeArgs a2 = a;
+  if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
   {
     ProfScope ps(ctx, PROF_DECODE_BWD, s, bwd_flops_per_sample(a.flags) * a.P);
-    hipLaunchKernelGGL(k_decode_bwd, dim3(tiles), dim3(WG), lds, s, a, o);
+    hipLaunchKernelGGL(k_decode_bwd, dim3(tiles), dim3(WG), lds, s, a2, o);
     PSL_LAUNCH_CHECK();
+  }
+  if (dbg_on) {
+    unsigned long long h[8];
+    PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[psl bwd P=%d flags=%x] cycles: p0 %llu col_trunk %llu col_nbr %llu geo %llu dp %llu | total %llu\n", a.P,
+            a.flags, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[5] - h[0]);
   }
   if ((a.flags & PSL_HAS_AFFINE) && color)
     PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
