@@ -565,7 +565,9 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
     ra.fallback_geo = m->fallback + (size_t)it * 64;
     ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
-    int rc = render_fwd_impl(ctx, &ra, s, true);
+    // the forward weights only change after the decoder was stepped (colour stage with train_decoder)
+    const bool repack = it == 0 || (m->train_decoder && it >= m->n_geo_iters + 2);
+    int rc = render_fwd_impl(ctx, &ra, s, repack);
     if (rc) return rc;
     hipLaunchKernelGGL(k_mapper_loss, dim3(1), dim3(1024), 0, s, b, n, m->w_color, color_stage ? 1 : 0,
                        m->loss_out ? m->loss_out + 4 * (size_t)it : loss_scratch);
