@@ -15,12 +15,24 @@ namespace psl {
 
 constexpr int LD_DE = 98;   // geo d_emb tile [16][96]  (98/2 odd)
 constexpr int LD_DEC = 50;  // colour d_emb tile [16][40..48]
-constexpr int LD_DXN = 66;
+constexpr int LD_Z1 = 66;   // half of F_theta's dz1 tile, per wave [16][64]
+constexpr int LD_XE = 22;   // rel-pos part of F_theta's dX1 tile, per wave [16][20]
+constexpr int PW = 16 * LD_CF + 16 * LD_Z1 + 16 * LD_XE;   // per-wave F_theta scratch
 
-constexpr int BWD_LDS_FLOATS = 128 + 128 + 384 + 64 + 16 + /*sGW*/ 128 + /*sDP*/ 64 + /*sDB*/ 32 + /*sAff*/ 16 +
-                               /*sG*/ 16 * LD_C + /*sDZ*/ 16 * LD_HN + /*sDEg*/ 16 * LD_DE + /*sDEc*/ 16 * LD_DEC +
-                               /*sDCg,sDCc*/ 2 * 16 * LD_CF + /*sDO*/ 64 +
-                               /*per wave: dnf [16][34] + dz1 [16][130] + dx [16][66]*/ 8 * (16 * LD_CF + 16 * LD_HN + 16 * LD_DXN);
+// LDS plan.  The per-wave F_theta scratch ALIASES the trunk tiles sG/sDZ (dead between the colour-trunk and the
+// geometry backward), F_theta's dz1 is processed in two 64-column halves and its feature gradients are scattered
+// straight from the MFMA registers, and the position-gradient tiles exist only in the PTSG instantiation: the
+// mapper instantiation needs 70 KB, so TWO workgroups share a CU and a 5 000-sample batch (313 tiles) is resident
+// in one round instead of two.
+template <bool PTSG>
+struct BwdLds {
+  static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oDB = 720, oAff = 752, oDO = 768,
+                       oDCg = 832, oDCc = oDCg + 16 * LD_CF, oP = oDCc + 16 * LD_CF;
+  static constexpr int oGW = oP, oDP = oGW + (PTSG ? 128 : 0), oDEg = oDP + (PTSG ? 64 : 0),
+                       oDEc = oDEg + (PTSG ? 16 * LD_DE : 0), oU = oDEc + (PTSG ? 16 * LD_DEC : 0);
+  static constexpr int oG = oU, oDZ = oG + 16 * LD_HN, trunk = 2 * 16 * LD_HN, waves = 8 * PW;
+  static constexpr int total = oU + (trunk > waves ? trunk : waves);
+};
 
 struct BwdOut {
   float* g_geo; float* g_col; const int* row_map;
@@ -37,25 +49,27 @@ __device__ __forceinline__ f32x4 frag_load(const float* src, int ld, int n0) {
   return v;
 }
 
-__global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
+template <bool PTSG>
+__global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, BwdOut o) {
+  using L = BwdLds<PTSG>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* sI = (int*)smem;                     // [16][8]
-  float* sW = smem + 128;                   // [16][8] normalised weights
-  float* sRel = sW + 128;                   // [16][8][3]
-  float* sPts = sRel + 384;                 // [16][4]
-  int* sHas = (int*)(sPts + 64);            // [16]
-  float* sGW = (float*)(sHas + 16);         // [16][8] dL/dw
-  float* sDP = sGW + 128;                   // [16][4] dL/dp
-  float* sDB = sDP + 64;                    // [32]    dL/dB_rel (30 used)
-  float* sAff = sDB + 32;                   // [16]    dL/d affine (12 used)
-  float* sG = sAff + 16;                    // [16][170] dL/dh tile (colour uses cols 0..127, geo 0..31)
-  float* sDZ = sG + 16 * LD_C;              // [16][130]
-  float* sDEg = sDZ + 16 * LD_HN;           // [16][98]  dL/d geo embedding
-  float* sDEc = sDEg + 16 * LD_DE;          // [16][50]  dL/d colour embedding
-  float* sDCg = sDEc + 16 * LD_DEC;         // [16][34]  dL/d c_geo
-  float* sDCc = sDCg + 16 * LD_CF;          // [16][34]  dL/d c_col
-  float* sDO = sDCc + 16 * LD_CF;           // [16][4]   dL/d colour logits (pre-affine)
-  float* sWave = sDO + 64;                  // per wave scratch
+  int* sI = (int*)(smem + L::oI);           // [16][8]
+  float* sW = smem + L::oW;                 // [16][8] normalised weights
+  float* sRel = smem + L::oRel;             // [16][8][3]
+  float* sPts = smem + L::oPts;             // [16][4]
+  int* sHas = (int*)(smem + L::oHas);       // [16]
+  float* sDB = smem + L::oDB;               // [32]    dL/dB_rel (30 used)
+  float* sAff = smem + L::oAff;             // [16]    dL/d affine (12 used)
+  float* sDO = smem + L::oDO;               // [16][4] dL/d colour logits (pre-affine)
+  float* sDCg = smem + L::oDCg;             // [16][34] dL/d c_geo
+  float* sDCc = smem + L::oDCc;             // [16][34] dL/d c_col
+  float* sGW = smem + L::oGW;               // [16][8]  dL/dw            (PTSG only)
+  float* sDP = smem + L::oDP;               // [16][4]  dL/dp            (PTSG only)
+  float* sDEg = smem + L::oDEg;             // [16][98] dL/d geo emb     (PTSG only)
+  float* sDEc = smem + L::oDEc;             // [16][50] dL/d colour emb  (PTSG only)
+  float* sG = smem + L::oG;                 // [16][130] dL/dh tile (colour: cols 0..127, geo 0..31)
+  float* sDZ = smem + L::oDZ;               // [16][130]
+  float* sWave = smem + L::oU;              // per-wave F_theta scratch, aliases sG/sDZ
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
   const int p0 = blockIdx.x * TILE;
   const bool color = (a.flags & PSL_STAGE_COLOR) != 0;
   const bool relpos = color && (a.flags & 0x10000) != 0;
-  const bool ptsg = (a.flags & PSL_PTS_GRAD) != 0;
+  constexpr bool ptsg = PTSG;
   const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
   const bool parg = (a.flags & PSL_PARAM_GRAD) != 0 && color;
   const float* __restrict__ M = a.master;
@@ -84,18 +98,20 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
     sI[s * K + k] = i;
     sW[s * K + k] = a.ws.w[p * K + k];
     sRel[(s * K + k) * 3 + 0] = rx; sRel[(s * K + k) * 3 + 1] = ry; sRel[(s * K + k) * 3 + 2] = rz;
-    sGW[s * K + k] = 0.f;
+    if constexpr (PTSG) sGW[s * K + k] = 0.f;
     if (k == 0) {
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
       // samples past the end of the batch behave as "no neighbours, zero gradient"
       sHas[s] = (p0 + s < a.P && a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
     }
   }
-  if (t < 64) sDP[t] = 0.f;
   if (t < 32) sDB[t] = 0.f;
   if (t < 16) sAff[t] = 0.f;
-  for (int e = t; e < 16 * LD_DE; e += WG) sDEg[e] = 0.f;
-  for (int e = t; e < 16 * LD_DEC; e += WG) sDEc[e] = 0.f;
+  if constexpr (PTSG) {
+    if (t < 64) sDP[t] = 0.f;
+    for (int e = t; e < 16 * LD_DE; e += WG) sDEg[e] = 0.f;
+    for (int e = t; e < 16 * LD_DEC; e += WG) sDEc[e] = 0.f;
+  }
   lds_barrier();
 
   PSL_STAMP(1);
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       const float* wo = M + MO(PI_C_OUT);
       for (int e = t; e < TILE * HC; e += WG) {
         int s = e >> 7, k = e & 127;
-        sG[s * LD_C + k] = sDO[s * 4] * wo[k] + sDO[s * 4 + 1] * wo[HC + k] + sDO[s * 4 + 2] * wo[2 * HC + k];
+        sG[s * LD_HN + k] = sDO[s * 4] * wo[k] + sDO[s * 4 + 1] * wo[HC + k] + sDO[s * 4 + 2] * wo[2 * HC + k];
       }
     }
     lds_barrier();
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
       // step A: dz = G * act'(y)
-      f32x4 gv = frag_load(sG, LD_C, n0), dz;
+      f32x4 gv = frag_load(sG, LD_HN, n0), dz;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int p = p0 + g4 + r;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       }
       frag_store(sDZ, LD_HN, n0, dz);
       // step B: dL/dc += G * Wc_i   (fc_c.i.weight [128][32])
-      if (wave < 2) dcacc += gemm16<HC>(sG, LD_C, M + MO(PI_C_FCC + 2 * i), C, n0);
+      if (wave < 2) dcacc += gemm16<HC>(sG, LD_HN, M + MO(PI_C_FCC + 2 * i), C, n0);
       lds_barrier();
       // step C: dL/d(input of layer i) = dz * W_i   (pts_linears.i.weight [128][Kin])
       f32x4 gn = {0.f, 0.f, 0.f, 0.f}, ge = {0.f, 0.f, 0.f, 0.f};
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         gn = gemm16<HC>(sDZ, LD_HN, Wi, HC, n0);
       }
       lds_barrier();
-      if (i > 0) frag_store(sG, LD_C, n0, gn);
+      if (i > 0) frag_store(sG, LD_HN, n0, gn);
       if ((i == 3 || i == 0) && ptsg && wave < 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (n0 + colw < EC) sDEc[(g4 + r) * LD_DEC + n0 + colw] += ge[r];
@@ -206,10 +222,11 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         }
       }
     } else {
-      // ---- F_theta backward, one wave per 16 (sample, neighbour) rows
-      float* sDnf = sWave + wave * (16 * LD_CF + 16 * LD_HN + 16 * LD_DXN);
-      float* sDz1 = sDnf + 16 * LD_CF;
-      float* sDx = sDz1 + 16 * LD_HN;
+      // ---- F_theta backward, one wave per 16 (sample, neighbour) rows.  Everything below is wave-private (its own
+      // scratch, its own rows), so the waves only order their own LDS traffic (s_waitcnt) and never meet at a barrier.
+      float* sDnf = sWave + wave * PW;          // [16][34]  A operand of dH1 = d_nf * W2
+      float* sDz1 = sDnf + 16 * LD_CF;          // [16][66]  one 64-column half of dz1
+      float* sDxe = sDz1 + 16 * LD_Z1;          // [16][22]  rel-pos part of dX1
       // d_nf[row][ch] = w[s][k] * dC[s][ch];  dL/dw[s][k] = sum_ch nf[row][ch] dC[s][ch]
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -221,65 +238,71 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
         sDnf[rl * LD_CF + ch] = dnf;
         bool live = (p0 + s) < a.P;
         if (parg && live) a.ws.n_dnf[((size_t)p0 * K + row) * C + ch] = dnf;
-        if (ptsg) {
+        if constexpr (PTSG) {
           float v = live ? a.ws.n_out[((size_t)p0 * K + row) * C + ch] * dc : 0.f;
 #pragma unroll
           for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
           if (ch == 0) sGW[s * K + k] += v;     // one writer per (s,k): this wave owns rows 16w..16w+15
         }
       }
-      lds_barrier();
-      // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1).
-      // All 8 column tiles at once: the saved h1 values (32 loads) and the W2 fragments are requested up front,
-      // so the wave pays one memory latency here instead of one per tile.
-      {
-        float h1v[8][4];
+      wave_lds_sync();
+      // dH1 = d_nf * W2 (linear2.weight [32][128]); dz1 = dH1 * softplus'(h1); dX1 = dz1 * W1 (linear1.weight
+      // [128][52], columns [sin 10 | cos 10 | feat 32]) -- in two 64-column halves of the hidden layer.  The saved
+      // h1 values and the weight fragments of a half are requested up front (one exposed latency per product).
+      f32x4 dxa[4];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
+      for (int kt = 0; kt < 4; ++kt) dxa[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float h1v[4][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             int row = 16 * wave + g4 + r;
             bool live = (p0 + (row >> 3)) < a.P;
-            h1v[nt][r] = live ? a.ws.n_h1[((size_t)p0 * K + row) * HC + 16 * nt + colw] : 0.f;
+            h1v[nt][r] = live ? a.ws.n_h1[((size_t)p0 * K + row) * HC + 64 * half + 16 * nt + colw] : 0.f;
           }
-        f32x4 dh[8];
-        gemm16_multi<C, 8>(sDnf, LD_CF, M + MO(PI_C_N2), HC, dh);
+        f32x4 dh[4];
+        gemm16_multi<C, 4>(sDnf, LD_CF, M + MO(PI_C_N2) + 64 * half, HC, dh);
+        if (half) wave_lds_sync();      // the first half's dz1 tile has been consumed
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
+        for (int nt = 0; nt < 4; ++nt) {
           f32x4 dz;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             int row = 16 * wave + g4 + r;
             bool live = (p0 + (row >> 3)) < a.P;
             dz[r] = live ? dh[nt][r] * softplus100_grad_from_out(h1v[nt][r]) : 0.f;
-            if (parg && live) a.ws.n_dz1[((size_t)p0 * K + row) * HC + 16 * nt + colw] = dz[r];
+            if (parg && live) a.ws.n_dz1[((size_t)p0 * K + row) * HC + 64 * half + 16 * nt + colw] = dz[r];
           }
-          frag_store(sDz1, LD_HN, 16 * nt, dz);
+          frag_store(sDz1, LD_Z1, 16 * nt, dz);
         }
-      }
-      lds_barrier();
-      // dX1 = dz1 * W1 (linear1.weight [128][52]): columns [sin 10 | cos 10 | feat 32]; 4 column tiles at once
-      {
+        wave_lds_sync();
         f32x4 dx[4];
-        gemm16_multi<HC, 4>(sDz1, LD_HN, M + MO(PI_C_N1), NX, dx);
+        gemm16_multi<64, 4>(sDz1, LD_Z1, M + MO(PI_C_N1) + 64 * half * NX, NX, dx);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) frag_store(sDx, LD_DXN, 16 * kt, dx[kt]);
+        for (int kt = 0; kt < 4; ++kt) dxa[kt] += dx[kt];
       }
-      lds_barrier();
-      // feature part -> scatter into the colour feature rows
-      if (featg) {
+      // feature part (columns 20..51) -> scattered into the colour feature rows straight from the MFMA registers;
+      // rel-pos part (columns 0..19) -> small LDS tile
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          int e = lane + 64 * j;
-          int rl = e >> 5, ch = e & 31;
-          int row = 16 * wave + rl;
-          int i = sI[row];
-          if (i >= 0 && sW[row] != 0.f && sHas[row >> 3]) {
-            int dst = o.row_map ? o.row_map[i] : i;
-            if (dst >= 0) atomic_add_f32(&o.g_col[(size_t)dst * C + ch], sDx[rl * LD_DXN + ER + ch]);
+      for (int kt = 0; kt < 4; ++kt) {
+        const int col = 16 * kt + colw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = g4 + r, row = 16 * wave + rl;
+          if (col < ER) sDxe[rl * LD_XE + col] = dxa[kt][r];
+          else if (featg && col < NX) {
+            int i = sI[row];
+            if (i >= 0 && sW[row] != 0.f && sHas[row >> 3]) {
+              int dst = o.row_map ? o.row_map[i] : i;
+              if (dst >= 0) atomic_add_f32(&o.g_col[(size_t)dst * C + col - ER], dxa[kt][r]);
+            }
           }
         }
       }
+      wave_lds_sync();
       // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]; one (row, frequency) pair per lane
       if (parg || ptsg) {
         const float* Brel = M + MO(PI_C_BREL);
@@ -296,12 +319,12 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           } else {
             sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), &sn, &cs);
           }
-          float dy2 = TWO_PI * (sDx[rl * LD_DXN + f] * cs - sDx[rl * LD_DXN + ERF + f] * sn);
+          float dy2 = TWO_PI * (sDxe[rl * LD_XE + f] * cs - sDxe[rl * LD_XE + ERF + f] * sn);
           if (parg) {
             atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
             atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
           }
-          if (ptsg) {   // rel = x_k - p  =>  dp -= d_rel
+          if constexpr (PTSG) {   // rel = x_k - p  =>  dp -= d_rel
             atomic_add_f32(&sDP[s * 4], -dy2 * Brel[f]); atomic_add_f32(&sDP[s * 4 + 1], -dy2 * Brel[ERF + f]);
             atomic_add_f32(&sDP[s * 4 + 2], -dy2 * Brel[2 * ERF + f]);
           }
@@ -319,7 +342,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
       int s = t >> 5, k = t & 31;
       int p = p0 + s;
       float docc = (p < a.P) ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
-      sG[s * LD_C + k] = docc * M[MO(PI_G_OUT) + k];
+      sG[s * LD_HN + k] = docc * M[MO(PI_G_OUT) + k];
     }
     lds_barrier();
     f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
       if (wave < 2) {
-        f32x4 gv = frag_load(sG, LD_C, n0), dz;
+        f32x4 gv = frag_load(sG, LD_HN, n0), dz;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int p = p0 + g4 + r;
@@ -335,7 +358,7 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           dz[r] = (p < a.P && y > 0.f) ? gv[r] : 0.f;       // ReLU
         }
         frag_store(sDZ, LD_HN, n0, dz);
-        dcacc += gemm16<HG>(sG, LD_C, M + MO(PI_G_FCC + 2 * i), C, n0);   // fc_c.i.weight [32][32]
+        dcacc += gemm16<HG>(sG, LD_HN, M + MO(PI_G_FCC + 2 * i), C, n0);   // fc_c.i.weight [32][32]
       }
       lds_barrier();
       const float* Wi = M + MO(PI_G_L + 2 * i);
@@ -352,11 +375,11 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
           int col = n0 + colw;
           if (i == 3) {
             if (col < EG) { if (ptsg) sDEg[(g4 + r) * LD_DE + col] += gx[r]; }
-            else if (col < Kin) sG[(g4 + r) * LD_C + col - EG] = gx[r];
+            else if (col < Kin) sG[(g4 + r) * LD_HN + col - EG] = gx[r];
           } else if (i == 0) {
             if (col < EG) sDEg[(g4 + r) * LD_DE + col] += gx[r];
           } else {
-            sG[(g4 + r) * LD_C + col] = gx[r];
+            sG[(g4 + r) * LD_HN + col] = gx[r];
           }
         }
       }
@@ -454,13 +477,20 @@ __global__ __launch_bounds__(WG) void k_decode_bwd(DecodeArgs a, BwdOut o) {
 
 int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g_brel, hipStream_t s);
 
-int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s) {
+template <bool PTSG>
+static int launch_bwd_t(const DecodeArgs& a, const BwdOut& o, int tiles, hipStream_t s) {
   static bool attr_set = false;
-  const size_t lds = sizeof(float) * BWD_LDS_FLOATS;
+  const size_t lds = sizeof(float) * BwdLds<PTSG>::total;
   if (!attr_set) {
-    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd<PTSG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  hipLaunchKernelGGL(k_decode_bwd<PTSG>, dim3(tiles), dim3(WG), lds, s, a, o);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s) {
   const bool color = a.flags & PSL_STAGE_COLOR;
   if ((a.flags & PSL_FEAT_GRAD) && (!g.g_geo_feats || (color && !g.g_col_feats))) {
     set_error("psl_render_bwd: PSL_FEAT_GRAD needs g_geo_feats/g_col_feats"); return PSL_ERR_ARG;
@@ -482,8 +512,8 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
   {
     ProfScope ps(ctx, PROF_DECODE_BWD, s, bwd_flops_per_sample(a.flags) * a.P);
-    hipLaunchKernelGGL(k_decode_bwd, dim3(tiles), dim3(WG), lds, s, a2, o);
-    PSL_LAUNCH_CHECK();
+    int rc = (a.flags & PSL_PTS_GRAD) ? launch_bwd_t<true>(a2, o, tiles, s) : launch_bwd_t<false>(a2, o, tiles, s);
+    if (rc) return rc;
   }
   if (dbg_on) {
     unsigned long long h[8];

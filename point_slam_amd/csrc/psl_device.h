@@ -92,6 +92,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// orders one wave's own LDS writes before its later LDS reads (wave-private scratch needs no workgroup barrier)
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // wave-level sums
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
