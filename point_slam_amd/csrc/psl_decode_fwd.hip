@@ -23,10 +23,16 @@ namespace psl {
 template <int MT>
 struct FwdLds {
   static constexpr int TM = 16 * MT;
+  // The F_theta tiles (sXn, per-wave half-hidden sHn) and the decoder input tiles (sXg, sXc) live in the SAME
+  // region: F_theta runs first, the Fourier embeddings are written afterwards.  69 KB (MT=1) / 77 KB (MT=2):
+  // two workgroups per CU.
+  static constexpr int LD_HH = 66;   // one 64-column half of F_theta's hidden layer, per wave [16][64]
   static constexpr int oI = 0, oW = oI + TM * K, oRel = oW + TM * K, oPts = oRel + TM * K * 3, oHas = oPts + TM * 4,
-                       oCg = oHas + TM, oCc = oCg + TM * LD_CF, oXg = oCc + TM * LD_CF, oXc = oXg + TM * LD_G,
-                       oOcc = oXc + TM * LD_C, oOut = oOcc + TM, oXn = oOut + TM * 4, oHn = oXn + 128 * LD_XN,
-                       total = oHn + 8 * 16 * LD_HN;
+                       oCg = oHas + TM, oCc = oCg + TM * LD_CF, oOcc = oCc + TM * LD_CF, oOut = oOcc + TM,
+                       oU = oOut + TM * 4;
+  static constexpr int oXn = oU, oHn = oXn + 128 * LD_XN, nbr = 128 * LD_XN + 8 * 16 * LD_HH;
+  static constexpr int oXg = oU, oXc = oXg + TM * LD_G, dec = TM * LD_G + TM * LD_C;
+  static constexpr int total = oU + (nbr > dec ? nbr : dec);
 };
 
 // acc[mt](16 x 16 slice at column n0) = X[mt*16 .. +16][K] * W[K][N]; the B fragments are fetched once and shared
@@ -59,7 +65,7 @@ __device__ __forceinline__ void gemm16m(const float* Xs, int ldx, const float* _
 }
 
 template <int MT>
-__global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
+__global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
   using L = FwdLds<MT>;
   constexpr int TM = L::TM;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
   float* sOcc = smem + L::oOcc;             // [TM]
   float* sOut = smem + L::oOut;             // [TM][4]
   float* sXn = smem + L::oXn;               // [128][54]   (one 16-sample sub-tile at a time)
-  float* sHn = smem + L::oHn;               // [8][16][130]
+  float* sHn = smem + L::oHn;               // [8][16][66]  (aliases sXg/sXc together with sXn)
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -146,6 +152,102 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
       if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + ch] = ac;
     }
   }
+  lds_barrier();
+  // ---------------------------------------------------------------- F_theta per neighbour, 16 samples at a time
+  if (color) {
+  if (relpos) {
+    const float* Brel = M + MO(PI_C_BREL);
+    for (int sub = 0; sub < MT; ++sub) {
+      if (16 * sub >= spt) break;
+      const int sb = 16 * sub;                  // first sample slot of this sub-tile
+      // launder the weight pointers: they are loop-invariant, and LICM would hoist ALL weight loads of both
+      // products out of the sub-tile loop (170 live registers -> scratch spills)
+      const float* WTs = WT; const float* Ms = M;
+      asm volatile("" : "+s"(WTs), "+s"(Ms));
+      // F_theta input rows [sin(10) cos(10) | feat(32)] for the 128 (sample, neighbour) pairs (decoder.py:371-378)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int e = t + WG * j;
+        int row = e >> 5, ch = e & 31;
+        int i = sI[sb * K + row];
+        float v = (i >= 0) ? a.col_feats[(size_t)i * C + ch] : 0.f;
+        sXn[row * LD_XN + ER + ch] = v;
+      }
+      for (int e = t; e < 128 * ERF; e += WG) {
+        int row = e / ERF, f = e - row * ERF;
+        const float* rl = sRel + (sb * K + row) * 3;
+        float sn, cs;
+        sincosf(fourier_phase(rl[0], rl[1], rl[2], Brel, ERF, f), &sn, &cs);
+        sXn[row * LD_XN + f] = sn;
+        sXn[row * LD_XN + ERF + f] = cs;
+      }
+      lds_barrier();
+      if (a.ws.n_x) {
+        for (int e = t; e < 128 * NX; e += WG) {
+          int row = e / NX, c = e - row * NX;
+          if (live(sb + (row >> 3))) a.ws.n_x[((size_t)(p0 + sb) * K + row) * NX + c] = sXn[row * LD_XN + c];
+        }
+      }
+      float* Hw = sHn + wave * 16 * L::LD_HH;
+      const float* Xw = sXn + wave * 16 * LD_XN;
+      const int g = lane >> 4, colw = lane & 15;
+      // hidden layer in two 64-column halves: linear1 -> softplus -> (wave-private LDS tile) -> partial linear2
+      f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4 acc[4];
+        gemm16_multi<NX, 4>(Xw, LD_XN, WTs + wtoff(WT_C_N1) + 64 * half, HC, acc);
+        if (half) wave_lds_sync();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = 64 * half + 16 * nt + colw;
+          float b = Ms[MO(PI_C_N1 + 1) + col];
+          f32x4 hv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[r] = softplus100(acc[nt][r] + b);
+          frag_store(Hw, L::LD_HH, 16 * nt, hv);
+          if (a.ws.n_h1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int row = 16 * wave + 4 * g + r;
+              if (live(sb + (row >> 3))) a.ws.n_h1[((size_t)(p0 + sb) * K + row) * HC + col] = hv[r];
+            }
+          }
+        }
+        wave_lds_sync();
+        f32x4 part[2];
+        gemm16_multi<64, 2>(Hw, L::LD_HH, WTs + wtoff(WT_C_N2) + 64 * half * C, C, part);
+        acc2[0] += part[0]; acc2[1] += part[1];
+      }
+      {
+        const int s = sb + 2 * wave + (g >> 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float b = Ms[MO(PI_C_N2 + 1) + 16 * nt + colw];
+          float part = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float nf = acc2[nt][r] + b;
+            int row = 16 * wave + 4 * g + r;
+            if (a.ws.n_out && live(sb + (row >> 3))) a.ws.n_out[((size_t)(p0 + sb) * K + row) * C + 16 * nt + colw] = nf;
+            part = __fadd_rn(part, __fmul_rn(sW[s * K + 4 * (g & 1) + r], nf));
+          }
+          float tot = part + __shfl_xor(part, 16);
+          if ((g & 1) == 0) {
+            float c = sHas[s] ? tot : a.fb_col[16 * nt + colw];
+            sCc[s * LD_CF + 16 * nt + colw] = c;
+            if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + 16 * nt + colw] = c;
+          }
+        }
+      }
+      lds_barrier();        // sXn / sHn are reused by the next sub-tile
+    }
+    if (MT * 16 > spt) {    // slots of sub-tiles that were skipped: defined (zero) colour features
+      for (int e = t; e < TM * C; e += WG) { int s = e >> 5; if (s >= ((spt + 15) & ~15)) sCc[s * LD_CF + (e & 31)] = 0.f; }
+    }
+  }
+  }
+  lds_barrier();      // sXn/sHn are dead from here on: their region now receives the decoder inputs
   PSL_STAMP(2);
   // ---------------------------------------------------------------- phase 2: Fourier embeddings of p
   {
@@ -223,92 +325,6 @@ __global__ __launch_bounds__(WG) void k_decode_fwd(DecodeArgs a) {
 
   PSL_STAMP(4);
   if (color) {
-    // -------------------------------------------------------------- phase 4: F_theta per neighbour, 16 samples at a time
-    if (relpos) {
-      const float* Brel = M + MO(PI_C_BREL);
-      for (int sub = 0; sub < MT; ++sub) {
-        if (16 * sub >= spt) break;
-        const int sb = 16 * sub;                  // first sample slot of this sub-tile
-        // launder the weight pointers: they are loop-invariant, and LICM would hoist ALL weight loads of both
-        // products out of the sub-tile loop (170 live registers -> scratch spills)
-        const float* WTs = WT; const float* Ms = M;
-        asm volatile("" : "+s"(WTs), "+s"(Ms));
-        // F_theta input rows [sin(10) cos(10) | feat(32)] for the 128 (sample, neighbour) pairs (decoder.py:371-378)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          int e = t + WG * j;
-          int row = e >> 5, ch = e & 31;
-          int i = sI[sb * K + row];
-          float v = (i >= 0) ? a.col_feats[(size_t)i * C + ch] : 0.f;
-          sXn[row * LD_XN + ER + ch] = v;
-        }
-        for (int e = t; e < 128 * ERF; e += WG) {
-          int row = e / ERF, f = e - row * ERF;
-          const float* rl = sRel + (sb * K + row) * 3;
-          float sn, cs;
-          sincosf(fourier_phase(rl[0], rl[1], rl[2], Brel, ERF, f), &sn, &cs);
-          sXn[row * LD_XN + f] = sn;
-          sXn[row * LD_XN + ERF + f] = cs;
-        }
-        lds_barrier();
-        if (a.ws.n_x) {
-          for (int e = t; e < 128 * NX; e += WG) {
-            int row = e / NX, c = e - row * NX;
-            if (live(sb + (row >> 3))) a.ws.n_x[((size_t)(p0 + sb) * K + row) * NX + c] = sXn[row * LD_XN + c];
-          }
-        }
-        float* Hw = sHn + wave * 16 * LD_HN;
-        const float* Xw = sXn + wave * 16 * LD_XN;
-        const int g = lane >> 4, colw = lane & 15;
-        {
-          f32x4 acc[8];
-          gemm16_multi<NX, 8>(Xw, LD_XN, WTs + wtoff(WT_C_N1), HC, acc);
-#pragma unroll
-          for (int nt = 0; nt < 8; ++nt) {
-            float b = Ms[MO(PI_C_N1 + 1) + 16 * nt + colw];
-            f32x4 hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = softplus100(acc[nt][r] + b);
-            frag_store(Hw, LD_HN, 16 * nt, hv);
-            if (a.ws.n_h1) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                int row = 16 * wave + 4 * g + r;
-                if (live(sb + (row >> 3))) a.ws.n_h1[((size_t)(p0 + sb) * K + row) * HC + 16 * nt + colw] = hv[r];
-              }
-            }
-          }
-        }
-        lds_barrier();
-        {
-          f32x4 acc[2];
-          gemm16_multi<HC, 2>(Hw, LD_HN, WTs + wtoff(WT_C_N2), C, acc);
-          const int s = sb + 2 * wave + (g >> 1);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            float b = Ms[MO(PI_C_N2 + 1) + 16 * nt + colw];
-            float part = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float nf = acc[nt][r] + b;
-              int row = 16 * wave + 4 * g + r;
-              if (a.ws.n_out && live(sb + (row >> 3))) a.ws.n_out[((size_t)(p0 + sb) * K + row) * C + 16 * nt + colw] = nf;
-              part = __fadd_rn(part, __fmul_rn(sW[s * K + 4 * (g & 1) + r], nf));
-            }
-            float tot = part + __shfl_xor(part, 16);
-            if ((g & 1) == 0) {
-              float c = sHas[s] ? tot : a.fb_col[16 * nt + colw];
-              sCc[s * LD_CF + 16 * nt + colw] = c;
-              if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + 16 * nt + colw] = c;
-            }
-          }
-        }
-        lds_barrier();        // sXn / sHn are reused by the next sub-tile
-      }
-      if (MT * 16 > spt) {    // slots of sub-tiles that were skipped: defined (zero) colour features
-        for (int e = t; e < TM * C; e += WG) { int s = e >> 5; if (s >= ((spt + 15) & ~15)) sCc[s * LD_CF + (e & 31)] = 0.f; }
-      }
-    }
     lds_barrier();
     PSL_STAMP(5);
     // -------------------------------------------------------------- phase 5: colour trunk, 8 waves x 16 columns
@@ -407,13 +423,13 @@ int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s) {
   return PSL_OK;
 }
 
-// Tile geometry: the smallest samples-per-tile (<= 32) that fits the whole batch in one round of workgroups
-// on the 256 CUs (1 workgroup per CU: the LDS footprint exceeds half of the 160 KiB).
+// Tile geometry: the smallest samples-per-tile (<= 32) that keeps the whole batch resident in ONE round of
+// workgroups: 256 CUs x 2 workgroups per CU (both instantiations need < 80 KB of LDS and <= 128 VGPRs).
 void choose_tile(int P, int& mt, int& spt) {
-  const int kCUs = 256;
-  if ((P + 15) / 16 <= kCUs) { mt = 1; spt = 16; return; }
+  const int kSlots = 512;
+  if ((P + 15) / 16 <= kSlots) { mt = 1; spt = 16; return; }
   mt = 2;
-  spt = std::min(32, std::max(17, (P + kCUs - 1) / kCUs));
+  spt = std::min(32, std::max(17, (P + kSlots - 1) / kSlots));
 }
 
 template <int MT>
