@@ -22,7 +22,11 @@ struct DwJob {
 constexpr int MAX_JOBS = 16;
 constexpr int MAX_CHUNKS = 256;
 struct DwArgs { DwJob job[MAX_JOBS]; int n_jobs; int n_items; float* slabs; };
-struct DwReduceArgs { int chunks_of_entry[kNumColorParams]; };
+struct DwReduceArgs { int chunks_of_entry[kNumColorParams]; int slab_off[kNumColorParams]; };
+// slab layout = master layout with every tensor start rounded up to 4 floats, so that a lane's 4 consecutive k
+// (one float4) is 16-byte aligned in every layer (all row lengths are multiples of 4)
+constexpr int SLAB_STRIDE = kColorFloats + 4 * kNumColorParams;
+static int slab_off_of(int pi) { int o = 0; for (int j = 0; j < pi; ++j) o += (kParams[j].rows * kParams[j].cols + 3) / 4 * 4; return o; }
 
 // One wavefront = one 64x64 output tile of one layer for one chunk of rows.  Each lane fetches ONE float4 of dZ
 // (4 consecutive n-columns) and ONE float4 of X (4 consecutive k-columns) per 4-row step and feeds 16 MFMAs with
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256) void k_dw(DwArgs d) {
   const int lane = threadIdx.x & 63, g = lane >> 4, colw = lane & 15;
   const long long r0 = (long long)chunk * J.rows_per_chunk;
   const long long r1 = min(J.rows, r0 + J.rows_per_chunk);
-  float* slab = d.slabs + (size_t)chunk * kColorFloats;
+  float* slab = d.slabs + (size_t)chunk * SLAB_STRIDE;
   const int nt = item / J.k_tiles, kt = item - nt * J.k_tiles;
   const int ktot = J.k0_cols + J.k1_cols;
   const int nq = 64 * nt + 4 * colw, kq = 64 * kt + 4 * colw;     // first column of this lane's quads
@@ -107,11 +111,9 @@ __global__ __launch_bounds__(256) void k_dw(DwArgs d) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       int n = 64 * nt + 4 * (4 * g + q) + x;
-      if (n < J.n_valid) {
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-          if (kq + y < ktot) slab[J.out_off + n * J.ld_out + kq + y] = acc[x][y][q];
-      }
+      if (n < J.n_valid && kin)     // ktot is a multiple of 4: the quad is entirely inside or outside
+        *reinterpret_cast<float4*>(slab + J.out_off + n * J.ld_out + kq) =
+            make_float4(acc[x][0][q], acc[x][1][q], acc[x][2][q], acc[x][3][q]);
     }
   if (kt == 0) {   // bias gradient = column sums of dZ: this lane saw rows g, g+4, ... of columns nq..nq+3
 #pragma unroll
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ sla
 #pragma unroll
       for (int j = 1; j < kNumColorParams; ++j) if (e >= poff(j)) ent = j;
       const int n_chunks = ra.chunks_of_entry[ent];
-      for (int c = cl; c < n_chunks; c += 8) v += slabs[(size_t)c * kColorFloats + e];
+      const int se = ra.slab_off[ent] + (e - poff(ent));
+      for (int c = cl; c < n_chunks; c += 8) v += slabs[(size_t)c * SLAB_STRIDE + se];
     }
   }
   (void)brel;
@@ -160,7 +163,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   const long long P = a.P;
   if (ctx->dw_slab_cap < MAX_CHUNKS) {
     if (ctx->dw_slabs) PSL_HIP(hipFree(ctx->dw_slabs));
-    PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)kColorFloats * MAX_CHUNKS));
+    PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS));
     ctx->dw_slab_cap = MAX_CHUNKS;
   }
   static int chunk_rows = 0;
@@ -169,6 +172,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   DwReduceArgs ra;
   memset(&d, 0, sizeof(d));
   memset(&ra, 0, sizeof(ra));
+  for (int j = 0; j < kNumColorParams; ++j) ra.slab_off[j] = slab_off_of(j);
   int nj = 0, base = 0;
   // every (chunk, tile) item writes its whole tile, so a slab entry is defined for exactly the chunks of its job:
   // no memset; the reduction reads chunks_of_entry[] slabs per parameter tensor
@@ -176,7 +180,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
                  long long rows, int out_pi) {
     DwJob& J = d.job[nj++];
     J.A = A; J.lda = lda; J.n_valid = nv; J.B0 = B0; J.ldb0 = ldb0; J.k0_cols = k0; J.B1 = B1; J.ldb1 = ldb1;
-    J.k1_cols = k1; J.rows = rows; J.out_off = poff(out_pi); J.ld_out = k0 + k1; J.bias_off = poff(out_pi + 1);
+    J.k1_cols = k1; J.rows = rows; J.out_off = slab_off_of(out_pi); J.ld_out = k0 + k1; J.bias_off = slab_off_of(out_pi + 1);
     J.n_tiles = (nv + 63) / 64; J.k_tiles = (k0 + k1 + 63) / 64;
     J.n_chunks = (int)std::min<long long>(std::max<long long>((rows + chunk_rows - 1) / chunk_rows, 1), MAX_CHUNKS);
     long long rpc = (rows + J.n_chunks - 1) / J.n_chunks;
