@@ -100,6 +100,14 @@ int psl_index_build(psl_ctx* ctx, void* stream);
 int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq,
             float* D_out, int64_t* I_out, int32_t* cnt_out, void* stream);
 
+/* NeuralPointCloud.sample_near_pcl marching test (src/neural_point.py:232-249): hits[ray][step] = 1 when the point
+ * rays_o + rays_d * z_steps[row][step] has >= 1 neural point strictly inside `radius` (cfg radius_query).
+ * z_steps is [n_rows][n_steps]; row = step_row[ray], or 0 when step_row is NULL (render_img marches each of its
+ * 3000-ray batches to that batch's own far bound, Renderer.py:108-112,254).  The caller turns the first two hits
+ * of a ray into its sample interval (:251-277); rays with < 2 hits are masked. */
+int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float* rays_d, int32_t n_rays, const float* z_steps,
+                      const int32_t* step_row, int32_t n_steps, float radius, uint8_t* hits, void* stream);
+
 /* add_neural_points (src/neural_point.py:91-167): for rays with depth>0 compute the surface
  * point o+d*depth, keep locations with ZERO existing points closer than the radius
  * (dedupe against the index as built, not against this batch), append n_add=3 points per
@@ -146,6 +154,9 @@ typedef struct psl_render_args {
   float* var;                    /* [R] */
   float* rgb;                    /* [R][3] */
   uint8_t* valid_ray;            /* [R] valid_ray_mask (decoder.py:200-201) */
+  /* optional input (ABI v2): explicit sample depths [R][5] replacing the 0.98..1.02*gt_depth rule, for batches
+   * with depth-less pixels (Renderer.py:142-170: sample_near_pcl / uniform branch). NULL = derive from gt_depth. */
+  const float* z_vals;
 } psl_render_args;
 
 int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream);

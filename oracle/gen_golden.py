@@ -98,12 +98,17 @@ def make_ref_npc(ns, cfg, cloud, geo, col):
 
 
 def run_render_case(name, cfg_name, stage, is_tracker, n_pts, n_rays, seed, sparse_frac=0.0, exposure=False,
-                    store_param_grads=False):
+                    store_param_grads=False, zero_depth_frac=0.0, sample_near_pcl=None):
     ns = RI.load()
     cfg = cfg_variant(cfg_name)
+    if sample_near_pcl is not None:
+        cfg["rendering"]["sample_near_pcl"] = bool(sample_near_pcl)
     dec = RI.make_decoders(cfg)
     P = RI.state_with_fixed_B(dec)
     sc = build_scene(cfg, n_pts, n_rays, seed, sparse_frac=sparse_frac)
+    if zero_depth_frac > 0:   # sensor holes: these rays take the sample_near_pcl / uniform branch
+        hole = torch.rand(n_rays, generator=torch.Generator().manual_seed(seed + 5)) < zero_depth_frac
+        sc["gt_depth"] = torch.where(hole, torch.zeros_like(sc["gt_depth"]), sc["gt_depth"])
     cam = sc["cam"]
     npc = make_ref_npc(ns, cfg, sc["cloud"], sc["geo"], sc["col"])
     slam = types.SimpleNamespace(**cam)
@@ -184,6 +189,7 @@ def run_render_case(name, cfg_name, stage, is_tracker, n_pts, n_rays, seed, spar
             assert v < (1e-3 if k.startswith("g_") else tol), (name, k, v)
 
     out = dict(cfg_name=cfg_name, stage=stage, is_tracker=is_tracker, coef=rend.sigmoid_coefficient,
+               sample_near_pcl=bool(cfg["rendering"]["sample_near_pcl"]),
                cloud=sc["cloud"], geo=sc["geo"], col=sc["col"], rays_o=rays_o.detach(), rays_d=rays_d.detach(),
                gt_depth=sc["gt_depth"], gt_color=sc["gt_color"], r_query=sc["r_query"], fb_geo=fb_geo,
                fb_col=fb_col, w_d=w_d, w_c=w_c, w_v=w_v, c2w=c2w, ui=sc["ui"], vi=sc["vi"],
@@ -312,6 +318,12 @@ def run_tracker_case(name, n_pts, n_rays, seed):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--zero-depth" in sys.argv:   # only the sensor-hole cases (the others are unchanged)
+        run_render_case("render_holes_nearpcl_mapper", "replica", "color", False, 3000, 96, 107, sparse_frac=0.35,
+                        zero_depth_frac=0.4, sample_near_pcl=True)
+        run_render_case("render_holes_uniform_tracker", "replica", "color", True, 2000, 64, 108,
+                        zero_depth_frac=0.4, sample_near_pcl=False)
+        return
     cfg, P = run_render_case("render_replica_color_tracker", "replica", "color", True, 2000, 96, 101,
                              store_param_grads=True)
     save("decoders_seed1219_replica", {k: v for k, v in P.items()})
@@ -322,6 +334,10 @@ def main():
                              exposure=True, store_param_grads=True)
     save("decoders_seed1219_scannet", {k: v for k, v in P.items()})
     run_tracker_case("tracker_iter_replica", 2000, 200, 106)
+    run_render_case("render_holes_nearpcl_mapper", "replica", "color", False, 3000, 96, 107, sparse_frac=0.35,
+                    zero_depth_frac=0.4, sample_near_pcl=True)
+    run_render_case("render_holes_uniform_tracker", "replica", "color", True, 2000, 64, 108,
+                    zero_depth_frac=0.4, sample_near_pcl=False)
 
 
 if __name__ == "__main__":

@@ -274,18 +274,70 @@ def composite(raw: Tensor, z: Tensor, coef: float):
 # --------------------------------------------------------------------------
 # full render (the Seam-1 contract)
 # --------------------------------------------------------------------------
+def sample_near_pcl(cloud: Tensor, rays_o: Tensor, rays_d: Tensor, near: float, far: float, num: int,
+                    radius_query: float, k: int = 8):
+    """NeuralPointCloud.sample_near_pcl, src/neural_point.py:217-277: march 25 steps from near to far, a step
+    'hits' when it has >= 1 neighbour closer than radius_query; rays with < 2 hits are invalid (uniform samples);
+    the others get `num` samples between their FIRST TWO hit steps (float64 linspace, cast to f32)."""
+    n = rays_o.shape[0]
+    steps = 25
+    z = torch.linspace(near, far, steps=steps)
+    pts = (rays_o[:, None, :] + rays_d[:, None, :] * z[None, :, None]).reshape(-1, 3)
+    D, _ = knn_exact(cloud, pts, k)
+    hit = (neighbor_count(D, radius_query) > 0).reshape(n, steps)
+    invalid = hit.sum(1) < 2
+    def np_linspace(a, b, m):                  # numpy.linspace in float64: arange * step + start, endpoint forced
+        a = torch.as_tensor(a, dtype=torch.float64).reshape(-1, 1)
+        b = torch.as_tensor(b, dtype=torch.float64).reshape(-1, 1)
+        y = torch.arange(m, dtype=torch.float64)[None, :] * ((b - a) / (m - 1)) + a
+        y[:, -1] = b[:, 0]
+        return y
+    far = float(torch.tensor(far, dtype=torch.float32))                 # the reference passes a float32 tensor
+    zs = np_linspace(near, far, steps)[0]                               # z_section (:247)
+    out = np_linspace(near, far, num).repeat(n, 1)
+    order = torch.argsort((~hit).int(), dim=1, stable=True)             # hit steps first, in step order
+    seg = np_linspace(zs[order[:, 0]], zs[order[:, 1]], num)            # (:262-265)
+    out = torch.where(invalid[:, None], out, seg)
+    return out.float(), invalid
+
+
+def render_z_vals(cfg: dict, cloud: Tensor, rays_o: Tensor, rays_d: Tensor, gt_depth: Tensor):
+    """Per-ray sample depths incl. pixels without sensor depth, src/utils/Renderer.py:104-170.
+    Returns z [R,S], near_pcl mask [R] (False only for depth-less rays far from the cloud)."""
+    S = cfg["rendering"]["N_surface"]
+    far = torch.minimum(5 * gt_depth.mean(), torch.max(gt_depth * 1.2))
+    nz = gt_depth > 0
+    z = torch.zeros(gt_depth.shape[0], S)
+    z[nz] = z_samples(gt_depth[nz], cfg["rendering"]["near_end_surface"], cfg["rendering"]["far_end_surface"], S)
+    near_mask = torch.ones(gt_depth.shape[0], dtype=torch.bool)
+    if int(nz.sum()) < gt_depth.shape[0]:
+        if cfg["rendering"]["sample_near_pcl"]:
+            zz, inv = sample_near_pcl(cloud, rays_o[~nz].detach(), rays_d[~nz].detach(), cfg["rendering"]["near_end"],
+                                      float(far), S, cfg["pointcloud"]["radius_query"], cfg["pointcloud"]["nn_num"])
+            z[~nz] = zz
+            idx = torch.nonzero(~nz).flatten()
+            near_mask[idx[inv]] = False
+        else:
+            z[~nz] = torch.linspace(cfg["rendering"]["near_end"], float(far), steps=S).repeat(int((~nz).sum()), 1)
+    return z, near_mask
+
+
 def render_batch_ray(cfg: dict, P: Dict[str, Tensor], cloud: Tensor, geo_feats: Tensor, col_feats: Tensor,
                      rays_o: Tensor, rays_d: Tensor, gt_depth: Tensor, stage: str,
                      r_query: Optional[Tensor], fallback_geo: Tensor, fallback_col: Tensor,
                      pts_grad: bool = False, exposure_affine: Optional[Tensor] = None,
                      coef: float = 0.1, knn: Optional[Tuple[Tensor, Tensor]] = None):
-    """Renderer.render_batch_ray for rays with gt_depth>0, src/utils/Renderer.py:77-202,
-    through POINT.forward (decoder.py:476-518).
+    """Renderer.render_batch_ray, src/utils/Renderer.py:77-202, through POINT.forward (decoder.py:476-518);
+    rays without sensor depth (gt_depth == 0) take the sample_near_pcl / uniform branch (:142-168).
 
     Returns depth[R], var[R], rgb[R,3], valid_ray[R], aux dict.
     """
     S = cfg["rendering"]["N_surface"]
-    z = z_samples(gt_depth, cfg["rendering"]["near_end_surface"], cfg["rendering"]["far_end_surface"], S)
+    if bool((gt_depth > 0).all()):
+        z = z_samples(gt_depth, cfg["rendering"]["near_end_surface"], cfg["rendering"]["far_end_surface"], S)
+        near_mask = None
+    else:
+        z, near_mask = render_z_vals(cfg, cloud, rays_o, rays_d, gt_depth)
     pts = sample_points(rays_o, rays_d, z)
     if cfg["use_dynamic_radius"]:
         rq = r_query.reshape(-1, 1).repeat_interleave(S, 0)          # Renderer.py:179-181
@@ -317,6 +369,10 @@ def render_batch_ray(cfg: dict, P: Dict[str, Tensor], cloud: Tensor, geo_feats: 
     occ = occ + (torch.where(has_nb, occ, torch.full_like(occ, -100.0)) - occ).detach()
     raw = torch.cat([rgb_pts, occ[:, None]], -1).reshape(-1, S, 4)
     depth, var, rgb, w = composite(raw, z, coef)
+    if near_mask is not None:
+        valid_ray = valid_ray & near_mask                                # Renderer.py:198
+        if not cfg["rendering"]["sample_near_pcl"]:
+            depth = torch.where(gt_depth > 0, depth, torch.zeros_like(depth))   # Renderer.py:200-201
     return depth, var, rgb, valid_ray, {"D": D, "I": I, "cnt": cnt, "z": z, "pts": pts, "raw": raw, "w": w,
                                         "has_nb": has_nb}
 

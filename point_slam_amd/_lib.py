@@ -28,7 +28,8 @@ class psl_render_args(C.Structure):
                 ("geo_feats", C.c_void_p), ("col_feats", C.c_void_p), ("params", C.c_void_p),
                 ("col_embed_B", C.c_void_p), ("fallback_geo", C.c_void_p), ("fallback_col", C.c_void_p),
                 ("exposure_affine", C.c_void_p), ("ws", C.c_void_p),
-                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("valid_ray", C.c_void_p)]
+                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("valid_ray", C.c_void_p),
+                ("z_vals", C.c_void_p)]
 
 
 class psl_render_grads(C.Structure):
@@ -90,6 +91,8 @@ _SIGS = {
     "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p]),
+    "psl_near_pcl_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_float, C.c_void_p, C.c_void_p]),   # ctx o d n z_steps step_row n_steps r hits stream
     "psl_add_points_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "psl_render_ws_floats": (C.c_int64, [C.c_int, C.c_int]),

@@ -28,9 +28,9 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
 int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
                          unsigned char* valid, float* cw, float* ray_aux, hipStream_t s);
-int launch_composite_bwd(const float4* raw, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
+int launch_composite_bwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
                          const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s);
-int launch_ray_grad(const float4* dp, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
+int launch_ray_grad(const float4* dp, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
                     float* g_d, hipStream_t s);
 
 static inline int64_t al4(int64_t x) { return (x + 3) & ~int64_t(3); }
@@ -91,7 +91,7 @@ static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& 
   d.near_s = ctx->cfg.near_end_surface;
   d.far_s = ctx->cfg.far_end_surface;
   d.r2_fixed = (float)((double)ctx->cfg.radius_query * (double)ctx->cfg.radius_query);
-  d.rays_o = a->rays_o; d.rays_d = a->rays_d; d.depth = a->gt_depth; d.r_query = a->r_query;
+  d.rays_o = a->rays_o; d.rays_d = a->rays_d; d.depth = a->gt_depth; d.zv = a->z_vals; d.r_query = a->r_query;
   d.pos = ctx->pos;
   d.geo_feats = a->geo_feats; d.col_feats = a->col_feats;
   d.master = a->params; d.wt = ctx->wt; d.Bcol = a->col_embed_B;
@@ -119,7 +119,7 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
 using namespace psl;
 
 extern "C" const char* psl_last_error(void) { return g_err; }
-extern "C" int psl_abi_version(void) { return 1; }
+extern "C" int psl_abi_version(void) { return 2; }
 
 extern "C" int psl_param_count(void) { return kNumParams; }
 extern "C" int psl_param_color_count(void) { return kNumColorParams; }
@@ -192,11 +192,11 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   fill_decode_args(ctx, a, d);
   if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
   { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
-    rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
+    rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
   { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P); rc = launch_decode_fwd(d, s); if (rc) return rc; }
   { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
-    rc = launch_composite_fwd((const float4*)d.ws.raw, nullptr, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
+    rc = launch_composite_fwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
                               a->n_rays, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, d.ws.cw,
                               d.ws.ray_aux, s);
     if (rc) return rc; }
@@ -214,14 +214,14 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
   { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays);
-    rc = launch_composite_bwd((const float4*)d.ws.raw, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
+    rc = launch_composite_bwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
                               g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, s);
     if (rc) return rc; }
   rc = launch_decode_bwd(ctx, d, *g, s);
   if (rc) return rc;
   if ((a->flags & PSL_PTS_GRAD) && (g->g_rays_o || g->g_rays_d)) {
     ProfScope ps(ctx, PROF_MISC, s);
-    rc = launch_ray_grad((const float4*)d.ws.dp, a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
+    rc = launch_ray_grad((const float4*)d.ws.dp, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
     if (rc) return rc;
   }
   return PSL_OK;

@@ -198,7 +198,7 @@ struct ProfScope {  // brackets a kernel class with HIP events on the launch str
 
 // ---- internal launchers (defined in the .hip files) -------------------------
 int grid_build(psl_ctx* ctx, hipStream_t s);
-int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* r_query,
+int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);

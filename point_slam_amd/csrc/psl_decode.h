@@ -9,6 +9,7 @@ struct DecodeArgs {
   int P, n_rays, flags, min_nn;
   float near_s, far_s, r2_fixed;
   const float *rays_o, *rays_d, *depth, *r_query;
+  const float* zv;       // explicit sample depths [P] (rays without sensor depth) or null
   const float4* pos;
   const float *geo_feats, *col_feats;
   const float* master;   // torch-layout parameter blob
@@ -53,8 +54,7 @@ __device__ __forceinline__ SampleGeom sample_geom(const DecodeArgs& a, int p) {
   SampleGeom g;
   int ray = p / S, si = p - ray * S;
   g.ray = ray;
-  float dep = a.depth[ray];
-  g.zval = sample_z(dep, si, a.near_s, a.far_s);
+  g.zval = a.zv ? a.zv[p] : sample_z(a.depth[ray], si, a.near_s, a.far_s);
   sample_point(a.rays_o[ray * 3], a.rays_o[ray * 3 + 1], a.rays_o[ray * 3 + 2], a.rays_d[ray * 3],
                a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2], g.zval, g.x, g.y, g.z);
   if (a.r_query) { float r = a.r_query[ray]; g.r2 = __fmul_rn(r, r); }

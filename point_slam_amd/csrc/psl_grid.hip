@@ -301,7 +301,8 @@ __device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lan
 __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                   const int* __restrict__ cell_start,
                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                  const float* __restrict__ depth, const float* __restrict__ r_query,
+                                                  const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                                  const float* __restrict__ r_query,
                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                   int* __restrict__ I_out, int* __restrict__ cnt_out) {
   const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -309,18 +310,62 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
   const GridMeta m = *meta;
-  const float dep = depth[ray];
+  const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
   float r, r2;
   if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
   float qx, qy, qz;
   sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
-               rays_d[ray * 3 + 2], sample_z(dep, si, near_s, far_s), qx, qy, qz);
+               rays_d[ray * 3 + 2], zq, qx, qy, qz);
   u64 best[K];
   wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best);
   unsigned ib, db; int cnt;
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) cnt_out[p] = cnt;
+}
+
+// sample_near_pcl marching test (src/neural_point.py:232-249): one wave per (ray, step); a step "hits" when at least
+// one neural point lies strictly inside the query radius (nearest of the 8-NN has D < r^2).  First hit ends the scan.
+__global__ __launch_bounds__(256) void k_near_pcl_hits(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                       const int* __restrict__ cell_start,
+                                                       const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ z_steps, const int* __restrict__ step_row,
+                                                       int n_rays, int n_steps, float r, float r2,
+                                                       unsigned char* __restrict__ hits) {
+  const int q = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (q >= n_rays * n_steps) return;
+  const int ray = q / n_steps, st = q - ray * n_steps;
+  const int lane = threadIdx.x & 63;
+  const GridMeta m = *meta;
+  float qx, qy, qz;
+  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+               rays_d[ray * 3 + 2], z_steps[(step_row ? step_row[ray] : 0) * n_steps + st], qx, qy, qz);
+  CellBox bx;
+  box_of(m, qx, qy, qz, r, bx);
+  const int ny_b = bx.hi[1] - bx.lo[1] + 1;
+  const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
+  bool hit = false;
+  for (int rb = 0; rb < nrows && !hit; rb += 64) {
+    int beg = 0, end = 0;
+    const int row = rb + lane;
+    if (row < nrows) {
+      const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+      const int rowbase = (cz * m.ny + cy) * m.nx;
+      beg = cell_start[rowbase + bx.lo[0]];
+      end = cell_start[rowbase + bx.hi[0] + 1];
+    }
+    const int nr = min(64, nrows - rb);
+    for (int ri = 0; ri < nr && !hit; ++ri) {
+      const int b0 = __builtin_amdgcn_readlane(beg, ri), e0 = __builtin_amdgcn_readlane(end, ri);
+      for (int j0 = b0; j0 < e0 && !hit; j0 += 64) {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < e0) { float4 c = spos[j]; in = dist2(c.x, c.y, c.z, qx, qy, qz) < r2; }
+        hit = __ballot(in) != 0ull;
+      }
+    }
+  }
+  if (lane == 0) hits[q] = hit ? 1 : 0;
 }
 
 // free-query mode: wave per query; outputs follow find_neighbors_faiss (D f32, I int64, cnt int32)
@@ -350,12 +395,12 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
 
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
-int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* r_query,
-             int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
+int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
+             const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
   int blocks = (n_rays * S + 3) / 4;
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                     rays_d, depth, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                     rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                      ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
@@ -487,6 +532,22 @@ extern "C" int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, f
   if (!ctx || !q || nq < 0) { set_error("psl_knn: bad argument"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_knn: index is stale, call psl_index_build"); return PSL_ERR_STATE; }
   return knn_queries(ctx, q, r_per_query, r_scalar, nq, D_out, I_out, cnt_out, (hipStream_t)stream);
+}
+
+extern "C" int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float* rays_d, int n_rays,
+                                 const float* z_steps, const int32_t* step_row, int n_steps, float radius,
+                                 uint8_t* hits, void* stream) {
+  if (!ctx || !rays_o || !rays_d || !z_steps || !hits || n_rays < 0 || n_steps <= 0) {
+    set_error("psl_near_pcl_hits: bad argument"); return PSL_ERR_ARG;
+  }
+  if (ctx->index_points != ctx->n_points) { set_error("psl_near_pcl_hits: index is stale, call psl_index_build"); return PSL_ERR_STATE; }
+  if (n_rays == 0) return PSL_OK;
+  if (ctx->n_points == 0) { PSL_HIP(hipMemsetAsync(hits, 0, (size_t)n_rays * n_steps, (hipStream_t)stream)); return PSL_OK; }
+  long long nq = (long long)n_rays * n_steps;
+  hipLaunchKernelGGL(k_near_pcl_hits, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ctx->meta,
+                     ctx->spos, ctx->cell_start, rays_o, rays_d, z_steps, step_row, n_rays, n_steps, radius, r2_of(radius), hits);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
 }
 
 extern "C" int psl_add_points_sync(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth,

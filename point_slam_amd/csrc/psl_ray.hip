@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float4* __restrict_
 // d(raw) from d(depth), d(var), d(rgb).  The -100 written into masked samples (Renderer.py:189-190) replaces the
 // VALUE only; autograd still routes d/d(occ) to the decoder output (in-place write under no_grad), so d_raw.w is
 // produced for masked samples as well.
-__global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ gt_depth,
-                                                       float near_s, float far_s, int n_rays, float coef,
+__global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ z_in,
+                                                       const float* __restrict__ gt_depth, float near_s, float far_s, int n_rays, float coef,
                                                        const float* __restrict__ g_depth, const float* __restrict__ g_var,
                                                        const float* __restrict__ g_rgb, float4* __restrict__ d_raw) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     float4 q = raw[r * S + s];
-    z[s] = sample_z(gt_depth[r], s, near_s, far_s);
+    z[s] = z_in ? z_in[r * S + s] : sample_z(gt_depth[r], s, near_s, far_s);
     al[s] = sigmoidf(coef * q.w);
     Tt[s] = T;
     w[s] = al[s] * T;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
 }
 
 // g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (pts = o + d*z, Renderer.py:172-173)
-__global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp, const float* __restrict__ gt_depth,
-                                                  float near_s, float far_s, int n_rays, float* __restrict__ g_o,
+__global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp, const float* __restrict__ z_in,
+                                                  const float* __restrict__ gt_depth, float near_s, float far_s, int n_rays, float* __restrict__ g_o,
                                                   float* __restrict__ g_d) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp,
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     float4 g = dp[r * S + s];
-    float z = sample_z(gt_depth[r], s, near_s, far_s);
+    float z = z_in ? z_in[r * S + s] : sample_z(gt_depth[r], s, near_s, far_s);
     o0 += g.x; o1 += g.y; o2 += g.z;
     d0 += z * g.x; d1 += z * g.y; d2 += z * g.z;
   }
@@ -129,19 +129,19 @@ int launch_composite_fwd(const float4* raw, const float* z, const float* gt_dept
   return PSL_OK;
 }
 
-int launch_composite_bwd(const float4* raw, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
+int launch_composite_bwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
                          const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, gt_depth, near_s, far_s,
+  hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
                      n_rays, coef, g_depth, g_var, g_rgb, d_raw);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
 
-int launch_ray_grad(const float4* dp, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
+int launch_ray_grad(const float4* dp, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
                     float* g_d, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_ray_grad, dim3((n_rays + 255) / 256), dim3(256), 0, s, dp, gt_depth, near_s, far_s, n_rays,
+  hipLaunchKernelGGL(k_ray_grad, dim3((n_rays + 255) / 256), dim3(256), 0, s, dp, z, gt_depth, near_s, far_s, n_rays,
                      g_o, g_d);
   PSL_LAUNCH_CHECK();
   return PSL_OK;

@@ -479,7 +479,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     float init[8] = {0, 0, 0, 0, 0, 0, 0, 1e20f};
     PSL_HIP(hipMemcpyAsync(t->best_out, init, sizeof(init), hipMemcpyHostToDevice, s));
   }
-  psl_render_args ra;
+  psl_render_args ra{};
   memset(&ra, 0, sizeof(ra));
   ra.n_rays = n; ra.flags = PSL_STAGE_COLOR | PSL_PTS_GRAD; ra.sigmoid_coef = t->sigmoid_coef;
   ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
@@ -543,7 +543,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     PSL_HIP(hipMemcpyAsync(fdev, fh.data(), sizeof(FrameDev) * m->n_frames, hipMemcpyHostToDevice, s));
     PSL_HIP(hipStreamSynchronize(s));   // fh goes out of scope; once per mapped frame
   }
-  psl_render_args ra;
+  psl_render_args ra{};
   memset(&ra, 0, sizeof(ra));
   ra.n_rays = n; ra.sigmoid_coef = m->sigmoid_coef;
   ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;

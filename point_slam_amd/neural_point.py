@@ -207,5 +207,43 @@ class HipNeuralPointCloud(object):
         return D, I, cnt
 
     def sample_near_pcl(self, rays_o, rays_d, near, far, num):
-        """Zero-depth pixels (neural_point.py:217-277): SURVEY §8f 'next' item, not built in this round."""
-        raise NotImplementedError("sample_near_pcl (zero-depth ray marching) is a §8f 'next' row")
+        """NeuralPointCloud.sample_near_pcl (src/neural_point.py:217-277) for pixels without sensor depth: march
+        25 steps from `near` to `far`, a step hits when a neural point lies inside radius_query
+        (psl_near_pcl_hits); a ray with >= 2 hits is sampled `num` times between its first two hit steps, the
+        others uniformly in [near, far] and flagged invalid.  `far` is a scalar / 0-dim tensor as in the
+        reference, or a per-ray [n] tensor (render_img: one far bound per 3000-ray batch).
+
+        Returns z_vals [n, num] float32 and invalid_mask [n] bool, both on the rays' device."""
+        dev = rays_o.device
+        n = rays_o.shape[0]
+        steps = 25
+        ro = rays_o.detach().float().contiguous()
+        rd = rays_d.detach().float().contiguous()
+        far_t = torch.as_tensor(far, dtype=torch.float32, device=dev)
+        if far_t.dim() == 0:
+            far_u, row = far_t.reshape(1), None
+        else:
+            far_u, row = torch.unique(far_t.reshape(-1), return_inverse=True)
+            row = row.to(torch.int32).contiguous()
+        z_steps = torch.stack([torch.linspace(near, f, steps=steps, device=dev) for f in far_u]).contiguous()
+        hits = torch.empty(n, steps, device=dev, dtype=torch.uint8)
+        _lib.check(_lib.lib().psl_near_pcl_hits(self._h, _lib.ptr(ro), _lib.ptr(rd), n, _lib.ptr(z_steps),
+                                                _lib.ptr(row), steps, float(self.radius_query), _lib.ptr(hits),
+                                                _lib.stream_ptr()), "psl_near_pcl_hits")
+        hit = hits.bool()
+        invalid = hit.sum(1) < 2
+        # np.linspace(near, far, 25) in float64 (:247): arange * step + start, endpoint forced
+        far64 = (far_u.double()[row.long()] if row is not None else far_u.double().expand(n))[:, None]
+        ar = torch.arange(steps, device=dev, dtype=torch.float64)[None, :]
+        z_sec = ar * ((far64 - near) / (steps - 1)) + near
+        z_sec[:, -1] = far64[:, 0]
+        order = torch.argsort((~hit).to(torch.int8), dim=1, stable=True)      # hit steps first, in step order
+        a = torch.gather(z_sec, 1, order[:, 0:1])
+        b = torch.gather(z_sec, 1, order[:, 1:2])
+        an = torch.arange(num, device=dev, dtype=torch.float64)[None, :]
+        seg = an * ((b - a) / (num - 1)) + a
+        seg[:, -1] = b[:, 0]
+        uni = an * ((far64 - near) / (num - 1)) + near
+        uni[:, -1] = far64[:, 0]
+        z = torch.where(invalid[:, None], uni, seg)
+        return z.float(), invalid

@@ -45,7 +45,7 @@ class _RenderFn(torch.autograd.Function):
             fallback_geo=m["fb_geo"].data_ptr(), fallback_col=m["fb_col"].data_ptr(),
             exposure_affine=affine_c.data_ptr() if affine_c is not None else None,
             ws=ws.data_ptr(), depth=depth.data_ptr(), var=var.data_ptr(), rgb=rgb.data_ptr(),
-            valid_ray=valid.data_ptr())
+            valid_ray=valid.data_ptr(), z_vals=m["z_vals"].data_ptr() if m.get("z_vals") is not None else None)
         _lib.check(L.psl_render_fwd(m["handle"], C.byref(a), _lib.stream_ptr()), "psl_render_fwd")
         ctx.m = m
         ctx.args = a
@@ -125,15 +125,53 @@ class HipRenderer(object):
         fb_col = torch.zeros([32], device=device).normal_(mean=0, std=0.01)
         return fb_geo, fb_col
 
+    def _linspace_rows(self, near, far, steps, device):
+        """rows of torch.linspace(near, far_i, steps) for a per-ray far bound (one linspace per distinct value)."""
+        far_u, row = torch.unique(far.reshape(-1), return_inverse=True)
+        tab = torch.stack([torch.linspace(near, f, steps=steps, device=device) for f in far_u])
+        return tab[row]
+
+    def sample_depths(self, npc, rays_o, rays_d, gt_depth, far):
+        """Per-ray sample depths for a batch that holds pixels without sensor depth (Renderer.py:126-170).
+        `far`: 0-dim tensor (one batch) or [R] (render_img: per 3000-ray batch).  Returns z_vals [R,S] and the
+        mask of rays close to the cloud (False only for depth-less rays that sample_near_pcl rejects)."""
+        S = self.N_surface
+        dev = gt_depth.device
+        R = gt_depth.shape[0]
+        t = torch.linspace(0.0, 1.0, steps=S, device=dev)
+        gd = gt_depth.reshape(-1, 1).repeat(1, S)
+        z = self.near_end_surface * gd * (1. - t) + self.far_end_surface * gd * t
+        near_mask = torch.ones(R, device=dev, dtype=torch.bool)
+        idx = torch.nonzero(gt_depth <= 0).flatten()
+        if idx.numel():
+            far_h = far[idx] if far.dim() else far
+            if self.sample_near_pcl:
+                zz, inv = npc.sample_near_pcl(rays_o[idx].detach().clone(), rays_d[idx].detach().clone(),
+                                              self.near_end, far_h, S)
+                near_mask[idx[inv]] = False
+            elif far.dim():
+                zz = self._linspace_rows(self.near_end, far_h, S, dev)
+            else:
+                zz = torch.linspace(self.near_end, far_h, steps=S, device=dev).repeat(idx.numel(), 1)
+            z[idx] = zz
+        return z.contiguous(), near_mask
+
     def render_batch_ray(self, npc, decoders, rays_d, rays_o, device, stage, gt_depth=None,
                          npc_geo_feats=None, npc_col_feats=None, is_tracker=False, cloud_pos=None,
-                         dynamic_r_query=None, exposure_feat=None):
+                         dynamic_r_query=None, exposure_feat=None, far=None):
         """Renderer.render_batch_ray (Renderer.py:77-202).  `cloud_pos` is accepted for signature
-        compatibility; positions live in the npc's device index."""
-        if gt_depth is None:
-            raise NotImplementedError("rays without sensor depth (sample_near_pcl branch, Renderer.py:142-168) "
-                                      "are a SURVEY §8f 'next' row")
+        compatibility; positions live in the npc's device index.  `far` (not in the reference signature) lets
+        render_img hand over the per-ray far bound of the reference's 3000-ray batches."""
+        N_rays = rays_o.shape[0]
+        if gt_depth is None:               # render over 10 m when no depth is available at all (:123-127)
+            gt_depth = torch.zeros(N_rays, device=rays_o.device)
+            far = torch.tensor(10.0, device=rays_o.device) if far is None else far
         gt_depth = gt_depth.detach().reshape(-1).float().contiguous()
+        z_vals = near_mask = None
+        if N_rays and not bool((gt_depth > 0).all()):
+            if far is None:
+                far = torch.minimum(5 * gt_depth.mean(), torch.max(gt_depth * 1.2)).float()
+            z_vals, near_mask = self.sample_depths(npc, rays_o, rays_d, gt_depth, far)
         color = stage == 'color'
         flags = _lib.STAGE_COLOR if color else 0
         theta = P_.pack_master(decoders)
@@ -167,17 +205,22 @@ class HipRenderer(object):
         m = dict(npc=npc,  # keeps the native context alive until backward has run
                  handle=npc.handle, gt_depth=gt_depth, r_query=rq, Bcol=P_.color_embed_B(decoders).to(rays_o.device)
                  .float().contiguous(), fb_geo=fb_geo.float().contiguous(), fb_col=fb_col.float().contiguous(),
-                 flags=flags, coef=self.sigmoid_coefficient)
+                 flags=flags, coef=self.sigmoid_coefficient, z_vals=z_vals)
         if npc_col_feats is None:
             npc_col_feats = npc_geo_feats
         depth, var, rgb, valid = _RenderFn.apply(rays_o, rays_d, npc_geo_feats, npc_col_feats, theta, affine, m)
+        if near_mask is not None:
+            valid = valid & near_mask                                     # Renderer.py:198
+            if not self.sample_near_pcl:
+                depth = torch.where(gt_depth > 0, depth, torch.zeros_like(depth))   # Renderer.py:200-201
         return depth, var, rgb, valid
 
     def render_img(self, npc, decoders, c2w, device, stage, gt_depth=None,
                    npc_geo_feats=None, npc_col_feats=None,
                    dynamic_r_query=None, cloud_pos=None, exposure_feat=None):
-        """Renderer.render_img (Renderer.py:204-283).  Pixels without sensor depth are returned as 0
-        (the reference ray-marches them, neural_point.py:217-277: SURVEY §8f-3)."""
+        """Renderer.render_img (Renderer.py:204-283).  The reference renders 3000-ray batches, and the far bound
+        of depth-less pixels is a statistic of their batch (:108-112): it is computed per such batch here and the
+        image is then rendered in a few large launches."""
         with torch.no_grad():
             H, W = self.H, self.W
             u = torch.arange(W, device=device, dtype=torch.float32)
@@ -186,17 +229,27 @@ class HipRenderer(object):
             dirs = torch.stack([(uu - self.cx) / self.fx, -(vv - self.cy) / self.fy, -torch.ones_like(uu)], -1)
             rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1).reshape(-1, 3)
             rays_o = c2w[:3, -1].expand(rays_d.shape)
-            gd = gt_depth.reshape(-1)
-            sel = torch.nonzero(gd > 0).flatten()
-            depth = torch.zeros(H * W, device=device, dtype=torch.float64)
-            unc = torch.zeros(H * W, device=device, dtype=torch.float64)
-            color = torch.zeros(H * W, 3, device=device)
+            n = H * W
+            B = self.ray_batch_size
+            if gt_depth is None:
+                gd = torch.zeros(n, device=device)
+                far = torch.full((n,), 10.0, device=device)
+            else:
+                gd = gt_depth.reshape(-1).float()
+                far = torch.empty(n, device=device)
+                for i in range(0, n, B):                     # the reference's batch statistics (:108-112)
+                    g = gd[i:i + B]
+                    far[i:i + B] = torch.minimum(5 * g.mean(), torch.max(g * 1.2))
+            depth = torch.zeros(n, device=device, dtype=torch.float64)
+            unc = torch.zeros(n, device=device, dtype=torch.float64)
+            color = torch.zeros(n, 3, device=device)
             rq = dynamic_r_query.reshape(-1) if self.use_dynamic_radius else None
-            for i in range(0, sel.shape[0], self.ray_batch_size * 16):
-                s = sel[i:i + self.ray_batch_size * 16]
+            big = B * 16
+            for i in range(0, n, big):
+                s = slice(i, min(i + big, n))
                 d, u_, c, _ = self.render_batch_ray(
                     npc, decoders, rays_d[s], rays_o[s].contiguous(), device, stage, gt_depth=gd[s],
                     npc_geo_feats=npc_geo_feats, npc_col_feats=npc_col_feats, cloud_pos=cloud_pos,
-                    dynamic_r_query=rq[s] if rq is not None else None, exposure_feat=exposure_feat)
+                    dynamic_r_query=rq[s] if rq is not None else None, exposure_feat=exposure_feat, far=far[s])
                 depth[s], unc[s], color[s] = d.double(), u_.double(), c
             return depth.reshape(H, W), unc.reshape(H, W), color.reshape(H, W, 3)

@@ -69,8 +69,18 @@ def load_decoders(cfg_name):
     return load_npz("decoders_seed1219_" + which)
 
 
+def fixture_cfg(fx):
+    """Config of a render fixture: the named variant + the flags the generator recorded."""
+    cfg = cfg_variant(fx["cfg_name"])
+    if "sample_near_pcl" in fx:
+        cfg["rendering"]["sample_near_pcl"] = bool(fx["sample_near_pcl"])
+    return cfg
+
+
+# the last two hold pixels without sensor depth (sample_near_pcl / uniform branch, Renderer.py:142-170)
 RENDER_CASES = ["render_replica_color_tracker", "render_replica_color_mapper", "render_replica_geometry_mapper",
-                "render_tum_color_mapper", "render_scannet_color_tracker"]
+                "render_tum_color_mapper", "render_scannet_color_tracker", "render_holes_nearpcl_mapper",
+                "render_holes_uniform_tracker"]
 
 
 def relerr(a, b):

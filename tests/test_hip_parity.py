@@ -13,7 +13,7 @@ import os
 import pytest
 import torch
 
-from tests.helpers import RENDER_CASES, base_cfg, cfg_variant, load_decoders, load_npz, relerr, ROOT
+from tests.helpers import RENDER_CASES, base_cfg, cfg_variant, fixture_cfg, load_decoders, load_npz, relerr, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -123,7 +123,7 @@ def test_composite_matches_oracle(dev):
 # ------------------------------------------------------------------------------ render forward
 def _run_case(case, dev, grads):
     fx = load_npz(case)
-    cfg = cfg_variant(fx["cfg_name"])
+    cfg = fixture_cfg(fx)
     dec = make_decoders(cfg, fx["cfg_name"], dev)
     npc = make_npc(cfg, fx["cloud"], fx["geo"], fx["col"], dev)
     rend = make_renderer(cfg, fx["coef"])
@@ -331,3 +331,101 @@ def test_tracker_iteration_through_hip_renderer(dev):
     assert rel < 1e-4                     # BASELINE.json: render-loss rel-err <= 1e-4
     # one Adam step moves each parameter by ~lr*sign(grad): equality means every gradient SIGN matches
     assert dq < 1e-6 and dT < 1e-6
+
+
+# ------------------------------------------------------------------------------ pixels without sensor depth
+def _hole_scene(seed, n_pts=9000, W=64, H=48):
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import synthetic as syn
+    cam = syn.intrinsics(W, H)
+    g = torch.Generator().manual_seed(seed)
+    c2w = syn.pose(3.0)
+    depth, color = syn.render_frame(cam, c2w)
+    cfg = base_cfg()
+    _, rq = syn.dynamic_radii(color, cfg)
+    pts = []
+    t = torch.linspace(0.0, 1.0, 3)
+    for v in range(3):
+        cw = syn.pose(3.0 + 1.0 * (v - 1))
+        u = torch.rand(n_pts // 9 + 1, generator=g) * (W - 1)
+        w = torch.rand(n_pts // 9 + 1, generator=g) * (H - 1)
+        ro, rd = O.rays_from_uv(u, w, cw, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        d = syn.box_depth(ro, rd)
+        z = 0.98 * d[:, None] * (1 - t) + 1.02 * d[:, None] * t
+        pts.append((ro[:, None] + rd[:, None] * z[..., None]).reshape(-1, 3))
+    cloud = torch.cat(pts)[:n_pts].float().contiguous()
+    cloud = cloud[cloud[:, 0] > cloud[:, 0].quantile(0.3)].contiguous()      # part of the view sees no cloud
+    N = cloud.shape[0]
+    geo = torch.zeros(N, 32).normal_(0, 0.1, generator=g)
+    col = torch.zeros(N, 32).normal_(0, 0.1, generator=g)
+    hole = torch.rand(H, W, generator=g) < 0.3
+    depth = torch.where(hole, torch.zeros_like(depth), depth)
+    return cfg, cam, c2w, depth, color, rq, cloud, geo, col
+
+
+def test_sample_near_pcl_matches_oracle(dev):
+    from oracle import pointslam_oracle as O
+    cfg, cam, c2w, depth, color, rq, cloud, geo, col = _hole_scene(31)
+    npc = make_npc(cfg, cloud, geo, col, dev)
+    g = torch.Generator().manual_seed(5)
+    n = 700
+    u = torch.rand(n, generator=g) * (cam["W"] - 1)
+    v = torch.rand(n, generator=g) * (cam["H"] - 1)
+    ro, rd = O.rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    near, far_a, far_b = cfg["rendering"]["near_end"], torch.tensor(4.3), torch.tensor(3.1)
+    z_o, inv_o = O.sample_near_pcl(cloud, ro, rd, near, float(far_a), 5, cfg["pointcloud"]["radius_query"])
+    z_h, inv_h = npc.sample_near_pcl(ro.to(dev), rd.to(dev), near, far_a.to(dev), 5)
+    assert 0.05 < float(inv_o.float().mean()) < 0.95
+    assert torch.equal(inv_h.cpu(), inv_o)
+    assert torch.equal(z_h.cpu(), z_o)
+    # per-ray far bound (render_img: one per reference batch): two groups
+    far_vec = torch.where(torch.arange(n) < n // 2, far_a, far_b)
+    z_h2, inv_h2 = npc.sample_near_pcl(ro.to(dev), rd.to(dev), near, far_vec.to(dev), 5)
+    h = n // 2
+    z_o2, inv_o2 = O.sample_near_pcl(cloud, ro[h:], rd[h:], near, float(far_b), 5, cfg["pointcloud"]["radius_query"])
+    assert torch.equal(z_h2[:h].cpu(), z_o[:h]) and torch.equal(inv_h2[:h].cpu(), inv_o[:h])
+    assert torch.equal(z_h2[h:].cpu(), z_o2) and torch.equal(inv_h2[h:].cpu(), inv_o2)
+    report(test="sample_near_pcl", n=n, invalid_frac=float(inv_o.float().mean()))
+
+
+@pytest.mark.parametrize("near_pcl", [True, False])
+def test_render_img_with_holes_matches_oracle(dev, near_pcl):
+    """render_img over an image with sensor holes, against the oracle run batch-by-batch like the reference
+    (Renderer.py:244-268: each 3000-ray batch has its own far bound; here batches of 500)."""
+    import types
+    from oracle import pointslam_oracle as O
+    from point_slam_amd.renderer import HipRenderer
+    cfg, cam, c2w, depth, color, rq, cloud, geo, col = _hole_scene(32)
+    cfg["rendering"]["sample_near_pcl"] = near_pcl
+    B = 500
+    dec = make_decoders(cfg, "replica", dev)
+    P = load_decoders("replica")
+    npc = make_npc(cfg, cloud, geo, col, dev)
+    rend = HipRenderer(cfg, None, types.SimpleNamespace(**cam), ray_batch_size=B)
+    g = torch.Generator().manual_seed(8)
+    fb_geo = torch.zeros(32).normal_(0, 0.01, generator=g)
+    fb_col = torch.zeros(32).normal_(0, 0.01, generator=g)
+    rend.fixed_fallback = (fb_geo.to(dev), fb_col.to(dev))
+    d_h, u_h, c_h = rend.render_img(npc, dec, c2w.to(dev), dev, "color", gt_depth=depth.to(dev),
+                                    npc_geo_feats=geo.to(dev), npc_col_feats=col.to(dev),
+                                    dynamic_r_query=rq.to(dev))
+    H, W = cam["H"], cam["W"]
+    vv, uu = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    ro, rd = O.rays_from_uv(uu.reshape(-1), vv.reshape(-1), c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    gd, rqf = depth.reshape(-1), rq.reshape(-1)
+    d_o, c_o = [], []
+    with torch.no_grad():
+        for i in range(0, H * W, B):
+            d, _, c, _, _ = O.render_batch_ray(cfg, P, cloud, geo, col, ro[i:i + B], rd[i:i + B], gd[i:i + B], "color",
+                                               rqf[i:i + B], fb_geo, fb_col, coef=rend.sigmoid_coefficient)
+            d_o.append(d); c_o.append(c)
+    d_o, c_o = torch.cat(d_o), torch.cat(c_o)
+    d_h, c_h = d_h.reshape(-1).float().cpu(), c_h.reshape(-1, 3).cpu()
+    hole = gd <= 0
+    rep = dict(test="render_img_holes", near_pcl=near_pcl, hole_frac=float(hole.float().mean()),
+               depth_rel=relerr(d_h, d_o), depth_rel_holes=relerr(d_h[hole], d_o[hole]) if near_pcl else 0.0,
+               rgb_abs=float((c_h - c_o).abs().max()), rgb_abs_holes=float((c_h[hole] - c_o[hole]).abs().max()))
+    report(**rep)
+    assert rep["depth_rel"] < 2e-4 and rep["rgb_abs"] < 5e-3
+    if not near_pcl:
+        assert float(d_h[hole].abs().max()) == 0.0

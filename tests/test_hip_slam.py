@@ -274,3 +274,29 @@ def test_depth_outlier_mask_native_matches_dropin():
     report(test="depth_outlier_mask", loss_rel=rel, active=[float(x) for x in n_act])
     assert float(n_act.max()) < 1500 * 0.995            # outliers and holes really were removed
     assert rel < 3e-4
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """Logger.log schema out, get_mesh_tsdf_fusion.load_neural_point_cloud in: same render afterwards."""
+    from point_slam_amd import checkpoint as CK
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev, n_pts=24000)
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(pts)
+    path = str(tmp_path / "00005.tar")
+    CK.save_checkpoint(path, s.npc, s.decoders, idx=5)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"geo_feats", "col_feats", "cloud_pos", "pts_num", "input_pos", "input_rgb",
+                       "decoder_state_dict", "gt_c2w_list", "estimate_c2w_list", "keyframe_list", "keyframe_dict",
+                       "selected_keyframes", "idx", "exposure_feat_all"}
+    assert isinstance(ck["cloud_pos"], list) and len(ck["cloud_pos"]) == ck["pts_num"] == pts.shape[0]
+    s2 = _slam(cfg, cam, "native", dev)
+    n = CK.load_neural_point_cloud(s2.npc, ck)
+    CK.load_decoders(s2.decoders, ck)
+    assert n == pts.shape[0]
+    assert torch.equal(s2.npc.cloud_pos().cpu(), s.npc.cloud_pos().cpu())
+    assert torch.equal(s2.npc.get_geo_feats().cpu(), s.npc.get_geo_feats().cpu())
+    q = pts[:500].to(dev)
+    D1, I1, c1 = s.npc.find_neighbors_faiss(q, step="query")
+    D2, I2, c2 = s2.npc.find_neighbors_faiss(q, step="query")
+    assert torch.equal(I1, I2) and torch.equal(c1, c2)
