@@ -97,6 +97,7 @@ static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& 
   d.master = a->params; d.wt = ctx->wt; d.Bcol = a->col_embed_B;
   d.fb_geo = a->fallback_geo; d.fb_col = a->fallback_col; d.affine = a->exposure_affine;
   d.ws = carve_ws(a->ws, a->n_rays, flags);
+  if (ctx->pre_I) { d.ws.I = ctx->pre_I; d.ws.cnt = ctx->pre_cnt; }   // neighbours answered ahead (psl_map_iters)
   return PSL_OK;
 }
 
@@ -191,6 +192,7 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
   if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
+  if (!ctx->pre_I)
   { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }

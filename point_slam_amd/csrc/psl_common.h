@@ -144,6 +144,8 @@ struct psl_ctx {
   int dw_slab_cap;       // number of slabs allocated
   // small device scratch
   int* d_counter;
+  int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
+  int* pre_cnt = nullptr;
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   int* scan_flags;       // for add_points compaction
   int scan_flags_cap;

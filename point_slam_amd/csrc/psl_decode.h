@@ -21,6 +21,11 @@ struct DecodeArgs {
   unsigned long long* dbg;   // optional phase timestamps (PSL_DEBUG_PHASES=1)
 };
 #define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
+#ifdef PSL_FINE_STAMPS   // stamps inside the GEMM loops perturb scheduling: opt-in build (make EXTRA=-DPSL_FINE_STAMPS)
+#define PSL_STAMPF(i) PSL_STAMP(i)
+#else
+#define PSL_STAMPF(i) do { } while (0)
+#endif
 
 // Algorithmic work per sample point (2 FLOP per MAC; unpadded layer sizes)
 constexpr double MAC_GEO = 15479.0, MAC_COL = 96700.0, MAC_NBR = 86256.0, MAC_INTERP = 256.0;

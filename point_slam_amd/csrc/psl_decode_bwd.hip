@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
             const float* xr = a.ws.n_x + ((size_t)p0 * K + row) * NX;
             sn = xr[f]; cs = xr[ERF + f];
           } else {
-            sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), &sn, &cs);
+            fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
           }
           float dy2 = TWO_PI * (sDxe[rl * LD_XE + f] * cs - sDxe[rl * LD_XE + ERF + f] * sn);
           if (parg) {
@@ -450,12 +450,12 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
       const float* Bg = M + MO(PI_G_B);
       float ax = 0.f, ay = 0.f, az = 0.f;
       for (int f = l32; f < EG; f += 32) {
-        float dy2 = TWO_PI * sDEg[s * LD_DE + f] * cosf(fourier_phase(x, y, z, Bg, EG, f));
+        float dy2 = TWO_PI * sDEg[s * LD_DE + f] * fast_cosf(fourier_phase(x, y, z, Bg, EG, f));
         ax += dy2 * Bg[f]; ay += dy2 * Bg[EG + f]; az += dy2 * Bg[2 * EG + f];
       }
       if (color && l32 < ECF) {
         float sn, cs;
-        sincosf(fourier_phase(x, y, z, a.Bcol, ECF, l32), &sn, &cs);
+        fast_sincosf(fourier_phase(x, y, z, a.Bcol, ECF, l32), sn, cs);
         float dy2 = TWO_PI * (sDEc[s * LD_DEC + l32] * cs - sDEc[s * LD_DEC + ECF + l32] * sn);
         ax += dy2 * a.Bcol[l32]; ay += dy2 * a.Bcol[ECF + l32]; az += dy2 * a.Bcol[2 * ECF + l32];
       }

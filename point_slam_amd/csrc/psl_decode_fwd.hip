@@ -152,7 +152,9 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
       if (live(s)) a.ws.cc[(size_t)(p0 + s) * C + ch] = ac;
     }
   }
+  PSL_STAMPF(8);
   lds_barrier();
+  PSL_STAMPF(9);
   // ---------------------------------------------------------------- F_theta per neighbour, 16 samples at a time
   if (color) {
   if (relpos) {
@@ -162,8 +164,11 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
       const int sb = 16 * sub;                  // first sample slot of this sub-tile
       // launder the weight pointers: they are loop-invariant, and LICM would hoist ALL weight loads of both
       // products out of the sub-tile loop (170 live registers -> scratch spills)
-      const float* WTs = WT; const float* Ms = M;
-      asm volatile("" : "+s"(WTs), "+s"(Ms));
+      // (an opaque zero OFFSET, not an opaque pointer: a laundered pointer loses its address space and every
+      // weight load becomes a flat_load that the LDS waits -- lgkmcnt -- then also wait for)
+      int opaque0 = 0;
+      asm volatile("" : "+s"(opaque0));
+      const float* WTs = WT + opaque0; const float* Ms = M + opaque0;
       // F_theta input rows [sin(10) cos(10) | feat(32)] for the 128 (sample, neighbour) pairs (decoder.py:371-378)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -177,17 +182,20 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
         int row = e / ERF, f = e - row * ERF;
         const float* rl = sRel + (sb * K + row) * 3;
         float sn, cs;
-        sincosf(fourier_phase(rl[0], rl[1], rl[2], Brel, ERF, f), &sn, &cs);
+        fast_sincosf(fourier_phase(rl[0], rl[1], rl[2], Brel, ERF, f), sn, cs);
         sXn[row * LD_XN + f] = sn;
         sXn[row * LD_XN + ERF + f] = cs;
       }
+      PSL_STAMPF(10);
       lds_barrier();
-      if (a.ws.n_x) {
-        for (int e = t; e < 128 * NX; e += WG) {
-          int row = e / NX, c = e - row * NX;
-          if (live(sb + (row >> 3))) a.ws.n_x[((size_t)(p0 + sb) * K + row) * NX + c] = sXn[row * LD_XN + c];
-        }
+      PSL_STAMPF(11);
+      if (a.ws.n_x) {   // each wave saves its own 16 rows, one 208 B row per store
+        float* nx = a.ws.n_x + ((size_t)(p0 + sb) * K + 16 * wave) * NX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (lane < NX && live(sb + ((16 * wave + r) >> 3))) nx[r * NX + lane] = sXn[(16 * wave + r) * LD_XN + lane];
       }
+      PSL_STAMPF(12);
       float* Hw = sHn + wave * 16 * L::LD_HH;
       const float* Xw = sXn + wave * 16 * LD_XN;
       const int g = lane >> 4, colw = lane & 15;
@@ -197,6 +205,7 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
       for (int half = 0; half < 2; ++half) {
         f32x4 acc[4];
         gemm16_multi<NX, 4>(Xw, LD_XN, WTs + wtoff(WT_C_N1) + 64 * half, HC, acc);
+        PSL_STAMPF(13 + 3 * half);
         if (half) wave_lds_sync();
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -214,10 +223,12 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
             }
           }
         }
+        PSL_STAMPF(14 + 3 * half);
         wave_lds_sync();
         f32x4 part[2];
         gemm16_multi<64, 2>(Hw, L::LD_HH, WTs + wtoff(WT_C_N2) + 64 * half * C, C, part);
         acc2[0] += part[0]; acc2[1] += part[1];
+        PSL_STAMPF(15 + 3 * half);
       }
       {
         const int s = sb + 2 * wave + (g >> 1);
@@ -240,6 +251,7 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
           }
         }
       }
+      PSL_STAMPF(19);
       lds_barrier();        // sXn / sHn are reused by the next sub-tile
     }
     if (MT * 16 > spt) {    // slots of sub-tiles that were skipped: defined (zero) colour features
@@ -255,14 +267,14 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
     for (int e = t; e < TM * EGP; e += WG) {
       int s = e / EGP, f = e - s * EGP;
       float v = 0.f;
-      if (f < EG) v = sinf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], Bg, EG, f));
+      if (f < EG) v = fast_sinf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], Bg, EG, f));
       sXg[s * LD_G + f] = v;
     }
     if (color) {
       for (int e = t; e < TM * ECF; e += WG) {
         int s = e / ECF, f = e - s * ECF;
         float sn, cs;
-        sincosf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], a.Bcol, ECF, f), &sn, &cs);
+        fast_sincosf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], a.Bcol, ECF, f), sn, cs);
         sXc[s * LD_C + f] = sn;
         sXc[s * LD_C + ECF + f] = cs;
         if (live(s) && a.ws.c_emb) {
@@ -314,12 +326,15 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
       }
       lds_barrier();
     }
-    if (t < TM) {  // output_linear 32 -> 1
-      const float* wo = M + MO(PI_G_OUT);
+    if (t < TM * 8) {  // output_linear 32 -> 1: 8 lanes per sample, 4 inputs each
+      const int sm = t >> 3, part = t & 7;
+      const float* wo = M + MO(PI_G_OUT) + 4 * part;
+      const float* xs = sXg + sm * LD_G + EGP + 4 * part;
       float o = 0.f;
 #pragma unroll
-      for (int k = 0; k < HG; ++k) o = fmaf(sXg[t * LD_G + EGP + k], wo[k], o);
-      sOcc[t] = o + M[MO(PI_G_OUT + 1)];
+      for (int k = 0; k < 4; ++k) o = fmaf(xs[k], wo[k], o);
+      o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
+      if (part == 0) sOcc[sm] = o + M[MO(PI_G_OUT + 1)];
     }
   }
 
@@ -333,10 +348,13 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         f32x4 acc[MT], u[MT];
+        if (i == 1) PSL_STAMPF(20);
         if (i == 0) gemm16m<EC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 0), HC, n0, acc);
         else if (i == 3) gemm16m<EC + HC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 3), HC, n0, acc);
         else gemm16m<HC, MT>(sXc + EC, LD_C, WT + wtoff(WT_C_L + i), HC, n0, acc);
+        if (i == 1) PSL_STAMPF(21);
         gemm16m<C, MT>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0, u);
+        if (i == 1) PSL_STAMPF(22);
         float b = M[MO(PI_C_L + 2 * i + 1) + n0 + colw];
         float bc = M[MO(PI_C_FCC + 2 * i + 1) + n0 + colw];
         f32x4 y[MT], h[MT];
@@ -347,7 +365,9 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
             y[m][r] = softplus100(acc[m][r] + b);
             h[m][r] = y[m][r] + (u[m][r] + bc);
           }
+        if (i == 1) PSL_STAMPF(23);
         lds_barrier();
+        if (i == 1) PSL_STAMPF(24);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           frag_store(sXc + m * 16 * LD_C + EC, LD_C, n0, h[m]);
@@ -362,15 +382,21 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
             }
           }
         }
+        if (i == 1) PSL_STAMPF(25);
         lds_barrier();
+        if (i == 1) PSL_STAMPF(26);
       }
-      if (t < TM * 3) {  // output_linear 128 -> 3
-        int s = t / 3, j = t - 3 * s;
-        const float* wo = M + MO(PI_C_OUT) + j * HC;
+      PSL_STAMPF(27);
+      for (int e = t; e < TM * 3 * 8; e += WG) {  // output_linear 128 -> 3: 8 lanes per output, 16 inputs each
+        const int o3 = e >> 3, part = e & 7;
+        const int s = o3 / 3, j = o3 - 3 * s;
+        const float* wo = M + MO(PI_C_OUT) + j * HC + 16 * part;
+        const float* xs = sXc + s * LD_C + EC + 16 * part;
         float o = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < HC; ++k) o = fmaf(sXc[s * LD_C + EC + k], wo[k], o);
-        sOut[s * 4 + j] = o + M[MO(PI_C_OUT + 1) + j];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o = fmaf(xs[k], wo[k], o);
+        o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
+        if (part == 0) sOut[s * 4 + j] = o + M[MO(PI_C_OUT + 1) + j];
       }
     }
   }
@@ -458,11 +484,24 @@ int launch_decode_fwd(const DecodeArgs& a, hipStream_t s) {
     if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long)));
     a2.dbg = dbg;
   }
+  static int nosave = -1;     // timing experiments only (results of the backward pass are garbage): PSL_DEBUG_NOSAVE
+  if (nosave < 0) { const char* e = getenv("PSL_DEBUG_NOSAVE"); nosave = e ? atoi(e) : 0; }
+  if (nosave & 1) a2.ws.n_h1 = nullptr;
+  if (nosave & 2) { a2.ws.n_x = nullptr; a2.ws.n_out = nullptr; }
+  if (nosave & 4) { a2.ws.c_y = nullptr; a2.ws.c_emb = nullptr; }
+  if (nosave & 8) a2.ws.g_y = nullptr;
   int rc = (mt == 1) ? launch_fwd_t<1>(a2, s) : launch_fwd_t<2>(a2, s);
   if (rc) return rc;
   if (dbg_on) {
-    unsigned long long h[8];
+    unsigned long long h[32];
     PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (a.flags & PSL_STAGE_COLOR) {
+      fprintf(stderr, "[psl fwd fine] p1: gather %llu bar %llu nbr-in %llu bar %llu nx-store %llu | g1a %llu act %llu g2a %llu g1b %llu act %llu g2b %llu epi %llu\n",
+              h[8] - h[1], h[9] - h[8], h[10] - h[9], h[11] - h[10], h[12] - h[11], h[13] - h[12], h[14] - h[13],
+              h[15] - h[14], h[16] - h[15], h[17] - h[16], h[18] - h[17], h[19] - h[18]);
+      fprintf(stderr, "[psl fwd fine] trunk layer1: gemm %llu fcc %llu act %llu bar %llu store %llu bar %llu | out-linear %llu\n",
+              h[21] - h[20], h[22] - h[21], h[23] - h[22], h[24] - h[23], h[25] - h[24], h[26] - h[25], h[6] - h[27]);
+    }
     fprintf(stderr, "[psl fwd P=%d flags=%x spt=%d] cycles: p0 %llu p1 %llu p2 %llu geo %llu nbr %llu trunk %llu | total %llu\n",
             a.P, a.flags, a2.spt, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[6] - h[0]);
   }

@@ -48,11 +48,12 @@ struct RayBufs {             // per-iteration ray batch (n slots, inactive slots
 __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int H1, int W0, int W1,
                                                    const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
                                                    const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
-                                                   RayBufs b) {
+                                                   RayBufs b, int n_batches = 1) {
+  // n_batches > 1: the rays of several mapper iterations at once (kNN prefetch); only o, d, gd, rq are written then
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int n = n_frames * pix_per_frame;
-  if (i >= n) return;
-  int f = i / pix_per_frame;
+  if (i >= n * n_batches) return;
+  int f = (i % n) / pix_per_frame;
   const FrameDev& fr = frames[f];
   float R[3][3], T[3];
   if (cam_tensor) {
@@ -71,13 +72,15 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
     b.rays_d[i * 3 + a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
     b.rays_o[i * 3 + a] = T[a];
   }
-  b.dirs[i * 3] = d0; b.dirs[i * 3 + 1] = d1; b.dirs[i * 3 + 2] = d2;
   size_t px = (size_t)v * cam.W + u;
   float dep = fr.depth[px];
-  b.gc[i * 3] = fr.color[px * 3]; b.gc[i * 3 + 1] = fr.color[px * 3 + 1]; b.gc[i * 3 + 2] = fr.color[px * 3 + 2];
+  if (b.dirs) {
+    b.dirs[i * 3] = d0; b.dirs[i * 3 + 1] = d1; b.dirs[i * 3 + 2] = d2;
+    b.gc[i * 3] = fr.color[px * 3]; b.gc[i * 3 + 1] = fr.color[px * 3 + 1]; b.gc[i * 3 + 2] = fr.color[px * 3 + 2];
+  }
   if (b.rq) b.rq[i] = fr.r_query ? fr.r_query[px] : 0.f;
   bool act = dep > 0.f;                      // depth_filter (common.py:173-179)
-  b.active[i] = act ? 1 : 0;
+  if (b.active) b.active[i] = act ? 1 : 0;
   b.gd[i] = act ? dep : 1.0f;                // inactive slots get a harmless finite depth
 }
 
@@ -510,9 +513,17 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   return PSL_OK;
 }
 
+// kNN prefetch: the mapper's rays do not depend on what it optimises (fixed poses, pre-drawn pixels), so the 8-NN
+// lookups of a block of iterations are answered by ONE launch (~10^5 queries) instead of one small launch each.
+static int map_knn_block(int n_rays) { return std::max(1, std::min(64, 262144 / std::max(n_rays, 1))); }
+static int64_t map_prefetch_floats(int n_rays) {
+  int64_t rays = (int64_t)map_knn_block(n_rays) * n_rays;
+  return rays * 8 + rays * S * (K + 1) + 64;       // o, d, gd, rq | I [.][5][8], cnt [.][5]
+}
+
 extern "C" int64_t psl_map_ws_floats(int n_rays, int n_frames) {
   if (n_rays < 0 || n_frames < 0) return PSL_ERR_ARG;
-  return rays_floats(n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
+  return map_prefetch_floats(n_rays) + rays_floats(n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
          (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 16 + psl_param_master_floats();
 }
 
@@ -533,7 +544,15 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   float* loss_scratch = p; p += 64;
   FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) * m->n_frames + 3) / 4 + 4;
   float* g_params = p; p += psl_param_master_floats();
+  const int kblock = map_knn_block(n);
+  RayBufs pb{};                                        // prefetch block: rays of `kblock` iterations
+  { const size_t nr = (size_t)kblock * n;
+    auto take = [&](size_t k) { float* r = p; p += (k + 3) / 4 * 4; return r; };
+    pb.rays_o = take(3 * nr); pb.rays_d = take(3 * nr); pb.gd = take(nr); pb.rq = any_rq ? take(nr) : nullptr; }
+  int* pre_I = (int*)p; p += (size_t)kblock * n * S * K;
+  int* pre_cnt = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; } } pre_guard{ctx};
   {
     std::vector<FrameDev> fh(m->n_frames);
     for (int f = 0; f < m->n_frames; ++f) {
@@ -557,6 +576,19 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   for (int it = 0; it < m->n_iters; ++it) {
     // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
     const bool color_stage = it > m->n_geo_iters;
+    if (it % kblock == 0) {
+      const int nb = std::min(kblock, m->n_iters - it);
+      { ProfScope ps(ctx, PROF_MISC, s);
+        hipLaunchKernelGGL(k_ray_setup, dim3((nb * n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W,
+                           fdev, m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, pb,
+                           nb);
+        PSL_LAUNCH_CHECK(); }
+      ProfScope ps(ctx, PROF_KNN, s, 108.0 * nb * n * S);
+      int rc = knn_rays(ctx, pb.rays_o, pb.rays_d, pb.gd, nullptr, pb.rq, nb * n, pre_I, pre_cnt, s);
+      if (rc) return rc;
+    }
+    ctx->pre_I = pre_I + (size_t)(it % kblock) * n * S * K;
+    ctx->pre_cnt = pre_cnt + (size_t)(it % kblock) * n * S;
     { ProfScope ps(ctx, PROF_MISC, s);
       hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W, fdev,
                          m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, b);
