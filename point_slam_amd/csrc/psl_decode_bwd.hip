@@ -27,7 +27,8 @@ constexpr int PW = 16 * LD_CF + 16 * LD_Z1 + 16 * LD_XE;   // per-wave F_theta s
 template <bool PTSG>
 struct BwdLds {
   static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oDB = 720, oAff = 752, oDO = 768,
-                       oDCg = 832, oDCc = oDCg + 16 * LD_CF, oP = oDCc + 16 * LD_CF;
+                       oDCg = 832, oDCc = oDCg + 16 * LD_CF, oGg = oDCc + 16 * LD_CF, oDZg = oGg + 16 * LD_CF,
+                       oP = oDZg + 16 * LD_CF;
   static constexpr int oGW = oP, oDP = oGW + (PTSG ? 128 : 0), oDEg = oDP + (PTSG ? 64 : 0),
                        oDEc = oDEg + (PTSG ? 16 * LD_DE : 0), oU = oDEc + (PTSG ? 16 * LD_DEC : 0);
   static constexpr int oG = oU, oDZ = oG + 16 * LD_HN, trunk = 2 * 16 * LD_HN, waves = 8 * PW;
@@ -63,6 +64,8 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
   float* sDO = smem + L::oDO;               // [16][4] dL/d colour logits (pre-affine)
   float* sDCg = smem + L::oDCg;             // [16][34] dL/d c_geo
   float* sDCc = smem + L::oDCc;             // [16][34] dL/d c_col
+  float* sGg = smem + L::oGg;               // [16][34] geometry dL/dh tile (fused geometry backward, mapper)
+  float* sDZg = smem + L::oDZg;             // [16][34] geometry dz tile
   float* sGW = smem + L::oGW;               // [16][8]  dL/dw            (PTSG only)
   float* sDP = smem + L::oDP;               // [16][4]  dL/dp            (PTSG only)
   float* sDEg = smem + L::oDEg;             // [16][98] dL/d geo emb     (PTSG only)
@@ -82,6 +85,11 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
   const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
   const bool parg = (a.flags & PSL_PARAM_GRAD) != 0 && color;
   const float* __restrict__ M = a.master;
+  // Mapper, colour stage: the geometry decoder's backward chain (2 column tiles wide) rides along inside the colour
+  // trunk's layer loop on waves 2..6, which have slack there (waves 0,1 carry the extra dL/dc product), instead of
+  // running as a 15-barrier phase of its own with six waves idle.  The tracker instantiation needs the 93/125-wide
+  // embedding gradients (all 8 waves) and keeps the separate phase.
+  const bool geo_fused = !PTSG && color;
 
   PSL_STAMP(0);
   // ---------------------------------------------------------------- phase 0: reload per-sample state, zero accumulators
@@ -151,9 +159,16 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
         int s = e >> 7, k = e & 127;
         sG[s * LD_HN + k] = sDO[s * 4] * wo[k] + sDO[s * 4 + 1] * wo[HC + k] + sDO[s * 4 + 2] * wo[2 * HC + k];
       }
+      if (geo_fused && t < TILE * HG) {   // geometry: G = d_occ * w_out (see the geometry phase below)
+        int s = t >> 5, k = t & 31;
+        int p = p0 + s;
+        float docc = (p < a.P) ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+        sGg[s * LD_CF + k] = docc * M[MO(PI_G_OUT) + k];
+      }
     }
     lds_barrier();
     f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};   // waves 0,1: dL/dc_col column slice
+    f32x4 dcg = {0.f, 0.f, 0.f, 0.f};     // waves 2,3: dL/dc_geo column slice (fused geometry backward)
     const int n0 = 16 * wave;
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
@@ -172,6 +187,18 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
       frag_store(sDZ, LD_HN, n0, dz);
       // step B: dL/dc += G * Wc_i   (fc_c.i.weight [128][32])
       if (wave < 2) dcacc += gemm16<HC>(sG, LD_HN, M + MO(PI_C_FCC + 2 * i), C, n0);
+      if (geo_fused && (wave == 2 || wave == 3)) {     // geometry steps A, B
+        const int ng = 16 * (wave - 2);
+        f32x4 gg = frag_load(sGg, LD_CF, ng), dzg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int p = p0 + g4 + r;
+          float y = (p < a.P) ? a.ws.g_y[((size_t)i * a.ws.Ppad + p) * HG + ng + colw] : 0.f;
+          dzg[r] = (p < a.P && y > 0.f) ? gg[r] : 0.f;       // ReLU
+        }
+        frag_store(sDZg, LD_CF, ng, dzg);
+        dcg += gemm16<HG>(sGg, LD_CF, M + MO(PI_G_FCC + 2 * i), C, ng);
+      }
       lds_barrier();
       // step C: dL/d(input of layer i) = dz * W_i   (pts_linears.i.weight [128][Kin])
       f32x4 gn = {0.f, 0.f, 0.f, 0.f}, ge = {0.f, 0.f, 0.f, 0.f};
@@ -184,7 +211,20 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
       } else {
         gn = gemm16<HC>(sDZ, LD_HN, Wi, HC, n0);
       }
+      // geometry step C on waves 4..6: dz * W_i; layer 3 only feeds columns 93..124 (the h part of [emb | h])
+      f32x4 gxg = {0.f, 0.f, 0.f, 0.f};
+      const bool geoC = geo_fused && i > 0 && wave >= 4 && wave < (i == 3 ? 7 : 6);
+      const int ngc = (i == 3 ? 80 : 0) + 16 * (wave - 4);
+      if (geoC) gxg = gemm16<HG>(sDZg, LD_CF, M + MO(PI_G_L + 2 * i), i == 3 ? EG + HG : HG, ngc);
       lds_barrier();
+      if (geoC) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int col = ngc + colw;
+          if (i == 3) { if (col >= EG && col < EG + HG) sGg[(g4 + r) * LD_CF + col - EG] = gxg[r]; }
+          else sGg[(g4 + r) * LD_CF + col] = gxg[r];
+        }
+      }
       if (i > 0) frag_store(sG, LD_HN, n0, gn);
       if ((i == 3 || i == 0) && ptsg && wave < 3) {
 #pragma unroll
@@ -195,6 +235,10 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
     if (wave < 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) sDCc[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
+    }
+    if (geo_fused && (wave == 2 || wave == 3)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDCg[(g4 + r) * LD_CF + 16 * (wave - 2) + colw] = sHas[g4 + r] ? dcg[r] : 0.f;
     }
     lds_barrier();
     PSL_STAMP(2);
@@ -337,6 +381,7 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
   PSL_STAMP(3);
   // ================================================================== geometry decoder
   {
+    if (!geo_fused) {
     // G = d_occ * w_out (output_linear.weight [1][32]); d_occ flows for masked samples too (straight-through)
     if (t < TILE * HG) {
       int s = t >> 5, k = t & 31;
@@ -390,6 +435,7 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
       for (int r = 0; r < 4; ++r) sDCg[(g4 + r) * LD_CF + n0 + colw] = sHas[g4 + r] ? dcacc[r] : 0.f;
     }
     lds_barrier();
+    }  // !geo_fused
     // scatter into the geometry feature rows, collect dL/dw
     {
       const int s = t >> 5, ch = t & 31;

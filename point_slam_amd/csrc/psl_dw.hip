@@ -16,6 +16,7 @@ struct DwJob {
   long long rows;
   int out_off, ld_out, bias_off;
   int n_tiles, k_tiles;
+  int aq, bq;                // columns per lane vector on the dZ / X side: 4 (64-wide tile) or 2 (32-wide)
   int item_base, items;      // items of this job = n_tiles*k_tiles*n_chunks
   int rows_per_chunk, n_chunks;
 };
@@ -28,12 +29,126 @@ struct DwReduceArgs { int chunks_of_entry[kNumColorParams]; int slab_off[kNumCol
 constexpr int SLAB_STRIDE = kColorFloats + 4 * kNumColorParams;
 static int slab_off_of(int pi) { int o = 0; for (int j = 0; j < pi; ++j) o += (kParams[j].rows * kParams[j].cols + 3) / 4 * 4; return o; }
 
-// One wavefront = one 64x64 output tile of one layer for one chunk of rows.  Each lane fetches ONE float4 of dZ
-// (4 consecutive n-columns) and ONE float4 of X (4 consecutive k-columns) per 4-row step and feeds 16 MFMAs with
-// them (element jn of the A quad x element jk of the B quad): 8x fewer load instructions per MFMA than a
+// One wavefront = one (16*AQ) x (16*BQ) output tile of one layer for one chunk of rows (AQ, BQ in {4, 2}: 64 or 32
+// columns; the 32-wide forms serve fc_c (32 inputs) and F_theta's second layer (32 outputs) without computing
+// padding).  Each lane fetches ONE AQ-vector of dZ (consecutive n-columns) and ONE BQ-vector of X (consecutive
+// k-columns) per 4-row step and feeds AQ*BQ MFMAs with them: 8x fewer load instructions per MFMA than a
 // scalar-fragment tile and half the L2 traffic of 32x32 tiles.  MFMA tile (jn,jk) therefore owns the interleaved
-// columns n = n0 + 4*i + jn, k = k0 + 4*j + jk; the epilogue writes 4 consecutive k per lane.
-// 4 row-steps are issued per loop trip (8 independent 16-B loads, then 64 MFMAs on 16 independent accumulators).
+// columns n = n0 + AQ*i + jn, k = k0 + BQ*j + jk; the epilogue writes BQ consecutive k per lane.
+// 4 row-steps are issued per loop trip (8 independent loads, then up to 64 MFMAs on independent accumulators).
+template <int Q> struct VecOf;
+template <> struct VecOf<4> { using type = float4; };
+template <> struct VecOf<2> { using type = float2; };
+template <int Q> __device__ __forceinline__ void unpack(const typename VecOf<Q>::type& v, float (&o)[Q]);
+template <> __device__ __forceinline__ void unpack<4>(const float4& v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+template <> __device__ __forceinline__ void unpack<2>(const float2& v, float (&o)[2]) { o[0] = v.x; o[1] = v.y; }
+
+template <int AQ, int BQ>
+__device__ __forceinline__ void dw_tile(const DwJob& J, int item, int chunk, float* slab) {
+  using AV = typename VecOf<AQ>::type;
+  using BV = typename VecOf<BQ>::type;
+  const int lane = threadIdx.x & 63, g = lane >> 4, colw = lane & 15;
+  const long long r0 = (long long)chunk * J.rows_per_chunk;
+  const long long r1 = min(J.rows, r0 + J.rows_per_chunk);
+  const int nt = item / J.k_tiles, kt = item - nt * J.k_tiles;
+  const int ktot = J.k0_cols + J.k1_cols;
+  const int nq = 16 * AQ * nt + AQ * colw, kq = 16 * BQ * kt + BQ * colw;   // first column of this lane's vectors
+  // a vector never straddles the B0|B1 seam (k0_cols is a multiple of 4); lanes whose columns lie past the end read
+  // column 0 instead (finite, in-buffer) and their results are never stored
+  const bool nin = nq < J.n_valid, kin = kq < ktot;
+  const float* ap = J.A + (nin ? nq : 0);
+  const float* bp; int ldb;
+  if (!kin) { bp = J.B0; ldb = J.ldb0; }
+  else if (kq < J.k0_cols) { bp = J.B0 + kq; ldb = J.ldb0; }
+  else { bp = J.B1 + (kq - J.k0_cols); ldb = J.ldb1; }
+  f32x4 acc[AQ][BQ];
+#pragma unroll
+  for (int x = 0; x < AQ; ++x)
+#pragma unroll
+    for (int y = 0; y < BQ; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bs[AQ];
+#pragma unroll
+  for (int x = 0; x < AQ; ++x) bs[x] = 0.f;
+  constexpr int U = 4;
+  // No element masks: columns past n_valid / ktot read finite in-buffer values whose products land in output
+  // elements that are never stored (and in bias sums that are never stored).  Rows are masked in the tail trip only.
+  // Software pipeline: the RAW loads of trip t+1 are issued before the MFMAs of trip t and not touched until
+  // trip t+1 (any arithmetic on them here -- e.g. masking -- would make the compiler wait for them first).
+  const float* a_ptr = ap + (r0 + g) * (long long)J.lda;
+  const float* b_ptr = bp + (r0 + g) * (long long)ldb;
+  const long long a_step = 4LL * J.lda, b_step = 4LL * ldb;
+  const int nfull = (int)((r1 - r0) / (4 * U));
+  AV av[U], an[U];
+  BV bv[U], bn[U];
+  auto fetch = [&](AV (&a_out)[U], BV (&b_out)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a_out[u] = *reinterpret_cast<const AV*>(a_ptr + u * a_step);
+      b_out[u] = *reinterpret_cast<const BV*>(b_ptr + u * b_step);
+    }
+    a_ptr += U * a_step; b_ptr += U * b_step;
+  };
+  auto trip = [&](const AV (&a4)[U], const BV (&b4)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float a_[AQ], b_[BQ];
+      unpack<AQ>(a4[u], a_);
+      unpack<BQ>(b4[u], b_);
+#pragma unroll
+      for (int x = 0; x < AQ; ++x) {
+#pragma unroll
+        for (int y = 0; y < BQ; ++y) acc[x][y] = mfma16(a_[x], b_[y], acc[x][y]);
+        bs[x] += a_[x];
+      }
+    }
+  };
+  if (nfull > 0) fetch(an, bn);
+  for (int t = 0; t < nfull; ++t) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+    if (t + 1 < nfull) fetch(an, bn);
+    trip(av, bv);
+  }
+  {  // tail: < 16 rows left; rows past r1 contribute zeros (A masked, B read from a clamped row)
+    const long long rt = r0 + (long long)nfull * (4 * U);
+    if (rt < r1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long row = rt + 4 * u + g;
+        const bool v = row < r1;
+        const long long rr = v ? row : r0;
+        AV a4 = *reinterpret_cast<const AV*>(ap + rr * J.lda);
+        bv[u] = *reinterpret_cast<const BV*>(bp + rr * ldb);
+        if (!v) {
+          if constexpr (AQ == 4) a4 = make_float4(0.f, 0.f, 0.f, 0.f); else a4 = make_float2(0.f, 0.f);
+        }
+        av[u] = a4;
+      }
+      trip(av, bv);
+    }
+  }
+  // acc[x][y][q] (lane g,colw) = dW[n = 16AQ*nt + AQ(4g+q) + x][k = 16BQ*kt + BQ*colw + y]
+#pragma unroll
+  for (int x = 0; x < AQ; ++x)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int n = 16 * AQ * nt + AQ * (4 * g + q) + x;
+      if (n < J.n_valid && kin) {    // ktot is a multiple of 4: the vector is entirely inside or outside
+        float* dst = slab + J.out_off + n * J.ld_out + kq;
+        if constexpr (BQ == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[x][0][q], acc[x][1][q], acc[x][2][q], acc[x][3][q]);
+        else *reinterpret_cast<float2*>(dst) = make_float2(acc[x][0][q], acc[x][1][q]);
+      }
+    }
+  if (kt == 0) {   // bias gradient = column sums of dZ: this lane saw rows g, g+4, ... of columns nq..nq+AQ-1
+#pragma unroll
+    for (int x = 0; x < AQ; ++x) {
+      float v = bs[x];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      if (g == 0 && nq + x < J.n_valid) slab[J.bias_off + nq + x] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_dw(DwArgs d) {
   const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (wid >= d.n_items) return;
@@ -45,84 +160,10 @@ __global__ __launch_bounds__(256) void k_dw(DwArgs d) {
   const int tiles = J.n_tiles * J.k_tiles;
   const int chunk = item / tiles;
   item -= chunk * tiles;
-  const int lane = threadIdx.x & 63, g = lane >> 4, colw = lane & 15;
-  const long long r0 = (long long)chunk * J.rows_per_chunk;
-  const long long r1 = min(J.rows, r0 + J.rows_per_chunk);
   float* slab = d.slabs + (size_t)chunk * SLAB_STRIDE;
-  const int nt = item / J.k_tiles, kt = item - nt * J.k_tiles;
-  const int ktot = J.k0_cols + J.k1_cols;
-  const int nq = 64 * nt + 4 * colw, kq = 64 * kt + 4 * colw;     // first column of this lane's quads
-  // the quad never straddles the B0|B1 seam (k0_cols is a multiple of 4); columns past the end are masked and
-  // their loads redirected to column 0 so that nothing is read outside the scratch buffer
-  const bool nin = nq < J.n_valid, kin = kq < ktot;
-  const float* ap = J.A + (nin ? nq : 0);
-  const float* bp; int ldb;
-  if (!kin) { bp = J.B0; ldb = J.ldb0; }
-  else if (kq < J.k0_cols) { bp = J.B0 + kq; ldb = J.ldb0; }
-  else { bp = J.B1 + (kq - J.k0_cols); ldb = J.ldb1; }
-  bool am[4], bm[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { am[e] = nq + e < J.n_valid; bm[e] = kq + e < ktot; }
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 4;
-  // software pipeline: the loads of trip t+1 are in flight while the 64 MFMAs of trip t issue
-  float4 av[U], bv[U], an[U], bn[U];
-  auto fetch = [&](long long r, float4 (&a_out)[U], float4 (&b_out)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      long long row = r + 4 * u + g;
-      bool v = row < r1;
-      long long rr = v ? row : r0;
-      float4 a4 = *reinterpret_cast<const float4*>(ap + rr * J.lda);
-      float4 b4 = *reinterpret_cast<const float4*>(bp + rr * ldb);
-      a_out[u] = make_float4((v && am[0]) ? a4.x : 0.f, (v && am[1]) ? a4.y : 0.f, (v && am[2]) ? a4.z : 0.f,
-                             (v && am[3]) ? a4.w : 0.f);
-      b_out[u] = make_float4(bm[0] ? b4.x : 0.f, bm[1] ? b4.y : 0.f, bm[2] ? b4.z : 0.f, bm[3] ? b4.w : 0.f);
-    }
-  };
-  fetch(r0, av, bv);
-  for (long long r = r0; r < r1; r += 4 * U) {
-    const bool more = r + 4 * U < r1;
-    if (more) fetch(r + 4 * U, an, bn);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float a_[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
-      const float b_[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = mfma16(a_[x], b_[y], acc[x][y]);
-        bs[x] += a_[x];
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
-    }
-  }
-  // acc[x][y][q] (lane g,colw) = dW[n = 64nt + 4(4g+q) + x][k = 64kt + 4colw + y]
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int n = 64 * nt + 4 * (4 * g + q) + x;
-      if (n < J.n_valid && kin)     // ktot is a multiple of 4: the quad is entirely inside or outside
-        *reinterpret_cast<float4*>(slab + J.out_off + n * J.ld_out + kq) =
-            make_float4(acc[x][0][q], acc[x][1][q], acc[x][2][q], acc[x][3][q]);
-    }
-  if (kt == 0) {   // bias gradient = column sums of dZ: this lane saw rows g, g+4, ... of columns nq..nq+3
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      float v = bs[x];
-      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-      if (g == 0 && nq + x < J.n_valid) slab[J.bias_off + nq + x] = v;
-    }
-  }
+  if (J.aq == 4 && J.bq == 4) dw_tile<4, 4>(J, item, chunk, slab);
+  else if (J.aq == 4) dw_tile<4, 2>(J, item, chunk, slab);
+  else dw_tile<2, 4>(J, item, chunk, slab);
 }
 
 // g_params[e] = sum over the chunks of e's tensor, in a fixed order (deterministic): 32 consecutive elements x 8
@@ -181,7 +222,9 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
     DwJob& J = d.job[nj++];
     J.A = A; J.lda = lda; J.n_valid = nv; J.B0 = B0; J.ldb0 = ldb0; J.k0_cols = k0; J.B1 = B1; J.ldb1 = ldb1;
     J.k1_cols = k1; J.rows = rows; J.out_off = slab_off_of(out_pi); J.ld_out = k0 + k1; J.bias_off = slab_off_of(out_pi + 1);
-    J.n_tiles = (nv + 63) / 64; J.k_tiles = (k0 + k1 + 63) / 64;
+    // 32-wide vectors where the operand has exactly 32 columns (fc_c: 32 inputs; F_theta linear2: 32 outputs)
+    J.aq = (nv == 32) ? 2 : 4; J.bq = (k0 + k1 == 32 && J.aq == 4) ? 2 : 4;
+    J.n_tiles = (nv + 16 * J.aq - 1) / (16 * J.aq); J.k_tiles = (k0 + k1 + 16 * J.bq - 1) / (16 * J.bq);
     J.n_chunks = (int)std::min<long long>(std::max<long long>((rows + chunk_rows - 1) / chunk_rows, 1), MAX_CHUNKS);
     long long rpc = (rows + J.n_chunks - 1) / J.n_chunks;
     J.rows_per_chunk = (int)((rpc + 15) / 16 * 16);
