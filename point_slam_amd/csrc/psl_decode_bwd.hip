@@ -172,6 +172,12 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
     const int n0 = 16 * wave;
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
+      // the weight fragments of step C depend on nothing computed here: request them first, so that their L2
+      // latency elapses behind step A/B and the barrier
+      float wC[HC / 4];
+      const float* Wi = M + MO(PI_C_L + 2 * i);
+      if (i == 3) fetch_b16<HC>(Wi, EC + HC, EC + n0, wC);
+      else if (i > 0) fetch_b16<HC>(Wi, HC, n0, wC);
       // step A: dz = G * act'(y)
       f32x4 gv = frag_load(sG, LD_HN, n0), dz;
 #pragma unroll
@@ -202,14 +208,13 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
       lds_barrier();
       // step C: dL/d(input of layer i) = dz * W_i   (pts_linears.i.weight [128][Kin])
       f32x4 gn = {0.f, 0.f, 0.f, 0.f}, ge = {0.f, 0.f, 0.f, 0.f};
-      const float* Wi = M + MO(PI_C_L + 2 * i);
       if (i == 3) {
-        gn = gemm16<HC>(sDZ, LD_HN, Wi, EC + HC, EC + n0);                 // h part: input cols 40..167
+        gn = mma16<HC>(sDZ, LD_HN, wC);                                     // h part: input cols 40..167
         if (ptsg && wave < 3) ge = gemm16<HC>(sDZ, LD_HN, Wi, EC + HC, n0); // embedding part: cols 0..39(47)
       } else if (i == 0) {
         if (ptsg && wave < 3) ge = gemm16<HC>(sDZ, LD_HN, Wi, EC, n0);
       } else {
-        gn = gemm16<HC>(sDZ, LD_HN, Wi, HC, n0);
+        gn = mma16<HC>(sDZ, LD_HN, wC);
       }
       // geometry step C on waves 4..6: dz * W_i; layer 3 only feeds columns 93..124 (the h part of [emb | h])
       f32x4 gxg = {0.f, 0.f, 0.f, 0.f};

@@ -64,6 +64,38 @@ __device__ __forceinline__ void gemm16m(const float* Xs, int ldx, const float* _
   }
 }
 
+// The same product in two halves, so that the B fragments of the NEXT layer can be requested before the barriers
+// and the activation of the current one (the weights do not depend on the data): fetch_b issues the loads,
+// mma16m consumes them.
+template <int KDIM>
+__device__ __forceinline__ void fetch_b(const float* __restrict__ W, int ldw, int n0, float (&wv)[KDIM / 4]) {
+  const int lane = threadIdx.x & 63;
+  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
+#pragma unroll
+  for (int ks = 0; ks < KDIM / 4; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
+}
+template <int KDIM, int MT>
+__device__ __forceinline__ void mma16m(const float* Xs, int ldx, const float (&wv)[KDIM / 4], f32x4 (&acc)[MT]) {
+  const int lane = threadIdx.x & 63;
+  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
+  constexpr int NK = KDIM / 4;
+  if constexpr (MT == 1) {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks + 1 < NK; ks += 2) { a0 = mfma16(xp[4 * ks], wv[ks], a0); a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1); }
+    if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
+    acc[0] = a0 + a1;
+  } else {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma16(xp[m * 16 * ldx + 4 * ks], wv[ks], acc[m]);
+    }
+  }
+}
+
 template <int MT>
 __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
   using L = FwdLds<MT>;
@@ -286,75 +318,85 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
   lds_barrier();
 
   PSL_STAMP(3);
-  // ---------------------------------------------------------------- phase 3: geometry MLP (waves 0,1)
-  // h = relu(W_i h + b_i) + (Wc_i c + bc_i); after block 2 the embedding is re-attached (decoder.py:207-219)
-  {
-    const int g4 = 4 * (lane >> 4), colw = lane & 15;
-    const int n0 = 16 * wave;
+  // ---------------------------------------------------------------- phase 3: geometry MLP, K-split over 8 waves
+  // h = relu(W_i h + b_i) + (Wc_i c + bc_i); after block 2 the embedding is re-attached (decoder.py:207-219).
+  // The layer is only 32 columns wide (2 MFMA column tiles): wave w takes column tile w&1 and the K-quarter w>>1,
+  // the four partial tiles meet in LDS and one thread per element finishes the layer (bias, ReLU, skip term, save).
+  // In the colour stage these two steps ride inside the colour trunk's layer loop and share its two barriers; the
+  // partial tiles live in the part of the F_theta region that the decoder inputs leave free.
+  float* sPm = sXc + TM * LD_C;             // [4][TM][34] partial sums of W_i h
+  float* sPf = sPm + 4 * TM * LD_CF;        // [TM][34]    Wc_i c
+  auto geo_partial = [&](int i) {
+    const int n0g = 16 * (wave & 1), kq = wave >> 1;
+    f32x4 pm[MT];
+    if (i == 0) gemm16m<EGP / 4, MT>(sXg + (EGP / 4) * kq, LD_G, WT + wtoff(WT_G_L + 0) + (EGP / 4) * kq * HG, HG, n0g, pm);
+    else if (i == 3) gemm16m<(EGP + HG) / 4, MT>(sXg + ((EGP + HG) / 4) * kq, LD_G,
+                                                 WT + wtoff(WT_G_L + 3) + ((EGP + HG) / 4) * kq * HG, HG, n0g, pm);
+    else gemm16m<HG / 4, MT>(sXg + EGP + (HG / 4) * kq, LD_G, WT + wtoff(WT_G_L + i) + (HG / 4) * kq * HG, HG, n0g, pm);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) frag_store(sPm + (kq * TM + 16 * m) * LD_CF, LD_CF, n0g, pm[m]);
+    if (kq == 0) {
+      f32x4 u[MT];
+      gemm16m<C, MT>(sCg, LD_CF, WT + wtoff(WT_G_FCC + i), HG, n0g, u);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) frag_store(sPf + 16 * m * LD_CF, LD_CF, n0g, u[m]);
+    }
+  };
+  auto geo_finish = [&](int i) {
+    for (int e = t; e < TM * HG; e += WG) {
+      const int sm = e >> 5, c = e & 31;
+      const float z = (sPm[sm * LD_CF + c] + sPm[(TM + sm) * LD_CF + c]) +
+                      (sPm[(2 * TM + sm) * LD_CF + c] + sPm[(3 * TM + sm) * LD_CF + c]);
+      const float y = fmaxf(z + M[MO(PI_G_L + 2 * i + 1) + c], 0.f);
+      const float h = y + (sPf[sm * LD_CF + c] + M[MO(PI_G_FCC + 2 * i + 1) + c]);
+      sXg[sm * LD_G + EGP + c] = h;
+      if (a.ws.g_y && live(sm)) a.ws.g_y[((size_t)i * a.ws.Ppad + p0 + sm) * HG + c] = y;
+    }
+  };
+  if (!color) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      f32x4 y[MT], h[MT];
-      if (wave < 2) {
-        f32x4 acc[MT], u[MT];
-        if (i == 0) gemm16m<EGP, MT>(sXg, LD_G, WT + wtoff(WT_G_L + 0), HG, n0, acc);
-        else if (i == 3) gemm16m<EGP + HG, MT>(sXg, LD_G, WT + wtoff(WT_G_L + 3), HG, n0, acc);
-        else gemm16m<HG, MT>(sXg + EGP, LD_G, WT + wtoff(WT_G_L + i), HG, n0, acc);
-        gemm16m<C, MT>(sCg, LD_CF, WT + wtoff(WT_G_FCC + i), HG, n0, u);
-        float b = M[MO(PI_G_L + 2 * i + 1) + n0 + colw];
-        float bc = M[MO(PI_G_FCC + 2 * i + 1) + n0 + colw];
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            y[m][r] = fmaxf(acc[m][r] + b, 0.f);
-            h[m][r] = y[m][r] + (u[m][r] + bc);
-          }
-      }
+      geo_partial(i);
       lds_barrier();
-      if (wave < 2) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          frag_store(sXg + m * 16 * LD_G + EGP, LD_G, n0, h[m]);
-          if (a.ws.g_y) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int s = 16 * m + g4 + r;
-              if (live(s)) a.ws.g_y[((size_t)i * a.ws.Ppad + p0 + s) * HG + n0 + colw] = y[m][r];
-            }
-          }
-        }
-      }
+      geo_finish(i);
       lds_barrier();
-    }
-    if (t < TM * 8) {  // output_linear 32 -> 1: 8 lanes per sample, 4 inputs each
-      const int sm = t >> 3, part = t & 7;
-      const float* wo = M + MO(PI_G_OUT) + 4 * part;
-      const float* xs = sXg + sm * LD_G + EGP + 4 * part;
-      float o = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o = fmaf(xs[k], wo[k], o);
-      o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
-      if (part == 0) sOcc[sm] = o + M[MO(PI_G_OUT + 1)];
     }
   }
 
   PSL_STAMP(4);
   if (color) {
-    lds_barrier();
     PSL_STAMP(5);
     // -------------------------------------------------------------- phase 5: colour trunk, 8 waves x 16 columns
     {
       const int n0 = 16 * wave, g4 = 4 * (lane >> 4), colw = lane & 15;
+      // MT == 1: the weight fragments of layer i+1 are requested right after the MFMAs of layer i were issued, i.e.
+      // their L2 latency elapses behind the activation, the two barriers and the activation saves (the 32-row tile
+      // has no registers to spare for this).
+      constexpr bool kPrefetch = (MT == 1);
+      float wA[(EC + HC) / 4];
+      if constexpr (kPrefetch) {
+        float (&w0)[EC / 4] = reinterpret_cast<float (&)[EC / 4]>(wA);
+        fetch_b<EC>(WT + wtoff(WT_C_L + 0), HC, n0, w0);
+      }
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         f32x4 acc[MT], u[MT];
-        if (i == 1) PSL_STAMPF(20);
-        if (i == 0) gemm16m<EC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 0), HC, n0, acc);
-        else if (i == 3) gemm16m<EC + HC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 3), HC, n0, acc);
-        else gemm16m<HC, MT>(sXc + EC, LD_C, WT + wtoff(WT_C_L + i), HC, n0, acc);
-        if (i == 1) PSL_STAMPF(21);
-        gemm16m<C, MT>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0, u);
-        if (i == 1) PSL_STAMPF(22);
+        if constexpr (kPrefetch) {
+          if (i == 0) mma16m<EC, MT>(sXc, LD_C, reinterpret_cast<float (&)[EC / 4]>(wA), acc);
+          else if (i == 3) mma16m<EC + HC, MT>(sXc, LD_C, wA, acc);
+          else mma16m<HC, MT>(sXc + EC, LD_C, reinterpret_cast<float (&)[HC / 4]>(wA), acc);
+          gemm16m<C, MT>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0, u);
+          if (i + 1 < 5) {
+            if (i + 1 == 3) fetch_b<EC + HC>(WT + wtoff(WT_C_L + 3), HC, n0, wA);
+            else fetch_b<HC>(WT + wtoff(WT_C_L + i + 1), HC, n0, reinterpret_cast<float (&)[HC / 4]>(wA));
+          }
+        } else {
+          if (i == 0) gemm16m<EC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 0), HC, n0, acc);
+          else if (i == 3) gemm16m<EC + HC, MT>(sXc, LD_C, WT + wtoff(WT_C_L + 3), HC, n0, acc);
+          else gemm16m<HC, MT>(sXc + EC, LD_C, WT + wtoff(WT_C_L + i), HC, n0, acc);
+          gemm16m<C, MT>(sCc, LD_CF, WT + wtoff(WT_C_FCC + i), HC, n0, u);
+        }
+        geo_partial(i);
         float b = M[MO(PI_C_L + 2 * i + 1) + n0 + colw];
         float bc = M[MO(PI_C_FCC + 2 * i + 1) + n0 + colw];
         f32x4 y[MT], h[MT];
@@ -365,9 +407,8 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
             y[m][r] = softplus100(acc[m][r] + b);
             h[m][r] = y[m][r] + (u[m][r] + bc);
           }
-        if (i == 1) PSL_STAMPF(23);
         lds_barrier();
-        if (i == 1) PSL_STAMPF(24);
+        geo_finish(i);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           frag_store(sXc + m * 16 * LD_C + EC, LD_C, n0, h[m]);
@@ -382,11 +423,8 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
             }
           }
         }
-        if (i == 1) PSL_STAMPF(25);
         lds_barrier();
-        if (i == 1) PSL_STAMPF(26);
       }
-      PSL_STAMPF(27);
       for (int e = t; e < TM * 3 * 8; e += WG) {  // output_linear 128 -> 3: 8 lanes per output, 16 inputs each
         const int o3 = e >> 3, part = e & 7;
         const int s = o3 / 3, j = o3 - 3 * s;
@@ -399,6 +437,16 @@ __global__ __launch_bounds__(WG, 4) void k_decode_fwd(DecodeArgs a) {
         if (part == 0) sOut[s * 4 + j] = o + M[MO(PI_C_OUT + 1) + j];
       }
     }
+  }
+  for (int e = t; e < TM * 8; e += WG) {  // geometry output_linear 32 -> 1: 8 lanes per sample, 4 inputs each
+    const int sm = e >> 3, part = e & 7;
+    const float* wo = M + MO(PI_G_OUT) + 4 * part;
+    const float* xs = sXg + sm * LD_G + EGP + 4 * part;
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o = fmaf(xs[k], wo[k], o);
+    o += __shfl_xor(o, 1); o += __shfl_xor(o, 2); o += __shfl_xor(o, 4);
+    if (part == 0) sOcc[sm] = o + M[MO(PI_G_OUT + 1)];
   }
   lds_barrier();
   PSL_STAMP(6);

@@ -104,6 +104,29 @@ __device__ __forceinline__ f32x4 gemm16(const float* Xs, int ldx, const float* _
   return a0 + a1;
 }
 
+// gemm16 in two halves: request the B fragments early (they depend on the weights only), multiply later
+template <int KDIM>
+__device__ __forceinline__ void fetch_b16(const float* __restrict__ W, int ldw, int n0, float (&wv)[KDIM / 4]) {
+  const int lane = threadIdx.x & 63;
+  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
+#pragma unroll
+  for (int ks = 0; ks < KDIM / 4; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
+}
+template <int KDIM>
+__device__ __forceinline__ f32x4 mma16(const float* Xs, int ldx, const float (&wv)[KDIM / 4]) {
+  const int lane = threadIdx.x & 63;
+  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
+  constexpr int NK = KDIM / 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks + 1 < NK; ks += 2) {
+    a0 = mfma16(xp[4 * ks], wv[ks], a0);
+    a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1);
+  }
+  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
+  return a0 + a1;
+}
+
 // store a C/D fragment to a row-major LDS/global tile: dst[row][n0 + col]
 __device__ __forceinline__ void frag_store(float* dst, int ld, int n0, f32x4 v) {
   const int lane = threadIdx.x & 63;

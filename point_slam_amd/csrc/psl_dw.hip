@@ -207,32 +207,53 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
     PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS));
     ctx->dw_slab_cap = MAX_CHUNKS;
   }
-  static int chunk_rows = 0;
-  if (!chunk_rows) { const char* e = getenv("PSL_DW_CHUNK"); chunk_rows = e ? atoi(e) : 256; if (chunk_rows < 16) chunk_rows = 256; }
+  static int chunk_rows = -1;    // > 0: fixed rows per chunk (debug); default: balanced sizing, see finish()
+  if (chunk_rows < 0) { const char* e = getenv("PSL_DW_CHUNK"); chunk_rows = e ? atoi(e) : 0; if (chunk_rows < 16) chunk_rows = 0; }
   DwArgs d;
   DwReduceArgs ra;
   memset(&d, 0, sizeof(d));
   memset(&ra, 0, sizeof(ra));
   for (int j = 0; j < kNumColorParams; ++j) ra.slab_off[j] = slab_off_of(j);
-  int nj = 0, base = 0;
+  int nj = 0;
   // every (chunk, tile) item writes its whole tile, so a slab entry is defined for exactly the chunks of its job:
   // no memset; the reduction reads chunks_of_entry[] slabs per parameter tensor
+  int out_pi_of[MAX_JOBS];
   auto add = [&](const float* A, int lda, int nv, const float* B0, int ldb0, int k0, const float* B1, int ldb1, int k1,
                  long long rows, int out_pi) {
-    DwJob& J = d.job[nj++];
+    DwJob& J = d.job[nj];
+    out_pi_of[nj++] = out_pi;
     J.A = A; J.lda = lda; J.n_valid = nv; J.B0 = B0; J.ldb0 = ldb0; J.k0_cols = k0; J.B1 = B1; J.ldb1 = ldb1;
     J.k1_cols = k1; J.rows = rows; J.out_off = slab_off_of(out_pi); J.ld_out = k0 + k1; J.bias_off = slab_off_of(out_pi + 1);
     // 32-wide vectors where the operand has exactly 32 columns (fc_c: 32 inputs; F_theta linear2: 32 outputs)
     J.aq = (nv == 32) ? 2 : 4; J.bq = (k0 + k1 == 32 && J.aq == 4) ? 2 : 4;
     J.n_tiles = (nv + 16 * J.aq - 1) / (16 * J.aq); J.k_tiles = (k0 + k1 + 16 * J.bq - 1) / (16 * J.bq);
-    J.n_chunks = (int)std::min<long long>(std::max<long long>((rows + chunk_rows - 1) / chunk_rows, 1), MAX_CHUNKS);
-    long long rpc = (rows + J.n_chunks - 1) / J.n_chunks;
-    J.rows_per_chunk = (int)((rpc + 15) / 16 * 16);
-    J.n_chunks = (int)((rows + J.rows_per_chunk - 1) / J.rows_per_chunk);
-    J.items = J.n_tiles * J.k_tiles * J.n_chunks;
-    J.item_base = base; base += J.items;
-    ra.chunks_of_entry[out_pi] = J.n_chunks;
-    ra.chunks_of_entry[out_pi + 1] = J.n_chunks;
+  };
+  // Chunking: one item = one wavefront = one tile x one row chunk, and a wavefront is a serial chain of
+  // rows*aq*bq/4 MFMAs.  Items are sized to EQUAL MFMA cost with about one item per SIMD (1024) in total: a batch of
+  // 5 000 samples then finishes in one balanced round instead of 0.6 or 1.2 waves per SIMD of unequal length.
+  auto finish = [&]() {
+    double total = 0.0;
+    for (int j = 0; j < nj; ++j) {
+      const DwJob& J = d.job[j];
+      total += (double)J.rows * J.n_tiles * J.k_tiles * (J.aq * J.bq) / 4.0;
+    }
+    double per_item = std::max(total / 1000.0, 64.0 * 16 / 4);      // MFMAs per item (>= 64 rows of a full tile)
+    if (chunk_rows > 0) per_item = chunk_rows * 16 / 4.0;           // PSL_DW_CHUNK: rows per chunk of a FULL tile
+    int base = 0;
+    for (int j = 0; j < nj; ++j) {
+      DwJob& J = d.job[j];
+      long long want = (long long)(per_item * 4.0 / (J.aq * J.bq));  // rows per chunk for this job's tile size
+      want = std::max<long long>((want + 15) / 16 * 16, 64);
+      J.n_chunks = (int)std::min<long long>(std::max<long long>((J.rows + want - 1) / want, 1), MAX_CHUNKS);
+      long long rpc = (J.rows + J.n_chunks - 1) / J.n_chunks;
+      J.rows_per_chunk = (int)((rpc + 15) / 16 * 16);
+      J.n_chunks = (int)((J.rows + J.rows_per_chunk - 1) / J.rows_per_chunk);
+      J.items = J.n_tiles * J.k_tiles * J.n_chunks;
+      J.item_base = base; base += J.items;
+      ra.chunks_of_entry[out_pi_of[j]] = J.n_chunks;
+      ra.chunks_of_entry[out_pi_of[j] + 1] = J.n_chunks;
+    }
+    return base;
   };
   const RenderWs& w = a.ws;
   for (int i = 0; i < 5; ++i) {
@@ -249,6 +270,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
     add(w.n_dnf, C, C, w.n_h1, HC, HC, nullptr, 0, 0, P * K, PI_C_N2);
     add(w.n_dz1, HC, HC, w.n_x, NX, NX, nullptr, 0, 0, P * K, PI_C_N1);
   }
+  const int base = finish();
   d.n_jobs = nj; d.n_items = base; d.slabs = ctx->dw_slabs;
   hipLaunchKernelGGL(k_dw, dim3((unsigned)((base + 3) / 4)), dim3(256), 0, s, d);
   PSL_LAUNCH_CHECK();
