@@ -29,7 +29,8 @@ int launch_composite_fwd(const float4* raw, const float* z, const float* gt_dept
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
                          unsigned char* valid, float* cw, float* ray_aux, hipStream_t s);
 int launch_composite_bwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
-                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s);
+                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, float* zero64,
+                         hipStream_t s);
 int launch_ray_grad(const float4* dp, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
                     float* g_d, hipStream_t s);
 
@@ -170,7 +171,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipDeviceSynchronize();
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
-  (void)hipFree(c->wt); (void)hipFree(c->d_counter); (void)hipFree(c->d_small);
+  (void)hipFree(c->wt); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); if (c->loss_acc) (void)hipFree(c->loss_acc);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
@@ -197,6 +198,7 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
   { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P); rc = launch_decode_fwd(d, s); if (rc) return rc; }
+  if (!ctx->fused_ray)     // psl_map_iters composites, takes the loss and back-propagates it in one kernel of its own
   { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
     rc = launch_composite_fwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
                               a->n_rays, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, d.ws.cw,
@@ -208,16 +210,17 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
 int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s) {
   int rc = check_render_args(ctx, a, "psl_render_bwd");
   if (rc) return rc;
-  if (!g || !g->g_depth) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
+  if (!g || (!g->g_depth && !ctx->fused_ray)) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
   if (!(a->flags & (PSL_PTS_GRAD | PSL_PARAM_GRAD | PSL_FEAT_GRAD))) {
     set_error("psl_render_bwd: forward was run without any gradient flag"); return PSL_ERR_STATE;
   }
   if (a->n_rays == 0) return PSL_OK;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
+  if (!ctx->fused_ray)
   { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays);
     rc = launch_composite_bwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
-                              g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, s);
+                              g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, ctx->d_small, s);
     if (rc) return rc; }
   rc = launch_decode_bwd(ctx, d, *g, s);
   if (rc) return rc;

@@ -146,6 +146,8 @@ struct psl_ctx {
   int* d_counter;
   int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
   int* pre_cnt = nullptr;
+  bool fused_ray = false;    // psl_map_iters: compositing fwd/bwd + loss run in its own fused kernel
+  double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   int* scan_flags;       // for add_points compaction
   int scan_flags_cap;
@@ -202,6 +204,10 @@ struct ProfScope {  // brackets a kernel class with HIP events on the launch str
 int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
+int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
+                         float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
+                         float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
+                         float* zero64, hipStream_t s);
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);
 int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);

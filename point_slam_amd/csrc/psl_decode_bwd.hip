@@ -170,11 +170,22 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
     f32x4 dcacc = {0.f, 0.f, 0.f, 0.f};   // waves 0,1: dL/dc_col column slice
     f32x4 dcg = {0.f, 0.f, 0.f, 0.f};     // waves 2,3: dL/dc_geo column slice (fused geometry backward)
     const int n0 = 16 * wave;
+    // saved activations of the layer are requested one layer ahead (they depend on the forward pass only)
+    auto load_y = [&](int i, float (&yv)[4]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int p = p0 + g4 + r;
+        yv[r] = (p < a.P) ? a.ws.c_y[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] : 0.f;
+      }
+    };
+    float ycur[4], ynxt[4];
+    load_y(4, ycur);
 #pragma unroll
     for (int i = 4; i >= 0; --i) {
       // the weight fragments of step C depend on nothing computed here: request them first, so that their L2
       // latency elapses behind step A/B and the barrier
       float wC[HC / 4];
+      if (i > 0) load_y(i - 1, ynxt);
       const float* Wi = M + MO(PI_C_L + 2 * i);
       if (i == 3) fetch_b16<HC>(Wi, EC + HC, EC + n0, wC);
       else if (i > 0) fetch_b16<HC>(Wi, HC, n0, wC);
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int p = p0 + g4 + r;
-        float y = (p < a.P) ? a.ws.c_y[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] : 0.f;
+        float y = ycur[r];
         dz[r] = (p < a.P) ? gv[r] * softplus100_grad_from_out(y) : 0.f;
         if (parg && p < a.P) {
           a.ws.c_dz[((size_t)i * a.ws.Ppad + p) * HC + n0 + colw] = dz[r];
@@ -236,6 +247,8 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
         for (int r = 0; r < 4; ++r) if (n0 + colw < EC) sDEc[(g4 + r) * LD_DEC + n0 + colw] += ge[r];
       }
       lds_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ycur[r] = ynxt[r];
     }
     if (wave < 2) {
 #pragma unroll
@@ -551,8 +564,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   BwdOut o;
   o.g_geo = g.g_geo_feats; o.g_col = g.g_col_feats; o.row_map = g.feat_row_map;
   // small accumulators: [0..31] dB_rel, [32..47] affine  (ctx->d_small)
-  float* small = ctx->d_small;
-  PSL_HIP(hipMemsetAsync(small, 0, sizeof(float) * 64, s));
+  float* small = ctx->d_small;     // cleared by the compositing-backward kernel that always runs just before
   o.g_brel = small;
   o.g_affine = small + 32;
   int tiles = (a.P + TILE - 1) / TILE;

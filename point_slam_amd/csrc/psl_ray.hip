@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float4* __restrict_
 __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict__ raw, const float* __restrict__ z_in,
                                                        const float* __restrict__ gt_depth, float near_s, float far_s, int n_rays, float coef,
                                                        const float* __restrict__ g_depth, const float* __restrict__ g_var,
-                                                       const float* __restrict__ g_rgb, float4* __restrict__ d_raw) {
+                                                       const float* __restrict__ g_rgb, float4* __restrict__ d_raw,
+                                                       float* __restrict__ zero64) {
+  // the decode backward that follows accumulates dB_rel / d(affine) into 64 floats: cleared here, not by a memset
+  if (zero64 && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rays) return;
   float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
@@ -119,6 +122,101 @@ __global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp,
   if (g_d) { g_d[r * 3] = d0; g_d[r * 3 + 1] = d1; g_d[r * 3 + 2] = d2; }
 }
 
+// Mapper iteration, everything between the two decode kernels in ONE launch: compositing (common.py:298-336), the
+// mapper loss with its mask (Mapper.py:524-553: L1 sums, so every ray's cotangent is local) and the compositing
+// backward.  Replaces k_composite_fwd + k_mapper_loss + k_composite_bwd (three ~6 us launches per iteration).
+// loss_acc[0..2] += (sum |d_gt - d|, sum |c_gt - c|, #rays in the mask) in double.
+__global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict__ raw, const int* __restrict__ cnt,
+                                                       const float* __restrict__ gt_depth, const float* __restrict__ gt_color,
+                                                       const int* __restrict__ active, float near_s, float far_s,
+                                                       int min_nn, int n_rays, float coef, float w_color, int color_stage,
+                                                       float* __restrict__ depth, float* __restrict__ var,
+                                                       float* __restrict__ rgb, unsigned char* __restrict__ valid,
+                                                       float4* __restrict__ d_raw, double* __restrict__ loss_acc,
+                                                       float* __restrict__ zero64) {
+  __shared__ double red[3][4];
+  if (zero64 && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  double lg = 0.0, lc = 0.0, lcnt = 0.0;
+  if (r < n_rays) {
+    float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
+    float T = 1.0f, wsum = 0.f;
+    int nhas = 0;
+    const float gt = gt_depth[r];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float4 q = raw[r * S + s];
+      z[s] = sample_z(gt, s, near_s, far_s);
+      al[s] = sigmoidf(coef * q.w);
+      Tt[s] = T;
+      w[s] = al[s] * T;
+      T = T * (1.0f - al[s] + 1e-10f);
+      wsum += w[s];
+      c0[s] = q.x; c1[s] = q.y; c2[s] = q.z;
+      nhas += (cnt[r * S + s] >= min_nn) ? 1 : 0;
+    }
+    const float W = wsum + 1e-10f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { a0 += w[s] * c0[s]; a1 += w[s] * c1[s]; a2 += w[s] * c2[s]; ad += w[s] * z[s]; }
+    const float d = ad / W, m0 = a0 / W, m1 = a1 / W, m2 = a2 / W;
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { float tmp = z[s] - d; v += w[s] * tmp * tmp; }
+    const bool vr = nhas >= (S / 2 + 1);
+    depth[r] = d; var[r] = v; rgb[r * 3] = m0; rgb[r * 3 + 1] = m1; rgb[r * 3 + 2] = m2; valid[r] = vr ? 1 : 0;
+    // loss + cotangents
+    float gd = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
+    if (active[r] && gt > 0.f && vr && d == d) {
+      lg = (double)fabsf(gt - d);
+      gd = (d > gt) ? 1.f : ((d < gt) ? -1.f : 0.f);
+      lcnt = 1.0;
+      if (color_stage) {
+        const float g0 = gt_color[r * 3], g1 = gt_color[r * 3 + 1], g2 = gt_color[r * 3 + 2];
+        lc = (double)fabsf(g0 - m0) + (double)fabsf(g1 - m1) + (double)fabsf(g2 - m2);
+        gr0 = w_color * ((m0 > g0) ? 1.f : ((m0 < g0) ? -1.f : 0.f));
+        gr1 = w_color * ((m1 > g1) ? 1.f : ((m1 < g1) ? -1.f : 0.f));
+        gr2 = w_color * ((m2 > g2) ? 1.f : ((m2 < g2) ? -1.f : 0.f));
+      }
+    }
+    // compositing backward (no variance cotangent in the mapper loss)
+    float gw[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      gw[s] = (gd * (z[s] - d) + gr0 * (c0[s] - m0) + gr1 * (c1[s] - m1) + gr2 * (c2[s] - m2)) / W;
+    float suffix = 0.f;
+#pragma unroll
+    for (int s = S - 1; s >= 0; --s) {
+      float ga = gw[s] * Tt[s] - suffix / (1.0f - al[s] + 1e-10f);
+      float gocc = ga * coef * al[s] * (1.0f - al[s]);
+      float ws = w[s] / W;
+      d_raw[r * S + s] = make_float4(gr0 * ws, gr1 * ws, gr2 * ws, gocc);
+      suffix += gw[s] * w[s];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lg += __shfl_xor(lg, o); lc += __shfl_xor(lc, o); lcnt += __shfl_xor(lcnt, o); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wv] = lg; red[1][wv] = lc; red[2][wv] = lcnt; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (t != 0.0) atomicAdd(&loss_acc[threadIdx.x], t);
+  }
+}
+
+int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
+                         float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
+                         float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
+                         float* zero64, hipStream_t s) {
+  if (n_rays <= 0) return PSL_OK;
+  hipLaunchKernelGGL(k_map_ray_fused, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
+                     near_s, far_s, min_nn, n_rays, coef, w_color, color_stage, depth, var, rgb, valid, d_raw, loss_acc,
+                     zero64);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
 int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
                          unsigned char* valid, float* cw, float* ray_aux, hipStream_t s) {
@@ -130,10 +228,11 @@ int launch_composite_fwd(const float4* raw, const float* z, const float* gt_dept
 }
 
 int launch_composite_bwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
-                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, hipStream_t s) {
+                         const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, float* zero64,
+                         hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
   hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
-                     n_rays, coef, g_depth, g_var, g_rgb, d_raw);
+                     n_rays, coef, g_depth, g_var, g_rgb, d_raw, zero64);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

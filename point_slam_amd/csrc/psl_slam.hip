@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
                                                    const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
                                                    const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
                                                    RayBufs b, int n_batches = 1) {
-  // n_batches > 1: the rays of several mapper iterations at once (kNN prefetch); only o, d, gd, rq are written then
+  // n_batches > 1: the rays of several mapper iterations at once (block prefetch)
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   int n = n_frames * pix_per_frame;
   if (i >= n * n_batches) return;
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
 // against all others held in LDS (n^2/1024 compares per thread, no sort, two barriers); larger batches use a
 // 4-pass byte-wise radix select over the float bit patterns (positive floats order like their bits).
 __global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
+  gd += (size_t)blockIdx.x * n; active += (size_t)blockIdx.x * n;   // one workgroup per ray batch
   __shared__ unsigned keys[4096];
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_min, s_med;
@@ -230,6 +231,17 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
       for (int j = 0; j < 7; ++j) best[j] = cam_tensor[j];
     }
   }
+}
+
+// per-iteration loss record of psl_map_iters from the double accumulators of k_map_ray_fused: (L, L_geo, L_col, #rays)
+__global__ void k_map_loss_finalize(const double* __restrict__ acc, int n_iters, int n_geo_iters, float w_color,
+                                    float* __restrict__ loss_out) {
+  int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n_iters) return;
+  const double Lg = acc[4 * it], Lc = acc[4 * it + 1], cnt = acc[4 * it + 2];
+  const double L = (it > n_geo_iters) ? Lg + (double)w_color * Lc : Lg;
+  loss_out[4 * it] = (float)L; loss_out[4 * it + 1] = (float)Lg; loss_out[4 * it + 2] = (float)Lc;
+  loss_out[4 * it + 3] = (float)cnt;
 }
 
 // Mapper loss + cotangents (Mapper.py:524-553): mask = (gt>0) & valid_ray & ~nan(depth); L1 depth (+ w * L1 colour)
@@ -518,12 +530,12 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
 static int map_knn_block(int n_rays) { return std::max(1, std::min(64, 262144 / std::max(n_rays, 1))); }
 static int64_t map_prefetch_floats(int n_rays) {
   int64_t rays = (int64_t)map_knn_block(n_rays) * n_rays;
-  return rays * 8 + rays * S * (K + 1) + 64;       // o, d, gd, rq | I [.][5][8], cnt [.][5]
+  return rays * S * (K + 1) + 64;                  // I [.][5][8], cnt [.][5]
 }
 
 extern "C" int64_t psl_map_ws_floats(int n_rays, int n_frames) {
   if (n_rays < 0 || n_frames < 0) return PSL_ERR_ARG;
-  return map_prefetch_floats(n_rays) + rays_floats(n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
+  return map_prefetch_floats(n_rays) + rays_floats(map_knn_block(n_rays) * n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
          (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 16 + psl_param_master_floats();
 }
 
@@ -537,22 +549,36 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   if (ctx->index_points != ctx->n_points) { set_error("psl_map_iters: index is stale"); return PSL_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   float* p = m->ws;
-  RayBufs b = carve_rays(p, n);
+  // Block prefetch: the mapper's rays depend on nothing it optimises (fixed poses, pre-drawn pixels), so ray set-up,
+  // the depth-outlier mask and the 8-NN lookups of `kblock` iterations are done by three launches per block
+  // instead of three per iteration; iteration `it` then works on slice it % kblock of these buffers.
+  const int kblock = map_knn_block(n);
+  RayBufs pb = carve_rays(p, kblock * n);
   bool any_rq = false;
   for (int f = 0; f < m->n_frames; ++f) any_rq |= m->frames[f].r_query != nullptr;
-  if (!any_rq) b.rq = nullptr;
-  float* loss_scratch = p; p += 64;
+  if (!any_rq) pb.rq = nullptr;
+  auto slice = [&](int j) {
+    RayBufs b = pb;
+    const size_t o = (size_t)j * n;
+    b.rays_o += 3 * o; b.rays_d += 3 * o; b.dirs += 3 * o; b.gd += o; b.gc += 3 * o; if (b.rq) b.rq += o;
+    b.active += o; b.depth += o; b.var += o; b.rgb += 3 * o; b.valid += o; b.g_depth += o; b.g_rgb += 3 * o;
+    b.g_o += 3 * o; b.g_d += 3 * o;
+    return b;
+  };
+  p += 64;
   FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) * m->n_frames + 3) / 4 + 4;
   float* g_params = p; p += psl_param_master_floats();
-  const int kblock = map_knn_block(n);
-  RayBufs pb{};                                        // prefetch block: rays of `kblock` iterations
-  { const size_t nr = (size_t)kblock * n;
-    auto take = [&](size_t k) { float* r = p; p += (k + 3) / 4 * 4; return r; };
-    pb.rays_o = take(3 * nr); pb.rays_d = take(3 * nr); pb.gd = take(nr); pb.rq = any_rq ? take(nr) : nullptr; }
   int* pre_I = (int*)p; p += (size_t)kblock * n * S * K;
   int* pre_cnt = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; } } pre_guard{ctx};
+  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false; } } pre_guard{ctx};
+  ctx->fused_ray = true;
+  if (ctx->loss_acc_cap < m->n_iters) {
+    if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
+    PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters));
+    ctx->loss_acc_cap = m->n_iters;
+  }
+  PSL_HIP(hipMemsetAsync(ctx->loss_acc, 0, sizeof(double) * 4 * (size_t)m->n_iters, s));
   {
     std::vector<FrameDev> fh(m->n_frames);
     for (int f = 0; f < m->n_frames; ++f) {
@@ -565,12 +591,11 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   psl_render_args ra{};
   memset(&ra, 0, sizeof(ra));
   ra.n_rays = n; ra.sigmoid_coef = m->sigmoid_coef;
-  ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
   ra.geo_feats = m->geo_feats; ra.col_feats = m->col_feats; ra.params = m->params; ra.col_embed_B = m->col_embed_B;
-  ra.ws = rws; ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
+  ra.ws = rws;
   psl_render_grads rg;
   memset(&rg, 0, sizeof(rg));
-  rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_geo_feats = m->g_geo; rg.g_col_feats = m->g_col;
+  rg.g_geo_feats = m->g_geo; rg.g_col_feats = m->g_col;
   rg.feat_row_map = m->row_map; rg.g_params = g_params;
   const int ncol = psl::kColorFloats;
   for (int it = 0; it < m->n_iters; ++it) {
@@ -582,6 +607,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
         hipLaunchKernelGGL(k_ray_setup, dim3((nb * n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W,
                            fdev, m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, pb,
                            nb);
+        hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, s, pb.gd, pb.active, n);
         PSL_LAUNCH_CHECK(); }
       ProfScope ps(ctx, PROF_KNN, s, 108.0 * nb * n * S);
       int rc = knn_rays(ctx, pb.rays_o, pb.rays_d, pb.gd, nullptr, pb.rq, nb * n, pre_I, pre_cnt, s);
@@ -589,11 +615,9 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     }
     ctx->pre_I = pre_I + (size_t)(it % kblock) * n * S * K;
     ctx->pre_cnt = pre_cnt + (size_t)(it % kblock) * n * S;
-    { ProfScope ps(ctx, PROF_MISC, s);
-      hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W, fdev,
-                         m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, b);
-      hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), 0, s, b.gd, b.active, n);
-      PSL_LAUNCH_CHECK(); }
+    const RayBufs b = slice(it % kblock);
+    ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
+    ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
     ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
     ra.fallback_geo = m->fallback + (size_t)it * 64;
     ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
@@ -601,9 +625,15 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     const bool repack = it == 0 || (m->train_decoder && it >= m->n_geo_iters + 2);
     int rc = render_fwd_impl(ctx, &ra, s, repack);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mapper_loss, dim3(1), dim3(1024), 0, s, b, n, m->w_color, color_stage ? 1 : 0,
-                       m->loss_out ? m->loss_out + 4 * (size_t)it : loss_scratch);
-    PSL_LAUNCH_CHECK();
+    { // compositing + mapper loss + compositing backward in one launch
+      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
+      const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
+      rc = launch_map_ray_fused((const float4*)rw.raw, ctx->pre_cnt, b.gd, b.gc, b.active, ctx->cfg.near_end_surface,
+                                ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, n, m->sigmoid_coef, m->w_color,
+                                color_stage ? 1 : 0, b.depth, b.var, b.rgb, b.valid, (float4*)rw.d_raw,
+                                ctx->loss_acc + 4 * (size_t)it, ctx->d_small, s);
+      if (rc) return rc;
+    }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
@@ -628,6 +658,11 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
         if (rc) return rc;
       }
     }
+  }
+  if (m->loss_out) {
+    hipLaunchKernelGGL(k_map_loss_finalize, dim3((m->n_iters + 255) / 256), dim3(256), 0, s, ctx->loss_acc, m->n_iters,
+                       m->n_geo_iters, m->w_color, m->loss_out);
+    PSL_LAUNCH_CHECK();
   }
   return PSL_OK;
 }
