@@ -24,6 +24,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int launch_decode_fwd(const DecodeArgs& a, hipStream_t s);
+int build_wt_index(psl_ctx* ctx, hipStream_t s);
 int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s);
 int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
@@ -159,6 +160,8 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8));
   PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta)));
   PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats));
+  PSL_HIP(hipMalloc(&c->wt_index, sizeof(int) * kColorFloats));
+  { int rc = build_wt_index(c, nullptr); if (rc) return rc; PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4));
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64));
   *out = c;
@@ -171,7 +174,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipDeviceSynchronize();
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
-  (void)hipFree(c->wt); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); if (c->loss_acc) (void)hipFree(c->loss_acc);
+  (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); if (c->loss_acc) (void)hipFree(c->loss_acc);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }

@@ -139,6 +139,7 @@ struct psl_ctx {
   int* bounds;           // 6 ints: ordered-int min/max
   // forward-layout weights (rebuilt per render call from the master blob)
   float* wt;
+  int* wt_index = nullptr;   // [kColorFloats] master element -> forward-layout element (or -1)
   // dW partial slabs
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
@@ -204,6 +205,10 @@ struct ProfScope {  // brackets a kernel class with HIP events on the launch str
 int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
+struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2; };
+struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt; };
+int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
+                    float lr_par, hipStream_t s);
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
                          float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,

@@ -491,6 +491,29 @@ __global__ __launch_bounds__(256) void k_repack(const float* __restrict__ master
   wt[e] = v;
 }
 
+// inverse of k_repack for the colour decoder: wt_index[master element] = forward-layout element
+__global__ __launch_bounds__(256) void k_wt_index(int* __restrict__ wt_index) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= wtoff(WT_G_FCC)) return;          // colour entries come first in kWt
+  int li = 0;
+#pragma unroll
+  for (int j = 1; j < kNumWt; ++j) if (e >= wtoff(j)) li = j;
+  const WtDesc d = kWt[li];
+  int loc = e - wtoff(li);
+  int kp = loc / d.N, n = loc - kp * d.N;
+  int k = -1;
+  if (kp < d.split) k = kp;
+  else if (kp >= d.split + d.gap) k = kp - d.gap;
+  if (k >= 0 && k < d.Kin) wt_index[poff(d.pi) + n * d.Kin + k] = e;
+}
+
+int build_wt_index(psl_ctx* ctx, hipStream_t s) {
+  PSL_HIP(hipMemsetAsync(ctx->wt_index, 0xFF, sizeof(int) * kColorFloats, s));     // -1
+  hipLaunchKernelGGL(k_wt_index, dim3((wtoff(WT_G_FCC) + 255) / 256), dim3(256), 0, s, ctx->wt_index);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
 int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s) {
   hipLaunchKernelGGL(k_repack, dim3((kWtFloats + 255) / 256), dim3(256), 0, s, master, ctx->wt);
   PSL_LAUNCH_CHECK();

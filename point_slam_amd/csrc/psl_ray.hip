@@ -294,6 +294,39 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
   }
 }
 
+// One launch for all Adam groups of a mapper iteration (Mapper.py:394-402,556): geometry feature rows, colour
+// feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the
+// forward-layout copy of each weight it steps (wt_index: master element -> element of the [Kpad][N] copy, -1 for
+// biases / B matrices), which replaces the separate re-pack launch before the next forward.
+__global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_geo, int nb_col,
+                                                  float b1, float b2, float eps) {
+  int blk = blockIdx.x;
+  if (blk < nb_geo + nb_col) {
+    const AdamRowsSeg& sg = (blk < nb_geo) ? geo : col;
+    if (blk >= nb_geo) blk -= nb_geo;
+    const long long i = (long long)blk * blockDim.x + threadIdx.x;
+    if (i >= (long long)sg.n_rows * (C / 4)) return;
+    const int row = (int)(i >> 3), q = (int)(i & 7);
+    const int dst = sg.rows ? sg.rows[row] : row;
+    float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
+    float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];
+    adam_update(pp.x, gg.x, mm.x, vv.x, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.y, gg.y, mm.y, vv.y, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.z, gg.z, mm.z, vv.z, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.w, gg.w, mm.w, vv.w, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
+    sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const int i = (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x;
+    if (i >= par.n) return;
+    float pp = par.p[i], mm = par.m[i], vv = par.v[i];
+    adam_update(pp, par.g[i], mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
+    par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
+    const int w = par.wt_index[i];
+    if (w >= 0) par.wt[w] = pp;
+  }
+}
+
 }  // namespace psl
 
 using namespace psl;
@@ -311,6 +344,23 @@ static void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, f
   lr_bc1 = (float)((double)lr / bc1);
   sqrt_bc2 = (float)sqrt(bc2);
 }
+
+namespace psl {
+int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
+                    float lr_par, hipStream_t s) {
+  adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
+  if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
+  if (par.n > 0) adam_consts(step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
+  const int nb_geo = (int)(((long long)geo.n_rows * (C / 4) + 255) / 256);
+  const int nb_col = (int)(((long long)col.n_rows * (C / 4) + 255) / 256);
+  const int nb_par = (par.n + 255) / 256;
+  if (nb_geo + nb_col + nb_par == 0) return PSL_OK;
+  hipLaunchKernelGGL(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
+                     0.999f, 1e-8f);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+}  // namespace psl
 
 extern "C" int psl_adam_step(float* p, float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
                              float beta2, float eps, int zero_grad, void* stream) {

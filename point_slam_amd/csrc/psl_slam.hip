@@ -622,7 +622,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     ra.fallback_geo = m->fallback + (size_t)it * 64;
     ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
     // the forward weights only change after the decoder was stepped (colour stage with train_decoder)
-    const bool repack = it == 0 || (m->train_decoder && it >= m->n_geo_iters + 2);
+    const bool repack = it == 0;   // afterwards the fused Adam kernel keeps the forward-layout copy in step
     int rc = render_fwd_impl(ctx, &ra, s, repack);
     if (rc) return rc;
     { // compositing + mapper loss + compositing backward in one launch
@@ -643,20 +643,23 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // SURVEY.md §8d) over every selected row
     ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((double)m->n_sel * C * (color_stage ? 2 : 1) +
                                              ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
-    rc = psl_adam_step_rows((float*)m->geo_feats, m->sel_rows, m->g_geo, m->adam_geo,
-                            m->adam_geo + (size_t)m->n_sel * C, m->n_sel, m->step0_geo + it + 1, lr_geo, 0.9f, 0.999f,
-                            1e-8f, 1, s);
-    if (rc) return rc;
-    if (color_stage) {
-      const int st = m->step0_col + (it - m->n_geo_iters);
-      rc = psl_adam_step_rows((float*)m->col_feats, m->sel_rows, m->g_col, m->adam_col,
-                              m->adam_col + (size_t)m->n_sel * C, m->n_sel, st, m->lr_col, 0.9f, 0.999f, 1e-8f, 1, s);
-      if (rc) return rc;
-      if (m->train_decoder) {
-        rc = psl_adam_step((float*)m->params, g_params, m->adam_params, m->adam_params + ncol, ncol, st, m->lr_decoder,
-                           0.9f, 0.999f, 1e-8f, 0, s);
-        if (rc) return rc;
+    {
+      AdamRowsSeg sg{}, sc{};
+      AdamParSeg sp{};
+      sg.feats = (float*)m->geo_feats; sg.rows = m->sel_rows; sg.g = (float4*)m->g_geo; sg.m = (float4*)m->adam_geo;
+      sg.v = (float4*)(m->adam_geo + (size_t)m->n_sel * C); sg.n_rows = m->n_sel;
+      int st = 1;
+      if (color_stage) {
+        st = m->step0_col + (it - m->n_geo_iters);
+        sc.feats = (float*)m->col_feats; sc.rows = m->sel_rows; sc.g = (float4*)m->g_col; sc.m = (float4*)m->adam_col;
+        sc.v = (float4*)(m->adam_col + (size_t)m->n_sel * C); sc.n_rows = m->n_sel;
+        if (m->train_decoder) {
+          sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
+          sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
+        }
       }
+      rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s);
+      if (rc) return rc;
     }
   }
   if (m->loss_out) {
