@@ -211,6 +211,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if os.environ.get("PSL_POISON") == "1":
+        # debug: leave 0x7F7F7F7F in the caching allocator's blocks so that a read of an uninitialised torch.empty
+        # buffer shows up deterministically (the library poisons its own allocations under the same variable)
+        junk = [torch.full((256 << 20,), 0x7F7F7F7F, dtype=torch.int32, device=dev) for _ in range(6)]
+        torch.cuda.synchronize()
+        del junk
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -16,6 +16,12 @@ bool debug_sync() {
   return v == 1;
 }
 
+void poison(void* p, size_t bytes) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PSL_POISON"); v = (e && e[0] == '1') ? 1 : 0; }
+  if (v == 1 && p) { (void)hipMemset(p, 0x7F, bytes); (void)hipDeviceSynchronize(); }
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -151,19 +157,19 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   c->cfg = *cfg;
   c->index_points = -1;
   size_t np = (size_t)cfg->max_points;
-  PSL_HIP(hipMalloc(&c->pos, sizeof(float4) * np));
-  PSL_HIP(hipMalloc(&c->spos, sizeof(float4) * np));
-  PSL_HIP(hipMalloc(&c->cell_of, sizeof(int) * np));
-  PSL_HIP(hipMalloc(&c->cell_start, sizeof(int) * (kMaxCells + 1)));
-  PSL_HIP(hipMalloc(&c->cell_fill, sizeof(int) * kMaxCells));
-  PSL_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * 4096));
-  PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8));
-  PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta)));
-  PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats));
-  PSL_HIP(hipMalloc(&c->wt_index, sizeof(int) * kColorFloats));
+  PSL_HIP(hipMalloc(&c->pos, sizeof(float4) * np)); psl::poison(c->pos, sizeof(float4) * np);
+  PSL_HIP(hipMalloc(&c->spos, sizeof(float4) * np)); psl::poison(c->spos, sizeof(float4) * np);
+  PSL_HIP(hipMalloc(&c->cell_of, sizeof(int) * np)); psl::poison(c->cell_of, sizeof(int) * np);
+  PSL_HIP(hipMalloc(&c->cell_start, sizeof(int) * (kMaxCells + 1))); psl::poison(c->cell_start, sizeof(int) * (kMaxCells + 1));
+  PSL_HIP(hipMalloc(&c->cell_fill, sizeof(int) * kMaxCells)); psl::poison(c->cell_fill, sizeof(int) * kMaxCells);
+  PSL_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * 4096)); psl::poison(c->scan_tmp, sizeof(int) * 4096);
+  PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8)); psl::poison(c->bounds, sizeof(int) * 8);
+  PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta))); psl::poison(c->meta, sizeof(GridMeta));
+  PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats)); psl::poison(c->wt, sizeof(float) * kWtFloats);
+  PSL_HIP(hipMalloc(&c->wt_index, sizeof(int) * kColorFloats)); psl::poison(c->wt_index, sizeof(int) * kColorFloats);
   { int rc = build_wt_index(c, nullptr); if (rc) return rc; PSL_HIP(hipStreamSynchronize(nullptr)); }
-  PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4));
-  PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64));
+  PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
+  PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   *out = c;
   return PSL_OK;
 }

@@ -1,6 +1,7 @@
 // Internal definitions shared by the HIP translation units of libpointslam_hip.so.
 // gfx950 only: 64-wide wavefronts, f32 MFMA 16x16x4, 160 KiB LDS per CU.
 #pragma once
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/pointslam_hip.h"
@@ -173,11 +174,15 @@ void set_error(const char* fmt, ...);
     }                                                                                  \
   } while (0)
 
+void poison(void* p, size_t bytes);   // PSL_POISON=1: fill fresh allocations with 0x7F (uninitialised-read hunts)
 bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every launch and report the failing one
 #define PSL_LAUNCH_CHECK()                                                             \
   do {                                                                                 \
     hipError_t e__ = hipGetLastError();                                                \
-    if (e__ == hipSuccess && psl::debug_sync()) e__ = hipDeviceSynchronize();          \
+    if (e__ == hipSuccess && psl::debug_sync()) {                                      \
+      fprintf(stderr, "[psl sync] %s:%d\n", __FILE__, __LINE__);                       \
+      e__ = hipDeviceSynchronize();                                                    \
+    }                                                                                  \
     if (e__ != hipSuccess) {                                                           \
       psl::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
       return PSL_ERR_HIP;                                                              \

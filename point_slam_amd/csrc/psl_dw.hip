@@ -204,7 +204,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   const long long P = a.P;
   if (ctx->dw_slab_cap < MAX_CHUNKS) {
     if (ctx->dw_slabs) PSL_HIP(hipFree(ctx->dw_slabs));
-    PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS));
+    PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS)); psl::poison(ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS);
     ctx->dw_slab_cap = MAX_CHUNKS;
   }
   static int chunk_rows = -1;    // > 0: fixed rows per chunk (debug); default: balanced sizing, see finish()

@@ -563,7 +563,7 @@ extern "C" int psl_add_points_sync(psl_ctx* ctx, const float* rays_o, const floa
   }
   if (ctx->scan_flags_cap < 4 * n) {
     if (ctx->scan_flags) (void)hipFree(ctx->scan_flags);
-    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * 4 * (size_t)n));
+    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * 4 * (size_t)n)); psl::poison(ctx->scan_flags, sizeof(int) * 4 * (size_t)n);
     ctx->scan_flags_cap = 4 * n;
   }
   float* qsurf = (float*)ctx->scan_flags;            // [n][3]

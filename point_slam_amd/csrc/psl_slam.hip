@@ -84,6 +84,11 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
   b.gd[i] = act ? dep : 1.0f;                // inactive slots get a harmless finite depth
 }
 
+__global__ void k_track_init(FrameDev* fdev, FrameDev fh, float* best) {
+  if (threadIdx.x == 0) *fdev = fh;
+  if (threadIdx.x < 8) best[threadIdx.x] = (threadIdx.x == 7) ? 1e20f : 0.f;
+}
+
 // inside_mask = d <= min(10*median(d), 1.2*max(d)) over the ACTIVE rays; torch.median = lower median
 // (Tracker.py:142-144, Mapper.py:507-509).  One workgroup.  n <= 4096: every thread ranks its own element
 // against all others held in LDS (n^2/1024 compares per thread, no sort, two barriers); larger batches use a
@@ -488,12 +493,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   FrameDev fh;
   memset(&fh, 0, sizeof(fh));
   fh.depth = t->frame.depth; fh.color = t->frame.color; fh.r_query = t->frame.r_query;
-  PSL_HIP(hipMemcpyAsync(fdev, &fh, sizeof(fh), hipMemcpyHostToDevice, s));
-  // best[0..6] pose, best[7] loss = +big
-  {
-    float init[8] = {0, 0, 0, 0, 0, 0, 0, 1e20f};
-    PSL_HIP(hipMemcpyAsync(t->best_out, init, sizeof(init), hipMemcpyHostToDevice, s));
-  }
+  // The frame descriptor and best[0..6] = pose, best[7] = loss = +big go to the device as KERNEL ARGUMENTS (captured
+  // at launch).  An asynchronous copy from these stack variables is read by the runtime whenever the stream gets
+  // to it -- after this function has returned when the host runs ahead of the GPU (no sync between tracked frames).
+  hipLaunchKernelGGL(k_track_init, dim3(1), dim3(64), 0, s, fdev, fh, t->best_out);
+  PSL_LAUNCH_CHECK();
   psl_render_args ra{};
   memset(&ra, 0, sizeof(ra));
   ra.n_rays = n; ra.flags = PSL_STAGE_COLOR | PSL_PTS_GRAD; ra.sigmoid_coef = t->sigmoid_coef;
@@ -575,7 +579,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   ctx->fused_ray = true;
   if (ctx->loss_acc_cap < m->n_iters) {
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
-    PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters));
+    PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters)); psl::poison(ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
     ctx->loss_acc_cap = m->n_iters;
   }
   PSL_HIP(hipMemsetAsync(ctx->loss_acc, 0, sizeof(double) * 4 * (size_t)m->n_iters, s));
@@ -699,7 +703,7 @@ extern "C" int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host /*[16
   const int nblk = (n + 1023) / 1024;
   if (ctx->scan_flags_cap < nblk + 64) {
     if (ctx->scan_flags) (void)hipFree(ctx->scan_flags);
-    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * (size_t)(nblk + 64) * 4));
+    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * (size_t)(nblk + 64) * 4)); psl::poison(ctx->scan_flags, sizeof(int) * (size_t)(nblk + 64) * 4);
     ctx->scan_flags_cap = (nblk + 64) * 4;
   }
   float* w2c_dev = ctx->d_small;   // 12 floats
