@@ -16,6 +16,9 @@ class PslError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2     # include/pointslam_hip.h: psl_abi_version(); v2 added psl_render_args.z_vals
+
+
 class psl_config(C.Structure):
     _fields_ = [("n_surface", C.c_int32), ("nn_num", C.c_int32), ("c_dim", C.c_int32), ("min_nn_num", C.c_int32),
                 ("near_end_surface", C.c_float), ("far_end_surface", C.c_float), ("radius_query", C.c_float),

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding declares a signature for each of them
     unbound = [n for n in names if n not in _lib.EXPORTED_SYMBOLS]
     assert not unbound, unbound
-    assert _lib.lib().psl_abi_version() == 2
+    assert _lib.lib().psl_abi_version() == _lib.ABI_VERSION
 
 
 def test_param_table_matches_reference_state_dict():
