@@ -264,6 +264,31 @@ int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream);
 int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host, psl_cam_intr cam, const float* depth, float depth_max,
                             float edge, int32_t* sel_out, int32_t* row_map_out, int* n_sel_host, void* stream);
 
+/* ---- per-frame image operators in front of the path ------------------------------------------
+ * Dynamic radii (src/Tracker.py:235-250, src/Mapper.py:686-701): rgb2gray (0.2125, 0.7154, 0.0721), Sobel
+ * [1,0,-1] x [1,2,1]/4 with scipy 'reflect' borders, magnitude, clip to [0, color_grad_threshold], piecewise-linear
+ * map with knots [0, 0.01, threshold] -> radius_add_max .. radius_add_min (and ratio * that for the query radius).
+ * float64 arithmetic as in numpy; grad_mag_out [H][W] f64 (or NULL), r_add_out / r_query_out [H][W] f32 (or NULL). */
+int psl_frame_radii(const float* color, int32_t H, int32_t W, float color_grad_threshold, float radius_add_max,
+                    float radius_add_min, float radius_query_ratio, double* grad_mag_out, float* r_add_out,
+                    float* r_query_out, void* stream);
+
+/* get_selected_index_with_grad (src/common.py:116-159): the k = ratio*n pixels with the largest gradient magnitude
+ * over the WHOLE image (np.argpartition; which of several equal values at the threshold are taken is open there and
+ * here), then masked by the region [H0,H1) x [W0,W1) and by depth > 0 (and <= depth_limit if > 0; depth may be NULL).
+ * sel_out [<= k] flat pixel indices in arbitrary order; synchronises and returns the count. */
+int psl_topgrad_select_sync(psl_ctx* ctx, const double* grad_mag, const float* depth, int32_t H, int32_t W, int32_t k,
+                            int32_t H0, int32_t H1, int32_t W0, int32_t W1, float depth_limit, int32_t* sel_out,
+                            int* n_sel_host, void* stream);
+
+/* keyframe_selection_overlap (src/Mapper.py:170-235), the geometric part: for every keyframe pose the share of the
+ * n_rays * n_samples frustum points (z from 0.8*depth to depth+0.5) of the current view that project inside its image
+ * with an `edge`-pixel border and lie in front of it.  c2w_host: n_kf row-major 4x4 poses (host); percent_host [n_kf].
+ * Sorting / thresholding / the random pick of k keyframes stay with the caller (host RNG). Synchronises. */
+int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_d, const float* depth, int32_t n_rays,
+                              int32_t n_samples, const float* c2w_host, int32_t n_kf, psl_cam_intr cam, float edge,
+                              float* percent_host, void* stream);
+
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);
 /* Kernel-class timing with HIP events recorded on the launch stream (for bench.py's roofline):

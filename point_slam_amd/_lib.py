@@ -94,6 +94,12 @@ _SIGS = {
     "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p]),
+    "psl_frame_radii": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psl_topgrad_select_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
+    "psl_keyframe_overlap_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                            C.c_int, psl_cam_intr, C.c_float, C.POINTER(C.c_float), C.c_void_p]),
     "psl_near_pcl_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_float, C.c_void_p, C.c_void_p]),   # ctx o d n z_steps step_row n_steps r hits stream
     "psl_add_points_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,

@@ -148,6 +148,7 @@ struct psl_ctx {
   int* d_counter;
   int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
   int* pre_cnt = nullptr;
+  unsigned* img_hist = nullptr;   // 65536-bin histogram + select state of psl_topgrad_select_sync
   bool fused_ray = false;    // psl_map_iters: compositing fwd/bwd + loss run in its own fused kernel
   double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators

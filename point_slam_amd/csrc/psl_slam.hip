@@ -249,39 +249,6 @@ __global__ void k_map_loss_finalize(const double* __restrict__ acc, int n_iters,
   loss_out[4 * it + 3] = (float)cnt;
 }
 
-// Mapper loss + cotangents (Mapper.py:524-553): mask = (gt>0) & valid_ray & ~nan(depth); L1 depth (+ w * L1 colour)
-__global__ __launch_bounds__(1024) void k_mapper_loss(RayBufs b, int n, float w_color, int color_stage, float* loss_out) {
-  __shared__ double lds[16];
-  double lg = 0.0, lc = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (b.active[i]) {
-      float d = b.depth[i], gt = b.gd[i];
-      bool m = (gt > 0.f) && b.valid[i] && (d == d);
-      if (m) {
-        lg += (double)fabsf(gt - d);
-        gdp = signf0(d - gt);
-        c += 1.0;
-        if (color_stage) {
-          float r0 = b.rgb[i * 3], r1 = b.rgb[i * 3 + 1], r2 = b.rgb[i * 3 + 2];
-          float c0 = b.gc[i * 3], c1 = b.gc[i * 3 + 1], c2 = b.gc[i * 3 + 2];
-          lc += (double)fabsf(c0 - r0) + (double)fabsf(c1 - r1) + (double)fabsf(c2 - r2);
-          g0 = w_color * signf0(r0 - c0); g1 = w_color * signf0(r1 - c1); g2 = w_color * signf0(r2 - c2);
-        }
-      }
-    }
-    b.g_depth[i] = gdp;
-    b.g_rgb[i * 3] = g0; b.g_rgb[i * 3 + 1] = g1; b.g_rgb[i * 3 + 2] = g2;
-  }
-  double Lg = block_sum_d(lg, lds);
-  double Lc = block_sum_d(lc, lds);
-  double cnt = block_sum_d(c, lds);
-  if (threadIdx.x == 0) {
-    loss_out[0] = (float)(color_stage ? Lg + (double)w_color * Lc : Lg);
-    loss_out[1] = (float)Lg; loss_out[2] = (float)Lc; loss_out[3] = (float)cnt;
-  }
-}
-
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, int step) {
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   m = m + (1.0f - b1) * (g - m);
