@@ -84,6 +84,10 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
     import torch
     from point_slam_amd import host_ops as H
     fr = frames[i]
+    if cfg["use_dynamic_radius"]:
+        # the per-frame radius maps are part of the reference's frame loop (Tracker.py:235-250): one kernel here
+        from point_slam_amd import frame_ops
+        fr.r_add, fr.r_query = frame_ops.dynamic_radius_maps(fr.color, cfg)
     best = slam.track(fr, cams0[i])
     if i % every == 0:
         c2w34 = H.get_camera_from_tensor(best)
