@@ -281,6 +281,13 @@ int psl_topgrad_select_sync(psl_ctx* ctx, const double* grad_mag, const float* d
                             int32_t H0, int32_t H1, int32_t W0, int32_t W1, float depth_limit, int32_t* sel_out,
                             int* n_sel_host, void* stream);
 
+/* End-of-run image metrics of one rendered frame (src/Mapper.py:861-879): out3 = { PSNR over the pixels with sensor
+ * depth, MS-SSIM (pytorch_msssim 0.2.x: data_range 1, 11-tap Gaussian sigma 1.5, 5 scales), mean depth L1 over the
+ * pixels with sensor depth }.  Images [H][W][3] / [H][W] f32 on the device; min(H, W) > 160.  Synchronises.
+ * (LPIPS needs a pretrained AlexNet and is out of scope.) */
+int psl_image_metrics_sync(const float* gt_color, const float* gt_depth, const float* color, const float* depth,
+                           int32_t H, int32_t W, double* out3_host, void* stream);
+
 /* keyframe_selection_overlap (src/Mapper.py:170-235), the geometric part: for every keyframe pose the share of the
  * n_rays * n_samples frustum points (z from 0.8*depth to depth+0.5) of the current view that project inside its image
  * with an `edge`-pixel border and lie in front of it.  c2w_host: n_kf row-major 4x4 poses (host); percent_host [n_kf].

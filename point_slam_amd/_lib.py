@@ -100,6 +100,8 @@ _SIGS = {
                                           C.c_int, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "psl_keyframe_overlap_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                             C.c_int, psl_cam_intr, C.c_float, C.POINTER(C.c_float), C.c_void_p]),
+    "psl_image_metrics_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double), C.c_void_p]),
     "psl_near_pcl_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_float, C.c_void_p, C.c_void_p]),   # ctx o d n z_steps step_row n_steps r hits stream
     "psl_add_points_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,

@@ -6,6 +6,8 @@
 //     (get_selected_index_with_grad, src/common.py:116-159);
 //   * overlap of the current view with every keyframe (keyframe_selection_overlap, src/Mapper.py:170-235).
 // All arithmetic that the reference does in float64 (numpy) is done in float64 here; the radii leave as float32.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include "psl_common.h"
@@ -152,6 +154,115 @@ __global__ __launch_bounds__(256) void k_keyframe_overlap(const float* __restric
   if (threadIdx.x == 0) percent[blockIdx.x] = total > 0 ? (float)((double)(cnt[0] + cnt[1] + cnt[2] + cnt[3]) / (double)total) : 0.f;
 }
 
+
+// ---- end-of-run image metrics (src/Mapper.py:861-879): PSNR and depth L1 over the pixels with sensor depth, and
+// MS-SSIM as pytorch_msssim 0.2.x computes it (11-tap Gaussian sigma 1.5, 'valid' separable filtering, 5 scales,
+// 2x2 average pooling with padding = size % 2).  float32 maps like the reference, float64 reductions.
+struct GaussWin { float w[11]; };
+
+__global__ __launch_bounds__(256) void k_metric_sums(const float* __restrict__ gt_color, const float* __restrict__ gt_depth,
+                                                     const float* __restrict__ color, const float* __restrict__ depth,
+                                                     int n, double* __restrict__ acc /*[3]: sq, count, |dd|*/) {
+  __shared__ double red[3][4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0, cnt = 0.0, ad = 0.0;
+  if (i < n && gt_depth[i] > 0.f) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { double d = (double)gt_color[i * 3 + c] - (double)color[i * 3 + c]; sq += d * d; }
+    cnt = 1.0;
+    ad = fabs((double)gt_depth[i] - (double)depth[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sq += __shfl_xor(sq, o); cnt += __shfl_xor(cnt, o); ad += __shfl_xor(ad, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = cnt; red[2][threadIdx.x >> 6] = ad; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (t != 0.0) atomicAdd(&acc[threadIdx.x], t);
+  }
+}
+
+// [H][W][3] interleaved -> planar [3][H][W] for both images
+__global__ __launch_bounds__(256) void k_planar(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                float* __restrict__ X, float* __restrict__ Y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { X[(size_t)c * n + i] = a[i * 3 + c]; Y[(size_t)c * n + i] = b[i * 3 + c]; }
+}
+
+// horizontal 11-tap pass of X, Y, XX, YY, XY: out [5][3][h][w-10]
+__global__ __launch_bounds__(256) void k_ssim_rows(const float* __restrict__ X, const float* __restrict__ Y, int h, int w,
+                                                   GaussWin g, float* __restrict__ out) {
+  const int wo = w - 10;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3LL * h * wo) return;
+  const int x = (int)(i % wo);
+  const long long cy = i / wo;                       // c * h + y
+  const float* xr = X + cy * w + x;
+  const float* yr = Y + cy * w + x;
+  float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float xv = xr[k], yv = yr[k], wk = g.w[k];
+    a += wk * xv; b += wk * yv; aa += wk * (xv * xv); bb += wk * (yv * yv); ab += wk * (xv * yv);
+  }
+  const size_t plane = (size_t)3 * h * wo;
+  out[i] = a; out[plane + i] = b; out[2 * plane + i] = aa; out[3 * plane + i] = bb; out[4 * plane + i] = ab;
+}
+
+// vertical pass + SSIM / contrast-structure maps + sums per channel: acc[c][0] += ssim, acc[c][1] += cs
+__global__ __launch_bounds__(256) void k_ssim_cols(const float* __restrict__ t, int h, int wo, GaussWin g, float C1, float C2,
+                                                   double* __restrict__ acc) {
+  __shared__ double red[2][4];
+  const int ho = h - 10;
+  const int c = blockIdx.y;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  double s_ssim = 0.0, s_cs = 0.0;
+  if (i < (long long)ho * wo) {
+    const int x = (int)(i % wo), y = (int)(i / wo);
+    const size_t plane = (size_t)3 * h * wo;
+    const float* p = t + ((size_t)c * h + y) * wo + x;
+    float m[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) v += g.w[k] * p[q * plane + (size_t)k * wo];
+      m[q] = v;
+    }
+    const float mu1 = m[0], mu2 = m[1];
+    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = m[2] - mu1_sq, s2 = m[3] - mu2_sq, s12 = m[4] - mu12;
+    const float cs = (2.f * s12 + C2) / (s1 + s2 + C2);
+    const float ss = ((2.f * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs;
+    s_ssim = (double)ss; s_cs = (double)cs;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s_ssim += __shfl_xor(s_ssim, o); s_cs += __shfl_xor(s_cs, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_ssim; red[1][threadIdx.x >> 6] = s_cs; }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(&acc[c * 2 + threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// F.avg_pool2d(kernel 2, padding = size % 2, zeros counted) on a planar [3][h][w] image
+__global__ __launch_bounds__(256) void k_pool2(const float* __restrict__ in, int h, int w, float* __restrict__ out, int h2,
+                                               int w2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3LL * h2 * w2) return;
+  const int x = (int)(i % w2), y = (int)((i / w2) % h2), c = (int)(i / ((long long)w2 * h2));
+  const int y0 = 2 * y - (h & 1), x0 = 2 * x - (w & 1);
+  float s = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int yy = y0 + dy, xx = x0 + dx;
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) s += in[((size_t)c * h + yy) * w + xx];
+    }
+  out[i] = s * 0.25f;
+}
+
 }  // namespace psl
 
 using namespace psl;
@@ -238,5 +349,70 @@ extern "C" int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_
   if (e == hipSuccess) e = hipMemcpy(percent_host, dpct, sizeof(float) * n_kf, hipMemcpyDeviceToHost);
   (void)hipFree(dev);
   if (e != hipSuccess) { set_error("psl_keyframe_overlap_sync: %s", hipGetErrorString(e)); return PSL_ERR_HIP; }
+  return PSL_OK;
+}
+
+extern "C" int psl_image_metrics_sync(const float* gt_color, const float* gt_depth, const float* color, const float* depth,
+                                      int32_t H, int32_t W, double* out3_host /*psnr, ms_ssim, depth_l1*/, void* stream) {
+  if (!gt_color || !gt_depth || !color || !depth || !out3_host || H <= 0 || W <= 0) { set_error("psl_image_metrics_sync: bad argument"); return PSL_ERR_ARG; }
+  if (std::min(H, W) <= 160) { set_error("psl_image_metrics_sync: MS-SSIM needs min(H, W) > 160 (5 scales, 11-tap window)"); return PSL_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = H * W;
+  // scratch: two planar pyramids (ping-pong per level), the 5 row-filtered maps, 3 + 5*3*2 double accumulators
+  float* buf = nullptr;
+  const size_t plane3 = (size_t)3 * n;
+  const size_t floats = (4 * plane3 + 5 * plane3 + 3) / 4 * 4;     // the double accumulators behind stay 16-B aligned
+  PSL_HIP(hipMalloc(&buf, sizeof(float) * floats + sizeof(double) * 40));
+  float *X = buf, *Y = buf + plane3, *X2 = buf + 2 * plane3, *Y2 = buf + 3 * plane3, *T = buf + 4 * plane3;
+  double* acc = (double*)(buf + floats);
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * 40, s);
+  GaussWin g;
+  { // _fspecial_gauss_1d(11, 1.5) in float32 like torch
+    float sum = 0.f;
+    for (int k = 0; k < 11; ++k) { float c = (float)(k - 5); g.w[k] = expf(-(c * c) / (2.0f * 1.5f * 1.5f)); sum += g.w[k]; }
+    for (int k = 0; k < 11; ++k) g.w[k] /= sum;
+  }
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  hipLaunchKernelGGL(k_metric_sums, dim3((n + 255) / 256), dim3(256), 0, s, gt_color, gt_depth, color, depth, n, acc);
+  hipLaunchKernelGGL(k_planar, dim3((n + 255) / 256), dim3(256), 0, s, gt_color, color, n, X, Y);
+  int h = H, w = W;
+  long long counts[5];
+  for (int l = 0; l < 5; ++l) {
+    const int wo = w - 10, ho = h - 10;
+    counts[l] = (long long)wo * ho;
+    hipLaunchKernelGGL(k_ssim_rows, dim3((unsigned)((3LL * h * wo + 255) / 256)), dim3(256), 0, s, X, Y, h, w, g, T);
+    hipLaunchKernelGGL(k_ssim_cols, dim3((unsigned)(((long long)ho * wo + 255) / 256), 3), dim3(256), 0, s, T, h, wo, g, C1, C2,
+                       acc + 3 + l * 6);
+    if (l < 4) {
+      const int h2 = (h + 1) / 2, w2 = (w + 1) / 2;
+      hipLaunchKernelGGL(k_pool2, dim3((unsigned)((3LL * h2 * w2 + 255) / 256)), dim3(256), 0, s, X, h, w, X2, h2, w2);
+      hipLaunchKernelGGL(k_pool2, dim3((unsigned)((3LL * h2 * w2 + 255) / 256)), dim3(256), 0, s, Y, h, w, Y2, h2, w2);
+      std::swap(X, X2); std::swap(Y, Y2);
+      h = h2; w = w2;
+    }
+  }
+  double host[40];
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(buf);
+  if (e != hipSuccess) { set_error("psl_image_metrics_sync: %s", hipGetErrorString(e)); return PSL_ERR_HIP; }
+  const double cnt = host[1];
+  out3_host[0] = cnt > 0 ? -10.0 * log10(host[0] / (3.0 * cnt)) : 0.0;
+  out3_host[2] = cnt > 0 ? host[2] / cnt : 0.0;
+  static const double wts[5] = {0.0448, 0.2856, 0.3001, 0.2363, 0.1333};
+  double ms = 0.0;
+  for (int c = 0; c < 3; ++c) {
+    double prod = 1.0;
+    for (int l = 0; l < 5; ++l) {
+      // float32 means like torch, relu, then the weighted power
+      const float ssim = (float)(host[3 + l * 6 + c * 2] / (double)counts[l]);
+      const float cs = (float)(host[3 + l * 6 + c * 2 + 1] / (double)counts[l]);
+      const float v = std::max(l < 4 ? cs : ssim, 0.f);
+      prod *= pow((double)v, wts[l]);
+    }
+    ms += prod;
+  }
+  out3_host[1] = ms / 3.0;
   return PSL_OK;
 }

@@ -84,3 +84,15 @@ def keyframe_selection_overlap(rays_o, rays_d, gt_depth, keyframe_c2w, cam: dict
     sel = [i for i in order if pct[i] > 0.0]
     perm = (rng or np.random).permutation(np.array(sel, dtype=np.int64)) if sel else np.zeros(0, dtype=np.int64)
     return list(perm[:k])
+
+
+def image_metrics(gt_color, gt_depth, color, depth):
+    """(psnr, ms_ssim, depth_l1) of one rendered frame as the end-of-run evaluation computes them
+    (src/Mapper.py:861-879).  Images [H,W,3] / [H,W] on the device."""
+    H, W = int(gt_depth.shape[0]), int(gt_depth.shape[1])
+    out = (C.c_double * 3)()
+    a, b = gt_color.detach().float().contiguous(), color.detach().float().contiguous()
+    c, d = gt_depth.detach().float().contiguous(), depth.detach().float().contiguous()
+    _lib.check(_lib.lib().psl_image_metrics_sync(_lib.ptr(a), _lib.ptr(c), _lib.ptr(b), _lib.ptr(d), H, W, out,
+                                                 _lib.stream_ptr()), "psl_image_metrics_sync")
+    return float(out[0]), float(out[1]), float(out[2])

@@ -73,6 +73,18 @@ def test_oracle_keyframe_overlap_extremes():
     assert pct[0] == 1.0 and pct[1] == 0.0          # same pose sees all of its own frustum, the reversed one none
 
 
+def test_oracle_image_metrics_known_answers():
+    from oracle import eval_oracle as E
+    cam, c2w, depth, color = _frame(256, 192)
+    psnr, ms, l1 = E.image_metrics(color, depth, (color + 0.1).clone(), depth + 0.25)
+    assert abs(psnr - 20.0) < 1e-4 and abs(l1 - 0.25) < 1e-6          # uniform error e -> -20 log10 e
+    assert abs(E.image_metrics(color, depth, color.clone(), depth)[1] - 1.0) < 1e-6
+    assert abs(float(E.gauss_1d().sum()) - 1.0) < 1e-6
+    g = torch.Generator().manual_seed(0)
+    noisy = (color + 0.1 * torch.randn(color.shape, generator=g)).clamp(0, 1)
+    assert 0.3 < E.image_metrics(color, depth, noisy, depth)[1] < 0.99
+
+
 # ------------------------------------------------------------------------------------------------ GPU: HIP vs oracle
 @pytest.mark.gpu
 def test_frame_radii_match_oracle():
@@ -149,3 +161,22 @@ def test_keyframe_overlap_matches_oracle():
     sel = FO.keyframe_selection_overlap(ro.to(dev), rd.to(dev), gd.to(dev), kfs, cam, k=3,
                                         rng=np.random.default_rng(0))
     assert len(sel) <= 3 and all(want[i] > 0 for i in sel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(640, 480), (333, 201)])
+def test_image_metrics_match_oracle(size):
+    from oracle import eval_oracle as E
+    from point_slam_amd import frame_ops as FO
+    dev = torch.device("cuda:0")
+    cam, c2w, depth, color = _frame(*size)
+    g = torch.Generator().manual_seed(11)
+    noisy = (color + 0.05 * torch.randn(color.shape, generator=g)).clamp(0, 1)
+    d2 = depth * (1 + 0.01 * torch.randn(depth.shape, generator=g))
+    gt_depth = torch.where(torch.rand(depth.shape, generator=g) < 0.1, torch.zeros_like(depth), depth)
+    want = E.image_metrics(color, gt_depth, noisy, d2)
+    got = FO.image_metrics(color.to(dev), gt_depth.to(dev), noisy.to(dev), d2.to(dev))
+    assert abs(got[0] - want[0]) < 1e-4 * abs(want[0])      # PSNR (dB)
+    assert abs(got[1] - want[1]) < 2e-5                     # MS-SSIM: float32 maps, different summation order
+    assert abs(got[2] - want[2]) < 1e-6 * max(want[2], 1.0)
+    assert 0.5 < want[1] < 0.999
