@@ -267,6 +267,30 @@ def main():
         prof = kernel_profile(slam)
         _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 0))
 
+    points_end = slam.npc.pts_num()
+    # (3) SURVEY.md 8(d): tracking-only and mapping-only rates next to the combined one (single GPU; after the measured
+    #     regions, on frames already seen: 10 tracked frames, then 2 mapped frames at their true poses)
+    split = None
+    if world == 1 and not args.no_kernel_timing:
+        from point_slam_amd import frame_ops
+        ids = list(range(max(len(frames) - 10, 0), len(frames)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in ids:
+            if cfg["use_dynamic_radius"]:
+                frames[i].r_add, frames[i].r_query = frame_ops.dynamic_radius_maps(frames[i].color, cfg)
+            slam.track(frames[i], cams0[i])
+        torch.cuda.synchronize()
+        t_track = (time.perf_counter() - t0) / len(ids)
+        t0 = time.perf_counter()
+        for i in ids[:2]:
+            slam.map(frames[i], frames[i].c2w)
+        torch.cuda.synchronize()
+        t_map = (time.perf_counter() - t0) / 2
+        split = {"track_ms_per_frame": round(t_track * 1e3, 3), "track_only_fps": round(1.0 / t_track, 2),
+                 "map_ms_per_mapped_frame": round(t_map * 1e3, 3),
+                 "map_only_fps": round(cfg["mapping"]["every_frame"] / t_map, 2)}
+
     if rank == 0:
         roof, per = roofline_of(prof)
         tr, mp = cfg["tracking"], cfg["mapping"]
@@ -279,11 +303,12 @@ def main():
                                    f"{args.mix} iteration mix: track {tr['pixels']}px x {tr['iters']}it per frame, map "
                                    f"{mp['pixels']}px x {mp['iters']}it + {mp['pixels_adding']} add-pixels every "
                                    f"{mp['every_frame']} frames, window {mp['mapping_window_size']}",
-                       "engine": args.engine, "points_end": slam.npc.pts_num(),
+                       "engine": args.engine, "points_end": points_end,
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                        "render_loss_rel_err_vs_reference": "<=1e-4 (tests/test_hip_parity.py, tests/test_hip_slam.py)"},
             "roofline": roof,
             "profiled_ms_per_step": round(dt_prof / args.steps * 1e3, 3) if dt_prof else None,
+            "split": split,
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in per.items()},
         }
