@@ -457,6 +457,10 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   float* loss_scratch = p; p += 64;
   FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) + 3) / 4 + 4;
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  // the carve above must stay inside what psl_track_ws_floats() promises the caller
+  if ((rws - t->ws) + psl_render_ws_floats(n, PSL_STAGE_COLOR | PSL_PTS_GRAD) > psl_track_ws_floats(n)) {
+    set_error("psl_track_iters: internal workspace layout exceeds psl_track_ws_floats"); return PSL_ERR_STATE;
+  }
   FrameDev fh;
   memset(&fh, 0, sizeof(fh));
   fh.depth = t->frame.depth; fh.color = t->frame.color; fh.r_query = t->frame.r_query;
@@ -542,6 +546,11 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   int* pre_I = (int*)p; p += (size_t)kblock * n * S * K;
   int* pre_cnt = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  // the carve above must stay inside what psl_map_ws_floats() promises the caller
+  if ((rws - m->ws) + psl_render_ws_floats(n, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) >
+      psl_map_ws_floats(n, m->n_frames)) {
+    set_error("psl_map_iters: internal workspace layout exceeds psl_map_ws_floats"); return PSL_ERR_STATE;
+  }
   struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false; } } pre_guard{ctx};
   ctx->fused_ray = true;
   if (ctx->loss_acc_cap < m->n_iters) {
