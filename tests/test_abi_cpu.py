@@ -69,3 +69,27 @@ def test_config_inheritance(tmp_path):
     assert cfg["tracking"]["pixels"] == 321 and cfg["tracking"]["iters"] == 9 and cfg["mapping"]["iters"] == 7
     assert cfg["pointcloud"]["nn_num"] == 8               # falls through to the built-in defaults
     assert replica_overrides(default_config())["mapping"]["pixels"] == 5000
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: the header must compile as C99 (no C++-isms, no torch types) and a C program must
+    link against the library and call into it (psl_abi_version / psl_param_* need no GPU)."""
+    import shutil
+    import subprocess
+    from point_slam_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pointslam_hip.h"\n'
+                   "int main(void) {\n"
+                   "  psl_config c; psl_render_args a; psl_render_grads g; psl_track_args t; psl_map_args m;\n"
+                   "  (void)c; (void)a; (void)g; (void)t; (void)m;\n"
+                   f"  if (psl_abi_version() != {_lib.ABI_VERSION}) return 1;\n"
+                   "  if (psl_param_master_floats() != 124665) return 2;\n"
+                   "  if (psl_create(0, (const psl_config*)0, (psl_ctx**)0) >= 0) return 3;   /* bad argument -> negative status */\n"
+                   "  return 0;\n}\n")
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lpointslam_hip", f"-Wl,-rpath,{libdir}"])
+    assert subprocess.call([str(exe)]) == 0
