@@ -93,3 +93,26 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
                            str(src), "-o", str(exe), "-L", libdir, "-lpointslam_hip", f"-Wl,-rpath,{libdir}"])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_argument_errors_are_reported_not_thrown():
+    """Error behaviour of the boundary: negative status + psl_last_error(), never an abort.  Only
+    argument checks are exercised here (they run before any device work, so no GPU is needed)."""
+    import ctypes as C
+    from point_slam_amd import _lib
+    L = _lib.lib()
+    none = C.c_void_p(None)
+    assert L.psl_create(0, None, None) < 0 and L.psl_last_error()
+    assert L.psl_render_ws_floats(-1, 0) < 0
+    assert L.psl_track_ws_floats(-5) < 0 and L.psl_map_ws_floats(-1, 1) < 0
+    assert L.psl_frame_radii(none, 480, 640, 0.15, 0.08, 0.02, 2.0, none, none, none, none) < 0
+    assert b"psl_frame_radii" in L.psl_last_error()
+    n = C.c_int(0)
+    assert L.psl_topgrad_select_sync(none, none, none, 480, 640, 10, 0, 480, 0, 640, 0.0, none, C.byref(n), none) < 0
+    out = (C.c_double * 3)()
+    assert L.psl_image_metrics_sync(none, none, none, none, 480, 640, out, none) < 0
+    assert L.psl_knn(none, none, none, 0.1, 1, none, none, none, none) < 0
+    assert L.psl_render_fwd(none, None, none) < 0 and L.psl_render_bwd(none, None, None, none) < 0
+    assert L.psl_track_iters(none, None, none) < 0 and L.psl_map_iters(none, None, none) < 0
+    with pytest.raises(_lib.PslError):
+        _lib.check(L.psl_points_append(none, none, 1, none), "psl_points_append")
