@@ -318,6 +318,9 @@ def run_tracker_case(name, n_pts, n_rays, seed):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--scannet-mapper" in sys.argv:   # encode_exposure with exposure_feat=None: raw colour logits, no sigmoid (decoder.py:432-448)
+        run_render_case("render_scannet_color_mapper", "scannet", "color", False, 2000, 64, 109)
+        return
     if "--zero-depth" in sys.argv:   # only the sensor-hole cases (the others are unchanged)
         run_render_case("render_holes_nearpcl_mapper", "replica", "color", False, 3000, 96, 107, sparse_frac=0.35,
                         zero_depth_frac=0.4, sample_near_pcl=True)
@@ -338,6 +341,8 @@ def main():
                     zero_depth_frac=0.4, sample_near_pcl=True)
     run_render_case("render_holes_uniform_tracker", "replica", "color", True, 2000, 64, 108,
                     zero_depth_frac=0.4, sample_near_pcl=False)
+
+    run_render_case("render_scannet_color_mapper", "scannet", "color", False, 2000, 64, 109)
 
 
 if __name__ == "__main__":
