@@ -63,6 +63,12 @@ def camera_tensor_from_c2w(c2w: torch.Tensor) -> torch.Tensor:
 class HipSLAM:
     def __init__(self, cfg, cam: dict, device="cuda:0", max_points=2_500_000, engine="native", decoders=None):
         self.cfg, self.cam, self.device, self.engine = cfg, cam, torch.device(device), engine
+        if cfg["model"].get("encode_exposure", False):
+            # the per-frame exposure vectors of the ScanNet config (Mapper.py:530-548, Tracker.py:305-311) are
+            # optimised by the reference's own loops; the drop-in classes support them (HipRenderer), the fused
+            # native / drop-in loops of this class do not carry them yet
+            raise NotImplementedError("HipSLAM: model.encode_exposure is supported through the drop-in HipRenderer "
+                                      "inside the reference's Tracker/Mapper, not by the HipSLAM loops")
         cfgd = dict(cfg)
         cfgd["mapping"] = dict(cfg["mapping"], device=str(device))
         self.npc = HipNeuralPointCloud(cfgd, max_points=max_points, device=str(device))
