@@ -455,6 +455,170 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 
 
 # --------------------------------------------------------------------------
+# the iteration loops (src/Mapper.py:408-568, src/Tracker.py:296-350), replayed for PRE-DRAWN random numbers
+# --------------------------------------------------------------------------
+class _Adam:
+    """torch.optim.Adam as the loops use it: one step counter per tensor, tensors whose gradient is None are
+    skipped (their counter does not advance) -- the semantics of torch >= 2.0's zero_grad(set_to_none=True)."""
+
+    def __init__(self):
+        self.state = {}
+
+    def step(self, name: str, p: Tensor, g: Optional[Tensor], lr: float) -> Tensor:
+        if g is None:
+            return p
+        st = self.state.setdefault(name, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
+        st["step"] += 1
+        q, st["m"], st["v"] = adam_step(p, g, st["m"], st["v"], st["step"], lr)
+        return q
+
+
+def mapper_rays(frames, pix_it, cam):
+    """get_samples per window frame (common.py:162-183, depth_filter) + concatenation + depth-outlier mask
+    (Mapper.py:455-514).  frames: dicts depth/color/c2w/r_query; pix_it [F][ppf] flat indices into the full image.
+    Returns rays_o, rays_d, gt_depth, gt_color, r_query (or None), frame id per ray."""
+    H, W = cam["H"], cam["W"]
+    ros, rds, gds, gcs, rqs, fids = [], [], [], [], [], []
+    for f, fr in enumerate(frames):
+        u, v = pixels_from_flat_index(pix_it[f].long(), 0, H, 0, W)
+        ro, rd = rays_from_uv(u, v, fr["c2w"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        ui, vi = u.long(), v.long()
+        gd = fr["depth"][vi, ui]
+        keep = gd > 0
+        ros.append(ro[keep]); rds.append(rd[keep]); gds.append(gd[keep]); gcs.append(fr["color"][vi, ui][keep].float())
+        if fr.get("r_query") is not None:
+            rqs.append(fr["r_query"][vi, ui][keep])
+        fids.append(torch.full((int(keep.sum()),), f, dtype=torch.long))
+    ro, rd, gd, gc, fid = torch.cat(ros), torch.cat(rds), torch.cat(gds), torch.cat(gcs), torch.cat(fids)
+    rq = torch.cat(rqs) if rqs else None
+    inl = depth_inlier_mask(gd)
+    return ro[inl], rd[inl], gd[inl], gc[inl], (rq[inl] if rq is not None else None), fid[inl]
+
+
+def mapper_iterations(cfg, P, cloud, geo_feats, col_feats, sel, frames, pix, fb, n_geo_iters, cam, coef=0.1,
+                      exposure_feats=None, init=False, record=None):
+    """The joint_iter loop of Mapper.optimize_map (src/Mapper.py:408-568, no BA) for pre-drawn pixels `pix`
+    [n_iters][F][ppf] and fallback vectors `fb` [n_iters][2][32].  The frustum-selected rows `sel` of both feature
+    sets, the colour decoder (all of color_decoder.parameters(), :358-360) and -- ScanNet -- the current frame's
+    exposure vector (lr 0.001, :399-401) are optimised; frames[-1] is the current frame.
+    exposure_feats: list of [8] tensors per window frame or None.  Returns (losses, geo_feats, col_feats, P,
+    exposure of the current frame)."""
+    mp = cfg["mapping"]
+    stage_tab = mp["init" if init else "stage"]
+    sel = sel.long()
+    geo_p = geo_feats[sel].detach().clone()
+    col_p = col_feats[sel].detach().clone()
+    P = {k: v.detach().clone() for k, v in P.items()}
+    train_keys = [k for k in P if k.startswith("color_decoder.") and k != "color_decoder.embedder._B"
+                  and P[k].dtype.is_floating_point] if not mp["fix_color_decoder"] else []
+    exposure = cfg["model"]["encode_exposure"]
+    ex_cur = exposure_feats[-1].detach().clone() if exposure else None
+    opt = _Adam()
+    n_iters = pix.shape[0]
+    losses = []
+    for it in range(n_iters):
+        stage = "geometry" if it <= n_geo_iters else "color"                       # Mapper.py:420-423
+        lr = stage_tab[stage]
+        gp, cp = geo_p.clone().requires_grad_(True), col_p.clone().requires_grad_(True)
+        Pg = {k: (v.clone().requires_grad_(True) if k in train_keys else v) for k, v in P.items()}
+        ex = ex_cur.clone().requires_grad_(True) if exposure else None
+        g_full = geo_feats.detach().index_put((sel,), gp)                          # :413-414
+        c_full = col_feats.detach().index_put((sel,), cp)
+        ro, rd, gd, gc, rq, fid = mapper_rays(frames, pix[it], cam)
+        depth, var, rgb, valid, _ = render_batch_ray(cfg, Pg, cloud, g_full, c_full, ro, rd, gd, stage, rq,
+                                                     fb[it, 0], fb[it, 1], pts_grad=False, coef=coef)
+        m = (gd > 0) & valid & (~torch.isnan(depth))                               # :524-526
+        loss = (gd[m] - depth[m]).abs().sum()
+        if stage == "color":
+            if exposure:                                                           # :530-548, frame by frame
+                rgb = rgb.clone()
+                for f in range(len(frames)):
+                    rows = torch.nonzero(fid == f).flatten()
+                    if rows.numel() == 0:
+                        continue
+                    a, b = int(rows[0]), int(rows[-1]) + 1
+                    aff = exposure_mlp(ex if f == len(frames) - 1 else exposure_feats[f], Pg)
+                    rgb[a:b] = rgb[a:b].clone() @ aff[:9].reshape(3, 3) + aff[9:]
+                rgb = torch.sigmoid(rgb)
+            loss = loss + mp["w_color_loss"] * (gc[m] - rgb[m]).abs().sum()
+        loss.backward()
+        losses.append(float(loss.detach()))
+        geo_p = opt.step("geo", geo_p, gp.grad, lr["geometry_lr"])
+        col_p = opt.step("col", col_p, cp.grad, lr["color_lr"])
+        for k in train_keys:
+            P[k] = opt.step(k, P[k], Pg[k].grad, lr["decoders_lr"])
+        if exposure:
+            ex_cur = opt.step("exposure", ex_cur, ex.grad, 0.001)
+        if record is not None:
+            record(it, geo_p, col_p, P, ex_cur)
+    geo_out, col_out = geo_feats.detach().clone(), col_feats.detach().clone()
+    geo_out[sel], col_out[sel] = geo_p, col_p
+    return losses, geo_out, col_out, P, ex_cur, opt
+
+
+def tracker_loop(cfg, P, cloud, geo_feats, col_feats, cam0, pix, fb, depth_img, color_img, rq_img, cam, edge_h,
+                 edge_w, coef=0.1, exposure_feat=None, full_image_index=False):
+    """The cam_iter loop of Tracker.run (src/Tracker.py:296-350) around optimize_cam_in_batch (:89-186): Adam on
+    T (lr) and the quaternion (0.2 lr, separate_LR) and -- encode_exposure -- on the frame's exposure vector and
+    mlp_exposure (both lr 0.001, :305-311).  pix [n_iters][n]: flat indices into the cropped window, or into the
+    FULL image when full_image_index (sample_with_color_grad, :115-128: no depth filter there).
+    Returns per-iteration losses, camera tensors [n_iters][7], the lowest-loss camera tensor, the exposure vector
+    and the (updated) parameter dict."""
+    tr = cfg["tracking"]
+    H, W = cam["H"], cam["W"]
+    quat, trans = cam0[:4].detach().clone(), cam0[4:].detach().clone()
+    P = {k: v.detach().clone() for k, v in P.items()}
+    exposure = cfg["model"]["encode_exposure"]
+    ex_keys = [k for k in P if k.startswith("color_decoder.mlp_exposure.")] if exposure else []
+    ex = exposure_feat.detach().clone() if exposure else None
+    lr = tr["lr"]
+    lr_q = lr * 0.2 if tr["separate_LR"] else lr
+    opt = _Adam()
+    losses, cams = [], []
+    best, best_loss = None, float("inf")
+    for it in range(pix.shape[0]):
+        q, t = quat.clone().requires_grad_(True), trans.clone().requires_grad_(True)
+        Pg = {k: (v.clone().requires_grad_(True) if k in ex_keys else v) for k, v in P.items()}
+        e = ex.clone().requires_grad_(True) if exposure else None
+        c2w = camera_from_tensor(q, t)
+        if full_image_index:
+            vi, ui = torch.div(pix[it].long(), W, rounding_mode="floor"), pix[it].long() % W
+            u, v = ui.float(), vi.float()
+        else:
+            u, v = pixels_from_flat_index(pix[it].long(), edge_h, H - edge_h, edge_w, W - edge_w)
+            ui, vi = u.long(), v.long()
+        ro, rd = rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        gd, gc = depth_img[vi, ui], color_img[vi, ui]
+        rq = rq_img[vi, ui] if cfg["use_dynamic_radius"] else None
+        if not full_image_index:
+            keep = gd > 0
+            ro, rd, gd, gc = ro[keep], rd[keep], gd[keep], gc[keep]
+            rq = rq[keep] if rq is not None else None
+        inl = depth_inlier_mask(gd)
+        ro, rd, gd, gc = ro[inl], rd[inl], gd[inl], gc[inl]
+        rq = rq[inl] if rq is not None else None
+        aff = exposure_mlp(e, Pg) if exposure else None
+        depth, var, rgb, valid, _ = render_batch_ray(cfg, Pg, cloud, geo_feats, col_feats, ro, rd, gd, "color", rq,
+                                                     fb[it, 0], fb[it, 1], pts_grad=True, exposure_affine=aff,
+                                                     coef=coef)
+        loss, geo, col, mask = tracker_loss(depth, var, rgb, gd, gc, tr["handle_dynamic"], tr["use_color_in_tracking"],
+                                            tr["w_color_loss"])
+        loss.backward()
+        lv = float(loss.detach())
+        if lv < best_loss:
+            best_loss, best = lv, torch.cat([quat, trans]).clone()
+        trans = opt.step("T", trans, t.grad, lr)
+        quat = opt.step("quat", quat, q.grad, lr_q)
+        if exposure:
+            ex = opt.step("exposure", ex, e.grad, 0.001)
+            for k in ex_keys:
+                P[k] = opt.step(k, P[k], Pg[k].grad, 0.001)
+        losses.append(lv)
+        cams.append(torch.cat([quat, trans]).clone())
+    return losses, torch.stack(cams), best, ex, P
+
+
+# --------------------------------------------------------------------------
 # point growth
 # --------------------------------------------------------------------------
 def add_points_select(cloud: Tensor, rays_o, rays_d, gt_depth, radius, n_add=3, near=0.98, far=1.02,

@@ -18,10 +18,15 @@ def base_cfg():
                   "encode_viewd": True},
         "tracking": {"ignore_edge_W": 20, "ignore_edge_H": 20, "use_color_in_tracking": True,
                      "handle_dynamic": True, "w_color_loss": 0.5, "separate_LR": True, "lr": 0.002,
-                     "pixels": 200, "iters": 20, "device": "cuda:0", "depth_limit": False},
+                     "pixels": 200, "iters": 20, "device": "cuda:0", "depth_limit": False,
+                     "sample_with_color_grad": False},
         "mapping": {"w_color_loss": 0.1, "pixels": 1000, "iters": 400, "every_frame": 5, "device": "cuda:0",
                     "geo_iter_ratio": 0.4, "fix_geo_decoder": True, "fix_color_decoder": False,
                     "mapping_window_size": 5, "pixels_adding": 6000, "frustum_edge": -4, "BA": False,
+                    "min_iter_ratio": 0.95, "geo_iter_first": 400, "iters_first": 1500, "keyframe_every": 20,
+                    "pixels_based_on_color_grad": 0, "keyframe_selection_method": "overlap",
+                    "init": {"geometry": {"decoders_lr": 0.001, "geometry_lr": 0.03, "color_lr": 0.0},
+                             "color": {"decoders_lr": 0.005, "geometry_lr": 0.005, "color_lr": 0.005}},
                     "stage": {"geometry": {"decoders_lr": 0.001, "geometry_lr": 0.03, "color_lr": 0.0},
                               "color": {"decoders_lr": 0.005, "geometry_lr": 0.005, "color_lr": 0.005}}},
         "rendering": {"N_surface": 5, "near_end": 0.3, "near_end_surface": 0.98, "far_end_surface": 1.02,
@@ -91,3 +96,23 @@ ORACLE_ONLY_CASES = ["render_scannet_color_mapper"]
 
 def relerr(a, b):
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+# ---- loop fixtures (oracle/gen_golden_loops.py: the reference's own Mapper.optimize_map / Tracker loops) -------
+def loop_cfg(fx):
+    """Config of a mapper_iters_* / tracker_iters_* fixture."""
+    cfg = cfg_variant(fx["cfg_name"])
+    if "mapping_pixels" in fx:
+        cfg["mapping"].update(pixels=fx["mapping_pixels"], iters=fx["iters_cfg"], pixels_adding=fx["pixels_adding"],
+                              mapping_window_size=3)
+    return cfg
+
+
+def loop_cam(fx):
+    from point_slam_amd import synthetic as syn
+    return syn.intrinsics(fx["W"], fx["H"])
+
+
+def mapper_frames(fx, exposure):
+    return [dict(depth=fx[f"f{k}_depth"], color=fx[f"f{k}_color"], c2w=fx[f"f{k}_c2w"], r_query=fx[f"f{k}_r_query"],
+                 exposure=fx[f"f{k}_exposure"] if exposure else None) for k in range(3)]
