@@ -90,6 +90,8 @@ int psl_points_truncate(psl_ctx* ctx, int n);
 int psl_points_count(psl_ctx* ctx);
 /* copy positions [count][3] f32 to a device buffer (checkpoint compatibility, src/utils/Logger.py:22-40) */
 int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_points, void* stream);
+/* the same for points [first, first+count): what a rank sends in the multi-GPU exchange (O(new), not O(N)) */
+int psl_points_download_range(psl_ctx* ctx, int first, int count, float* pos_out, void* stream);
 /* (re)build the uniform-grid index over all points: index.train/index.add (src/neural_point.py:161-164) */
 int psl_index_build(psl_ctx* ctx, void* stream);
 
@@ -195,8 +197,7 @@ int psl_adam_step_rows(float* feats, const int32_t* rows, float* g, float* m, fl
  * The bodies of the reference's per-frame loops, run n_iters times back-to-back on `stream`:
  *   psl_track_iters : Tracker.optimize_cam_in_batch (src/Tracker.py:89-186) inside the loop of
  *                     Tracker.run (src/Tracker.py:332-350, incl. the lowest-loss candidate pose);
- *   psl_map_iters   : the joint_iter loop of Mapper.optimize_map (src/Mapper.py:408-568), without BA and
- *                     without per-frame exposure.
+ *   psl_map_iters   : the joint_iter loop of Mapper.optimize_map (src/Mapper.py:408-568), without BA.
  * Random draws stay with the host (torch RNG): flat pixel indices as torch.randint would produce them in
  * select_uv (src/common.py:59-74) and the per-call fallback vectors (decoder.py:170,387), pre-drawn for
  * all iterations. */
@@ -208,6 +209,22 @@ typedef struct psl_frame_view {     /* one RGB-D (key)frame resident in device m
   const float* r_query;             /* [H][W] per-pixel query radius, or NULL (fixed radius) */
   float c2w[12];                    /* row-major 3x4 pose (mapping only) */
 } psl_frame_view;
+
+/* Per-frame exposure compensation (model.encode_exposure, configs/ScanNet/scannet.yaml:5): MLP_exposure
+ * (decoder.py:243-258) maps a frame's 8-d latent to a 3x3 colour matrix + offset applied to the colour logits before the
+ * sigmoid.  Tracker (Tracker.py:305-311): this frame's latent and the MLP are both optimised, lr 0.001.  Mapper
+ * (Mapper.py:399-401,530-548): one latent per window frame, applied to that frame's slice of the COMPOSITED logits; only
+ * the current frame's latent is optimised (lr 0.001), the MLP is part of color_decoder.parameters() (decoders_lr). */
+#define PSL_EXPOSURE_DIM 8
+#define PSL_EXPOSURE_MLP_FLOATS 2700   /* linear1.weight [128][8], linear1.bias [128], linear2.weight [12][128], linear2.bias [12] */
+typedef struct psl_exposure_args {
+  float* mlp;          /* [PSL_EXPOSURE_MLP_FLOATS], updated in place */
+  float* feats;        /* tracker: [8]; mapper: [n_frames][8], the LAST row (current frame) is updated in place */
+  float* adam;         /* [2][PSL_EXPOSURE_MLP_FLOATS + 8] exp_avg, exp_avg_sq; zero at frame start */
+  float lr_mlp;        /* tracker: 0.001; mapper: mapping.stage.color.decoders_lr */
+  float lr_feat;       /* 0.001 */
+  int32_t step0;       /* Adam steps already taken on this state */
+} psl_exposure_args;
 
 typedef struct psl_track_args {
   psl_cam_intr cam;
@@ -227,6 +244,11 @@ typedef struct psl_track_args {
   float* ws;                        /* psl_track_ws_floats(n_pix) floats */
   float* loss_out;                  /* [n_iters][4] (loss, geo, colour, #active) or NULL */
   float* best_out;                  /* [8] lowest-loss pose [7] + its loss (candidate_cam_tensor, Tracker.py:347-350) */
+  /* ABI v3 */
+  int32_t pix_full_image;           /* 1: pix_idx are flat indices into the FULL image, no border crop and no depth filter --
+                                       tracking.sample_with_color_grad (Tracker.py:115-128): the caller draws them from the
+                                       top-gradient set of psl_topgrad_select_sync */
+  const psl_exposure_args* exposure;/* NULL unless model.encode_exposure */
 } psl_track_args;
 int64_t psl_track_ws_floats(int n_pix);
 int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stream);
@@ -254,6 +276,12 @@ typedef struct psl_map_args {
   float w_color, sigmoid_coef;
   float* ws;                        /* psl_map_ws_floats() floats */
   float* loss_out;                  /* [n_iters][4] or NULL */
+  /* ABI v3 */
+  const psl_exposure_args* exposure;/* NULL unless model.encode_exposure */
+  int32_t step0_params;             /* Adam steps the colour-decoder group has already counted when its first gradient arrives.
+                                       0 = torch >= 2.0 (zero_grad sets .grad to None: the group is skipped during the geometry
+                                       stage); n_geo_iters + 1 reproduces torch 1.12 (env.yaml) from the second mapped frame on,
+                                       where zero_grad leaves zero tensors and Adam counts the geometry-stage steps */
 } psl_map_args;
 int64_t psl_map_ws_floats(int n_rays, int n_frames);
 int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream);

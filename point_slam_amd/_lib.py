@@ -16,7 +16,9 @@ class PslError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2     # include/pointslam_hip.h: psl_abi_version(); v2 added psl_render_args.z_vals
+ABI_VERSION = 3     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
+#                     full-image pixel indices in psl_track_args, step0_params in psl_map_args
+EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 
 
 class psl_config(C.Structure):
@@ -51,6 +53,11 @@ class psl_frame_view(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("r_query", C.c_void_p), ("c2w", C.c_float * 12)]
 
 
+class psl_exposure_args(C.Structure):
+    _fields_ = [("mlp", C.c_void_p), ("feats", C.c_void_p), ("adam", C.c_void_p), ("lr_mlp", C.c_float),
+                ("lr_feat", C.c_float), ("step0", C.c_int32)]
+
+
 class psl_track_args(C.Structure):
     _fields_ = [("cam", psl_cam_intr), ("edge_h", C.c_int32), ("edge_w", C.c_int32), ("n_iters", C.c_int32),
                 ("n_pix", C.c_int32), ("pix_idx", C.c_void_p), ("fallback", C.c_void_p), ("frame", psl_frame_view),
@@ -58,7 +65,8 @@ class psl_track_args(C.Structure):
                 ("lr_quat", C.c_float), ("w_color", C.c_float), ("handle_dynamic", C.c_int32),
                 ("use_color", C.c_int32), ("sigmoid_coef", C.c_float), ("geo_feats", C.c_void_p),
                 ("col_feats", C.c_void_p), ("params", C.c_void_p), ("col_embed_B", C.c_void_p), ("ws", C.c_void_p),
-                ("loss_out", C.c_void_p), ("best_out", C.c_void_p)]
+                ("loss_out", C.c_void_p), ("best_out", C.c_void_p), ("pix_full_image", C.c_int32),
+                ("exposure", C.POINTER(psl_exposure_args))]
 
 
 class psl_map_args(C.Structure):
@@ -70,7 +78,8 @@ class psl_map_args(C.Structure):
                 ("adam_params", C.c_void_p), ("step0_geo", C.c_int32), ("step0_col", C.c_int32),
                 ("train_decoder", C.c_int32), ("lr_geo_geo_stage", C.c_float), ("lr_geo_color_stage", C.c_float),
                 ("lr_col", C.c_float), ("lr_decoder", C.c_float), ("w_color", C.c_float), ("sigmoid_coef", C.c_float),
-                ("ws", C.c_void_p), ("loss_out", C.c_void_p)]
+                ("ws", C.c_void_p), ("loss_out", C.c_void_p), ("exposure", C.POINTER(psl_exposure_args)),
+                ("step0_params", C.c_int32)]
 
 
 # psl_render_flags
@@ -91,6 +100,7 @@ _SIGS = {
     "psl_points_truncate": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_points_count": (C.c_int, [C.c_void_p]),
     "psl_points_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "psl_points_download_range": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p]),

@@ -13,8 +13,8 @@ def checkpoint_dict(npc, decoders, idx=0, keyframe_dict=None, keyframe_list=None
     positions_as_list (what the reference tools expect), else a [N,3] CPU tensor (cheaper at 1 M points)."""
     pos = npc.cloud_pos().detach().cpu()
     return {
-        "geo_feats": npc.get_geo_feats(),
-        "col_feats": npc.get_col_feats(),
+        "geo_feats": npc.get_geo_feats().clone(),        # views of the pre-allocated stores: save N rows, not capacity
+        "col_feats": npc.get_col_feats().clone(),
         "cloud_pos": pos.tolist() if positions_as_list else pos,
         "pts_num": npc.pts_num(),
         "input_pos": npc.input_pos(),
@@ -38,8 +38,9 @@ def load_neural_point_cloud(npc, ckpt: dict):
     """get_mesh_tsdf_fusion.load_neural_point_cloud: positions + features into the npc, index rebuilt."""
     pos = ckpt["cloud_pos"]
     pos = pos if torch.is_tensor(pos) else torch.tensor(pos, dtype=torch.float32)
-    npc._input_pos = ckpt.get("input_pos", [])
-    npc._input_rgb = ckpt.get("input_rgb", [])
+    ip, ir = ckpt.get("input_pos", []), ckpt.get("input_rgb", [])
+    npc._input_pos = [torch.tensor(ip, dtype=torch.float32, device=npc.device).reshape(-1, 3)] if len(ip) else []
+    npc._input_rgb = [torch.tensor(ir, dtype=torch.float32, device=npc.device).reshape(-1, 3)] if len(ir) else []
     npc.geo_feats = None
     npc.col_feats = None
     npc.set_points(pos.reshape(-1, 3), ckpt["geo_feats"], ckpt["col_feats"])

@@ -152,6 +152,7 @@ struct psl_ctx {
   bool fused_ray = false;    // psl_map_iters: compositing fwd/bwd + loss run in its own fused kernel
   double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
+  float* d_expo;         // per-frame exposure scratch: affines [64][12], hidden activations [64][128], d(affine) [64][12]
   int* scan_flags;       // for add_points compaction
   int scan_flags_cap;
   // profiling: a ring of HIP event pairs per kernel class, recorded on the launch stream
@@ -214,11 +215,11 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
 struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s);
+                    float lr_par, hipStream_t s, int step_par = -1);
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
                          float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
-                         float* zero64, hipStream_t s);
+                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s);
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);
 int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);

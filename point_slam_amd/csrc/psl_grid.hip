@@ -522,6 +522,17 @@ extern "C" int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_po
   return n;
 }
 
+extern "C" int psl_points_download_range(psl_ctx* ctx, int first, int count, float* pos_out, void* stream) {
+  if (!ctx || first < 0 || count < 0 || first + count > ctx->n_points || (count > 0 && !pos_out)) {
+    set_error("psl_points_download_range: bad range [%d, %d) of %d", first, first + count, ctx ? ctx->n_points : -1);
+    return PSL_ERR_ARG;
+  }
+  if (count > 0)
+    hipLaunchKernelGGL(k_download, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->pos + first, count, pos_out);
+  PSL_LAUNCH_CHECK();
+  return count;
+}
+
 extern "C" int psl_index_build(psl_ctx* ctx, void* stream) {
   if (!ctx) return PSL_ERR_ARG;
   return grid_build(ctx, (hipStream_t)stream);

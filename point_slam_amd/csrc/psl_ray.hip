@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
                                                        float* __restrict__ depth, float* __restrict__ var,
                                                        float* __restrict__ rgb, unsigned char* __restrict__ valid,
                                                        float4* __restrict__ d_raw, double* __restrict__ loss_acc,
-                                                       float* __restrict__ zero64) {
+                                                       float* __restrict__ zero64, const float* __restrict__ frame_affine,
+                                                       int pix_per_frame, float* __restrict__ g_frame_affine) {
+  // frame_affine != null (ScanNet, colour stage): the decoder returned raw colour logits; the affine of the ray's window
+  // frame (slot r / pix_per_frame) and the sigmoid are applied to the COMPOSITED logits here (Mapper.py:530-548), and
+  // d(loss)/d(affine) is accumulated per frame into g_frame_affine [F][12].
   __shared__ double red[3][4];
   if (zero64 && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,7 +168,16 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
 #pragma unroll
     for (int s = 0; s < S; ++s) { float tmp = z[s] - d; v += w[s] * tmp * tmp; }
     const bool vr = nhas >= (S / 2 + 1);
-    depth[r] = d; var[r] = v; rgb[r * 3] = m0; rgb[r * 3 + 1] = m1; rgb[r * 3 + 2] = m2; valid[r] = vr ? 1 : 0;
+    // colour as the loss sees it: composited value, or sigmoid(composited logits @ A_f + t_f) with per-frame exposure
+    float e0 = m0, e1 = m1, e2 = m2;
+    const float* A = nullptr;
+    if (frame_affine && color_stage) {
+      A = frame_affine + 12 * (r / pix_per_frame);
+      e0 = sigmoidf(m0 * A[0] + m1 * A[3] + m2 * A[6] + A[9]);
+      e1 = sigmoidf(m0 * A[1] + m1 * A[4] + m2 * A[7] + A[10]);
+      e2 = sigmoidf(m0 * A[2] + m1 * A[5] + m2 * A[8] + A[11]);
+    }
+    depth[r] = d; var[r] = v; rgb[r * 3] = e0; rgb[r * 3 + 1] = e1; rgb[r * 3 + 2] = e2; valid[r] = vr ? 1 : 0;
     // loss + cotangents
     float gd = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
     if (active[r] && gt > 0.f && vr && d == d) {
@@ -173,10 +186,23 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
       lcnt = 1.0;
       if (color_stage) {
         const float g0 = gt_color[r * 3], g1 = gt_color[r * 3 + 1], g2 = gt_color[r * 3 + 2];
-        lc = (double)fabsf(g0 - m0) + (double)fabsf(g1 - m1) + (double)fabsf(g2 - m2);
-        gr0 = w_color * ((m0 > g0) ? 1.f : ((m0 < g0) ? -1.f : 0.f));
-        gr1 = w_color * ((m1 > g1) ? 1.f : ((m1 < g1) ? -1.f : 0.f));
-        gr2 = w_color * ((m2 > g2) ? 1.f : ((m2 < g2) ? -1.f : 0.f));
+        lc = (double)fabsf(g0 - e0) + (double)fabsf(g1 - e1) + (double)fabsf(g2 - e2);
+        gr0 = w_color * ((e0 > g0) ? 1.f : ((e0 < g0) ? -1.f : 0.f));
+        gr1 = w_color * ((e1 > g1) ? 1.f : ((e1 < g1) ? -1.f : 0.f));
+        gr2 = w_color * ((e2 > g2) ? 1.f : ((e2 < g2) ? -1.f : 0.f));
+      }
+    }
+    if (A) {
+      // through the sigmoid, then out' = out @ A + t: dA[i][j] = out_i d_j, dt_j = d_j, d out_i = sum_j A[i][j] d_j
+      const float q0 = gr0 * e0 * (1.f - e0), q1 = gr1 * e1 * (1.f - e1), q2 = gr2 * e2 * (1.f - e2);
+      float ga[12] = {m0 * q0, m0 * q1, m0 * q2, m1 * q0, m1 * q1, m1 * q2, m2 * q0, m2 * q1, m2 * q2, q0, q1, q2};
+      gr0 = A[0] * q0 + A[1] * q1 + A[2] * q2;
+      gr1 = A[3] * q0 + A[4] * q1 + A[5] * q2;
+      gr2 = A[6] * q0 + A[7] * q1 + A[8] * q2;
+      float* dst = g_frame_affine + 12 * (r / pix_per_frame);
+      if (q0 != 0.f || q1 != 0.f || q2 != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) atomic_add_f32(dst + j, ga[j]);
       }
     }
     // compositing backward (no variance cotangent in the mapper loss)
@@ -208,11 +234,11 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
                          float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
-                         float* zero64, hipStream_t s) {
+                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
   hipLaunchKernelGGL(k_map_ray_fused, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
                      near_s, far_s, min_nn, n_rays, coef, w_color, color_stage, depth, var, rgb, valid, d_raw, loss_acc,
-                     zero64);
+                     zero64, frame_affine, pix_per_frame, g_frame_affine);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
@@ -347,10 +373,10 @@ static void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, f
 
 namespace psl {
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s) {
+                    float lr_par, hipStream_t s, int step_par) {
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
-  if (par.n > 0) adam_consts(step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
+  if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
   const int nb_geo = (int)(((long long)geo.n_rows * (C / 4) + 255) / 256);
   const int nb_col = (int)(((long long)col.n_rows * (C / 4) + 255) / 256);
   const int nb_par = (par.n + 255) / 256;

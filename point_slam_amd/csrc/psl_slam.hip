@@ -321,6 +321,99 @@ __global__ __launch_bounds__(256) void k_pose_step(RayBufs b, int n, float* cam_
   for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, step);
 }
 
+// ------------------------------------------------------------------ per-frame exposure compensation
+// MLP_exposure (decoder.py:243-258): aff = linear2(softplus100(linear1(e))), e [8] -> 128 -> 12.  The affine of every
+// window frame is evaluated by one small workgroup each; its backward, the sum over frames and Adam on the MLP and on
+// the trainable latent run in ONE single-workgroup kernel which also re-evaluates the affines for the next iteration.
+constexpr int EXD = PSL_EXPOSURE_DIM, EXH = 128, EXO = 12;
+constexpr int EX_W1 = 0, EX_B1 = EXH * EXD, EX_W2 = EX_B1 + EXH, EX_B2 = EX_W2 + EXO * EXH, EX_N = EX_B2 + EXO;
+static_assert(EX_N == PSL_EXPOSURE_MLP_FLOATS, "exposure MLP layout");
+
+// one thread per hidden unit; aff [12] and act [128] of frame f
+__device__ __forceinline__ void exposure_eval(const float* __restrict__ mlp, const float* __restrict__ e, float* aff,
+                                              float* act, float* lds_a /*[128]*/) {
+  const int j = threadIdx.x;
+  if (j < EXH) {
+    float h = mlp[EX_B1 + j];
+#pragma unroll
+    for (int k = 0; k < EXD; ++k) h = fmaf(mlp[EX_W1 + j * EXD + k], e[k], h);
+    const float a = softplus100(h);
+    lds_a[j] = a;
+    act[j] = a;
+  }
+  __syncthreads();
+  if (j < EXO) {
+    float o = mlp[EX_B2 + j];
+    for (int k = 0; k < EXH; ++k) o = fmaf(mlp[EX_W2 + j * EXH + k], lds_a[k], o);
+    aff[j] = o;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(128) void k_exposure_fwd(const float* __restrict__ mlp, const float* __restrict__ feats, float* aff,
+                                                      float* act) {
+  __shared__ float la[EXH];
+  const int f = blockIdx.x;
+  exposure_eval(mlp, feats + f * EXD, aff + f * EXO, act + f * EXH, la);
+}
+
+// g_aff [F][12] (consumed and cleared), act [F][128]; trainable latent = row F-1.  128 threads.
+__global__ __launch_bounds__(128) void k_exposure_step(float* mlp, float* feats, int F, float* g_aff, float* aff, float* act,
+                                                       float* adam_m, float* adam_v, int step, float lr_mlp, float lr_feat) {
+  __shared__ float la[EXH];
+  __shared__ float sg[64 * EXO];
+  __shared__ float sde[EXH][EXD + 1];
+  const int j = threadIdx.x;
+  for (int e = j; e < F * EXO; e += EXH) sg[e] = g_aff[e];
+  __syncthreads();
+  float dW1[EXD], dW2[EXO], db1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < EXD; ++k) dW1[k] = 0.f;
+#pragma unroll
+  for (int o = 0; o < EXO; ++o) dW2[o] = 0.f;
+  float dh_last = 0.f;
+  for (int f = 0; f < F; ++f) {
+    const float a = act[f * EXH + j];
+    float da = 0.f;
+#pragma unroll
+    for (int o = 0; o < EXO; ++o) {
+      const float g = sg[f * EXO + o];
+      da = fmaf(mlp[EX_W2 + o * EXH + j], g, da);
+      dW2[o] = fmaf(g, a, dW2[o]);
+    }
+    const float dh = da * softplus100_grad_from_out(a);
+    db1 += dh;
+#pragma unroll
+    for (int k = 0; k < EXD; ++k) dW1[k] = fmaf(dh, feats[f * EXD + k], dW1[k]);
+    if (f == F - 1) dh_last = dh;
+  }
+  // d/d(latent of the current frame) = W1^T dh: per-thread products, reduced over the hidden units below
+#pragma unroll
+  for (int k = 0; k < EXD; ++k) sde[j][k] = mlp[EX_W1 + j * EXD + k] * dh_last;
+  __syncthreads();
+  // Adam (torch single-tensor op order, adam1) -- every thread owns row j of linear1 and column j of linear2
+#pragma unroll
+  for (int k = 0; k < EXD; ++k) { const int i = EX_W1 + j * EXD + k; adam1(mlp[i], dW1[k], adam_m[i], adam_v[i], lr_mlp, step); }
+  { const int i = EX_B1 + j; adam1(mlp[i], db1, adam_m[i], adam_v[i], lr_mlp, step); }
+#pragma unroll
+  for (int o = 0; o < EXO; ++o) { const int i = EX_W2 + o * EXH + j; adam1(mlp[i], dW2[o], adam_m[i], adam_v[i], lr_mlp, step); }
+  if (j < EXO) {
+    float db2 = 0.f;
+    for (int f = 0; f < F; ++f) db2 += sg[f * EXO + j];
+    const int i = EX_B2 + j;
+    adam1(mlp[i], db2, adam_m[i], adam_v[i], lr_mlp, step);
+  }
+  if (j < EXD) {
+    float de = 0.f;
+    for (int h = 0; h < EXH; ++h) de += sde[h][j];
+    adam1(feats[(F - 1) * EXD + j], de, adam_m[EX_N + j], adam_v[EX_N + j], lr_feat, step);
+  }
+  for (int e = j; e < F * EXO; e += EXH) g_aff[e] = 0.f;
+  __threadfence_block();
+  __syncthreads();
+  for (int f = 0; f < F; ++f) exposure_eval(mlp, feats + f * EXD, aff + f * EXO, act + f * EXH, la);
+}
+
 // ------------------------------------------------------------------ frustum feature selection
 // Mapper.get_mask_from_c2w (src/Mapper.py:120-168): project every neural point with the frame pose, bilinear
 // sensor-depth lookup (cv2.remap INTER_LINEAR, constant-0 border), keep points inside the (edge-enlarged) image
@@ -448,6 +541,8 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
       !t->fallback || !t->best_out) { set_error("psl_track_iters: missing argument"); return PSL_ERR_ARG; }
   if (!t->handle_dynamic) { set_error("psl_track_iters: tracking.handle_dynamic=False (median mask) is not built; every shipped config uses True"); return PSL_ERR_UNSUPPORTED; }
   if (t->n_pix <= 0 || t->n_pix > 65536) { set_error("psl_track_iters: n_pix must be in [1,65536]"); return PSL_ERR_ARG; }
+  const psl_exposure_args* ex = t->exposure;
+  if (ex && (!ex->mlp || !ex->feats || !ex->adam)) { set_error("psl_track_iters: incomplete exposure block"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_track_iters: index is stale"); return PSL_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   const int n = t->n_pix;
@@ -478,10 +573,19 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   psl_render_grads rg;
   memset(&rg, 0, sizeof(rg));
   rg.g_depth = b.g_depth; rg.g_rgb = b.g_rgb; rg.g_rays_o = b.g_o; rg.g_rays_d = b.g_d;
+  // sample_with_color_grad (Tracker.py:115-128): indices address the whole image, no crop
+  const int eh = t->pix_full_image ? 0 : t->edge_h, ew = t->pix_full_image ? 0 : t->edge_w;
+  float *ex_aff = nullptr, *ex_act = nullptr, *ex_g = nullptr;
+  if (ex) {   // per-frame exposure (Tracker.py:305-311): affine of this frame's latent, refreshed by k_exposure_step
+    ex_aff = ctx->d_expo; ex_act = ex_aff + 64 * EXO; ex_g = ex_act + 64 * EXH;
+    hipLaunchKernelGGL(k_exposure_fwd, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, ex_aff, ex_act);
+    PSL_LAUNCH_CHECK();
+    ra.flags |= PSL_HAS_AFFINE; ra.exposure_affine = ex_aff; rg.g_exposure_affine = ex_g;
+  }
   for (int it = 0; it < t->n_iters; ++it) {
     { ProfScope ps(ctx, PROF_MISC, s);
-      hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, t->edge_h, t->cam.H - t->edge_h,
-                         t->edge_w, t->cam.W - t->edge_w, fdev, 1, n, t->pix_idx + (size_t)it * n, t->cam_tensor, b);
+      hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, eh, t->cam.H - eh,
+                         ew, t->cam.W - ew, fdev, 1, n, t->pix_idx + (size_t)it * n, t->cam_tensor, b);
       hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), 0, s, b.gd, b.active, n);
       PSL_LAUNCH_CHECK(); }
     ra.fallback_geo = t->fallback + (size_t)it * 64;
@@ -495,6 +599,9 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     if (rc) return rc;
     hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
                        t->lr_T, t->lr_quat);
+    if (ex)
+      hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, 1, ex_g, ex_aff, ex_act, ex->adam,
+                         ex->adam + (EX_N + EXD), ex->step0 + it + 1, ex->lr_mlp, ex->lr_feat);
     PSL_LAUNCH_CHECK();
   }
   return PSL_OK;
@@ -522,6 +629,9 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   const int n = m->n_frames * m->pix_per_frame;
   if (n <= 0 || n > 65536) { set_error("psl_map_iters: n_frames*pix_per_frame must be in [1,65536]"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_map_iters: index is stale"); return PSL_ERR_STATE; }
+  const psl_exposure_args* ex = m->exposure;
+  if (ex && (!ex->mlp || !ex->feats || !ex->adam)) { set_error("psl_map_iters: incomplete exposure block"); return PSL_ERR_ARG; }
+  if (ex && m->n_frames > 64) { set_error("psl_map_iters: exposure supports windows of <= 64 frames"); return PSL_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
   float* p = m->ws;
   // Block prefetch: the mapper's rays depend on nothing it optimises (fixed poses, pre-drawn pixels), so ray set-up,
@@ -578,6 +688,13 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   rg.g_geo_feats = m->g_geo; rg.g_col_feats = m->g_col;
   rg.feat_row_map = m->row_map; rg.g_params = g_params;
   const int ncol = psl::kColorFloats;
+  float *ex_aff = nullptr, *ex_act = nullptr, *ex_g = nullptr;
+  if (ex) {   // per-frame affines of the window (Mapper.py:530-548); refreshed by k_exposure_step after every update
+    ex_aff = ctx->d_expo; ex_act = ex_aff + 64 * EXO; ex_g = ex_act + 64 * EXH;
+    PSL_HIP(hipMemsetAsync(ex_g, 0, sizeof(float) * 64 * EXO, s));
+    hipLaunchKernelGGL(k_exposure_fwd, dim3(m->n_frames), dim3(128), 0, s, ex->mlp, ex->feats, ex_aff, ex_act);
+    PSL_LAUNCH_CHECK();
+  }
   for (int it = 0; it < m->n_iters; ++it) {
     // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
     const bool color_stage = it > m->n_geo_iters;
@@ -599,6 +716,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
     ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
     ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
+    if (ex && color_stage) ra.flags |= PSL_NO_SIGMOID;   // raw logits; affine + sigmoid per frame slice in the ray kernel
     ra.fallback_geo = m->fallback + (size_t)it * 64;
     ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
     // the forward weights only change after the decoder was stepped (colour stage with train_decoder)
@@ -611,7 +729,8 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       rc = launch_map_ray_fused((const float4*)rw.raw, ctx->pre_cnt, b.gd, b.gc, b.active, ctx->cfg.near_end_surface,
                                 ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, n, m->sigmoid_coef, m->w_color,
                                 color_stage ? 1 : 0, b.depth, b.var, b.rgb, b.valid, (float4*)rw.d_raw,
-                                ctx->loss_acc + 4 * (size_t)it, ctx->d_small, s);
+                                ctx->loss_acc + 4 * (size_t)it, ctx->d_small, (ex && color_stage) ? ex_aff : nullptr,
+                                m->pix_per_frame, ex_g, s);
       if (rc) return rc;
     }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
@@ -638,8 +757,15 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
           sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
         }
       }
-      rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s);
+      rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
+                           st + m->step0_params);
       if (rc) return rc;
+      if (ex && color_stage) {   // mlp_exposure is part of color_decoder.parameters() (decoders_lr); latent lr 0.001
+        hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, m->n_frames, ex_g, ex_aff, ex_act,
+                           ex->adam, ex->adam + (EX_N + EXD), ex->step0 + (it - m->n_geo_iters),
+                           m->train_decoder ? ex->lr_mlp : 0.f, ex->lr_feat);
+        PSL_LAUNCH_CHECK();
+      }
     }
   }
   if (m->loss_out) {

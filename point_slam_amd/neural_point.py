@@ -6,8 +6,13 @@ of FAISS-GPU, with device-resident positions instead of Python lists.
 Deviations, all documented in DESIGN.md:
   * the search is exact (FAISS IVF nprobe=4 is approximate); `nlist`/`nprobe` are ignored;
   * find_neighbors_faiss returns (inf, -1) in slots beyond the query radius;
-  * cloud_pos() returns a [N,3] device tensor (the reference returns a list of lists;
-    its callers immediately do torch.tensor(...) on it, Mapper.py:336-337, Tracker.py:198-199).
+  * cloud_pos() returns a [N,3] float32 CPU tensor instead of a list of lists: every reference caller wraps it
+    at once -- np.array(...) (Mapper.py:131,760), torch.tensor(..., device=...) (Mapper.py:336-337,
+    Tracker.py:198-199) -- or stores it (Logger.py:25), and all of these accept a CPU tensor.
+    cloud_pos_device() is the no-copy-to-host variant the native loops and tests use;
+  * features live in ONE pre-allocated [max_points, 32] store per set; geo_feats / col_feats are views of its first
+    N rows, so appending points writes the new rows in place instead of re-concatenating 128 MB tensors
+    (neural_point.py:155-159 does torch.cat per call).
 """
 from __future__ import annotations
 
@@ -37,10 +42,14 @@ class HipNeuralPointCloud(object):
             raise NotImplementedError("N_add must be 3")
         self.near_end_surface = cfg['pointcloud']['near_end_surface']
         self.far_end_surface = cfg['pointcloud']['far_end_surface']
-        self._input_pos = []
-        self._input_rgb = []
+        self._input_pos = []          # device tensors [k,3], one per add call (neural_point.py:123)
+        self._input_rgb = []          # device tensors [k,3], colour * 255 (neural_point.py:109,124)
         self.geo_feats = None
         self.col_feats = None
+        self._geo_store = None        # [max_points, c_dim] backing stores; geo_feats / col_feats are views [:N]
+        self._col_store = None
+        self._rad_store = None        # [max_points] add-radius of the location a point belongs to (multi-GPU dedupe)
+        self._max_points = int(max_points)
         self.keyframe_dict = []
 
         pc = cfg['pointcloud']
@@ -76,18 +85,29 @@ class HipNeuralPointCloud(object):
     def handle(self):
         return self._h
 
-    def cloud_pos(self, index=None):
+    def cloud_pos_device(self, first=0, count=None):
+        """Positions [count,3] of points [first, first+count) as a device tensor (no host copy)."""
         n = self.pts_num()
-        out = torch.empty(n, 3, device=self.device, dtype=torch.float32)
-        if n:
-            _lib.check(_lib.lib().psl_points_download(self._h, _lib.ptr(out), n, _lib.stream_ptr()), "download")
-        return out if index is None else out[index]
+        count = n - first if count is None else count
+        out = torch.empty(count, 3, device=self.device, dtype=torch.float32)
+        if count:
+            _lib.check(_lib.lib().psl_points_download_range(self._h, int(first), int(count), _lib.ptr(out),
+                                                            _lib.stream_ptr()), "psl_points_download_range")
+        return out
+
+    def cloud_pos(self, index=None):
+        """neural_point.py:44-47.  A CPU float32 tensor [N,3] (see the module docstring): np.array(...),
+        torch.tensor(..., device=...), .tolist() and indexing all behave as on the reference's list of lists."""
+        if index is not None:
+            return self.cloud_pos_device(int(index), 1)[0].cpu()
+        return self.cloud_pos_device().cpu()
 
     def input_pos(self):
-        return self._input_pos
+        """neural_point.py:49-50: surface points of every added location, list of [x,y,z]."""
+        return torch.cat(self._input_pos).cpu().tolist() if self._input_pos else []
 
     def input_rgb(self):
-        return self._input_rgb
+        return torch.cat(self._input_rgb).cpu().tolist() if self._input_rgb else []
 
     def pts_num(self):
         return _lib.lib().psl_points_count(self._h)
@@ -115,7 +135,7 @@ class HipNeuralPointCloud(object):
             self.geo_feats[indices] = feats.detach().clone()
         else:
             assert feats.shape[0] == self.geo_feats.shape[0], 'feature shape[0] mismatch'
-            self.geo_feats = feats.detach().clone()
+            self.geo_feats.copy_(feats.detach())          # stays a view of the pre-allocated store
 
     def update_col_feats(self, feats, indices=None):
         assert torch.is_tensor(feats), 'use tensor to update features'
@@ -123,32 +143,62 @@ class HipNeuralPointCloud(object):
             self.col_feats[indices] = feats.detach().clone()
         else:
             assert feats.shape[0] == self.col_feats.shape[0], 'feature shape[0] mismatch'
-            self.col_feats = feats.detach().clone()
+            self.col_feats.copy_(feats.detach())
+
+    def _append_feats(self, gnew, cnew, radius=None):
+        """Write new feature rows behind the current ones in the pre-allocated stores (no torch.cat of the map)."""
+        n_old = 0 if self.geo_feats is None else self.geo_feats.shape[0]
+        k = gnew.shape[0]
+        if self._geo_store is None:
+            self._geo_store = torch.empty(self._max_points, self.c_dim, device=self.device, dtype=torch.float32)
+            self._col_store = torch.empty(self._max_points, self.c_dim, device=self.device, dtype=torch.float32)
+            self._rad_store = torch.empty(self._max_points, device=self.device, dtype=torch.float32)
+        if n_old + k > self._max_points:
+            raise _lib.PslError(f"feature capacity {self._max_points} exceeded ({n_old} + {k})")
+        self._geo_store[n_old:n_old + k] = gnew
+        self._col_store[n_old:n_old + k] = cnew
+        self._rad_store[n_old:n_old + k] = self.radius_add if radius is None else radius
+        self.geo_feats = self._geo_store[:n_old + k]
+        self.col_feats = self._col_store[:n_old + k]
+
+    def point_radius(self, first=0, count=None):
+        """Add-radius of the location each point was created for (dynamic r_add of its pixel, radius_min for
+        gradient pixels, radius_add otherwise): what the cross-rank dedupe of the multi-GPU exchange tests with."""
+        n = self.pts_num()
+        count = n - first if count is None else count
+        return self._rad_store[first:first + count]
+
+    def locations_free(self, loc, radius):
+        """True where a surface point has NO existing neural point strictly inside its radius: the admission test
+        of add_neural_points (neural_point.py:116-121) for externally supplied locations."""
+        _, _, cnt = self.find_neighbors_faiss(loc, step='add', dynamic_radius=radius)
+        return cnt == 0
 
     # ---- state upload (checkpoint / multi-GPU merge) ------------------------------------
     def set_points(self, pos: torch.Tensor, geo_feats: torch.Tensor = None, col_feats: torch.Tensor = None):
         """Replace the cloud by `pos` [N,3] (device tensor) and rebuild the index."""
         L = _lib.lib()
         _lib.check(L.psl_points_reset(self._h))
+        if geo_feats is not None:
+            self.geo_feats = self.col_feats = None
         self.append_points(pos, geo_feats, col_feats)
 
     def truncate(self, n: int):
-        """Keep the first n points (positions and features); used by the multi-GPU merge."""
+        """Keep the first n points (positions and features); used by the multi-GPU merge.  O(1): views shrink."""
         _lib.check(_lib.lib().psl_points_truncate(self._h, int(n)), "psl_points_truncate")
         if self.geo_feats is not None:
-            self.geo_feats = self.geo_feats[:n].contiguous()
-            self.col_feats = self.col_feats[:n].contiguous()
+            self.geo_feats = self._geo_store[:n]
+            self.col_feats = self._col_store[:n]
 
-    def append_points(self, pos, geo_feats=None, col_feats=None):
+    def append_points(self, pos, geo_feats=None, col_feats=None, build=True, radius=None):
         pos = pos.to(self.device, torch.float32).contiguous()
         n = pos.shape[0]
         if n:
             _lib.check(_lib.lib().psl_points_append(self._h, _lib.ptr(pos), n, _lib.stream_ptr()), "append")
         if geo_feats is not None:
-            gf, cf = geo_feats.to(self.device).float(), col_feats.to(self.device).float()
-            self.geo_feats = gf.clone() if self.geo_feats is None else torch.cat([self.geo_feats, gf], 0)
-            self.col_feats = cf.clone() if self.col_feats is None else torch.cat([self.col_feats, cf], 0)
-        self._build()
+            self._append_feats(geo_feats.to(self.device).float(), col_feats.to(self.device).float(), radius)
+        if build:
+            self._build()
 
     def _build(self):
         _lib.check(_lib.lib().psl_index_build(self._h, _lib.stream_ptr()), "psl_index_build")
@@ -176,12 +226,15 @@ class HipNeuralPointCloud(object):
         # features ~ N(0, 0.1^2), geometry first then colour (neural_point.py:149-159)
         gnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
         cnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
-        if self.geo_feats is None:
-            self.geo_feats, self.col_feats = gnew, cnew
-        else:
-            self.geo_feats = torch.cat([self.geo_feats, gnew], 0)
-            self.col_feats = torch.cat([self.col_feats, cnew], 0)
-        self._build()
+        kb = keep.bool()
+        rad_new = (rad[kb] if rad is not None else torch.full((kept.value,), float(r_scalar), device=ro.device))
+        self._append_feats(gnew, cnew, rad_new.repeat_interleave(3))
+        # surface point and colour*255 of every kept location (neural_point.py:109,113,123-124; exported by
+        # Mapper.py:757-758 and the checkpoint)
+        self._input_pos.append((ro + rd * dep[:, None])[kb])
+        self._input_rgb.append((batch_gt_color.detach().to(ro.device) * 255)[kb].float())
+        if kept.value:
+            self._build()
         if return_new:
             return kept.value, keep.bool(), n_before
         return torch.tensor(kept.value, device=self.device)

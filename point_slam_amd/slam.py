@@ -11,9 +11,11 @@ and frustum feature selection, driven from Python but with two engines:
                    calling HipRenderer.render_batch_ray -- what a user gets by swapping only the
                    Renderer / NeuralPointCloud classes (parity path).
 
-Keyframe selection uses the reference's 'global' rule (random keyframes + the last
-one + the current frame, Mapper.py:263-276); the 'overlap' rule and BA are host
-logic outside the hot path.
+Around the loops `HipSLAM.map` reproduces the per-mapped-frame logic of Mapper.optimize_map / Mapper.run:
+uniform + colour-gradient point adding (Mapper.py:306-330), frustum feature selection (:120-168), keyframe
+selection by overlap or at random (:170-235,263-276), the first-frame schedule (`iters_first`, `geo_iter_first`,
+the `init` LR table, :420,424), the data-dependent iteration count (:404-406) and, for `model.encode_exposure`,
+the per-frame exposure latents (:399-401,530-548; Tracker.py:305-311).  BA is not built (off in every config).
 """
 from __future__ import annotations
 
@@ -31,13 +33,15 @@ from .renderer import HipRenderer
 class Frame:
     """One RGB-D frame resident on the device."""
 
-    def __init__(self, idx, depth, color, r_add=None, r_query=None, c2w=None):
+    def __init__(self, idx, depth, color, r_add=None, r_query=None, c2w=None, exposure=None):
         self.idx = idx
         self.depth = depth.float().contiguous()
         self.color = color.float().contiguous()
         self.r_add = r_add.float().contiguous() if r_add is not None else None
         self.r_query = r_query.float().contiguous() if r_query is not None else None
         self.c2w = c2w            # [4,4] estimated pose (device tensor)
+        self.exposure = exposure  # [8] exposure latent of a keyframe (model.encode_exposure)
+        self.grad_mag = None      # [H,W] f64 colour-gradient magnitude, filled on demand
 
     def view(self) -> _lib.psl_frame_view:
         v = _lib.psl_frame_view()
@@ -63,12 +67,10 @@ def camera_tensor_from_c2w(c2w: torch.Tensor) -> torch.Tensor:
 class HipSLAM:
     def __init__(self, cfg, cam: dict, device="cuda:0", max_points=2_500_000, engine="native", decoders=None):
         self.cfg, self.cam, self.device, self.engine = cfg, cam, torch.device(device), engine
-        if cfg["model"].get("encode_exposure", False):
-            # the per-frame exposure vectors of the ScanNet config (Mapper.py:530-548, Tracker.py:305-311) are
-            # optimised by the reference's own loops; the drop-in classes support them (HipRenderer), the fused
-            # native / drop-in loops of this class do not carry them yet
-            raise NotImplementedError("HipSLAM: model.encode_exposure is supported through the drop-in HipRenderer "
-                                      "inside the reference's Tracker/Mapper, not by the HipSLAM loops")
+        self.encode_exposure = bool(cfg["model"].get("encode_exposure", False))
+        if self.encode_exposure and engine != "native":
+            raise NotImplementedError("HipSLAM(engine='dropin') does not carry the per-frame exposure latents; use the "
+                                      "native engine, or HipRenderer inside the reference's own Tracker/Mapper")
         cfgd = dict(cfg)
         cfgd["mapping"] = dict(cfg["mapping"], device=str(device))
         self.npc = HipNeuralPointCloud(cfgd, max_points=max_points, device=str(device))
@@ -87,6 +89,19 @@ class HipSLAM:
         self._ws_map = None
         self.last_losses = None
         self.map_step = dict(geo=0, col=0)
+        self.n_mapped = 0
+        # torch 1.12 (the reference's env.yaml) keeps zero .grad tensors after zero_grad(): from the second mapped frame
+        # on its Adam counts the geometry-stage iterations for the colour decoder as well.  "torch2" (None gradients,
+        # what the fixtures of this repo were generated with) is the default; see psl_map_args.step0_params.
+        self.adam_zero_grad_semantics = "torch2"
+        if self.encode_exposure:
+            # MLP_exposure weights live outside the master blob (decoder.py:243-258); shared latent as in
+            # Point_SLAM.py:85-87 (N(0, 0.01^2))
+            ex = self.decoders.color_decoder.mlp_exposure
+            self.exposure_mlp = torch.cat([ex.linear1.weight.reshape(-1), ex.linear1.bias, ex.linear2.weight.reshape(-1),
+                                           ex.linear2.bias]).detach().float().clone().contiguous()
+            assert self.exposure_mlp.numel() == _lib.EXPOSURE_MLP_FLOATS
+            self.exposure_feat = torch.zeros(cfg["model"]["exposure_dim"], device=self.device).normal_(0, 0.01)
 
     # ------------------------------------------------------------------ state
     def seed_points(self, pos: torch.Tensor, seed=1219):
@@ -102,6 +117,35 @@ class HipSLAM:
             named = dict(self.decoders.named_parameters())
             for name, t in P_.unpack_master(self.theta).items():
                 named[name].copy_(t)
+            if self.encode_exposure:
+                ex, m = self.decoders.color_decoder.mlp_exposure, self.exposure_mlp
+                ex.linear1.weight.copy_(m[:1024].reshape(128, 8)); ex.linear1.bias.copy_(m[1024:1152])
+                ex.linear2.weight.copy_(m[1152:2688].reshape(12, 128)); ex.linear2.bias.copy_(m[2688:2700])
+
+    def sync_theta_from_decoders(self):
+        """The opposite direction (after load_state_dict): repack the native blob and the colour Fourier matrix."""
+        self.theta = P_.pack_master(self.decoders).detach().clone().contiguous()
+        self.Bcol = P_.color_embed_B(self.decoders).to(self.device).float().contiguous()
+        if self.encode_exposure:
+            ex = self.decoders.color_decoder.mlp_exposure
+            self.exposure_mlp = torch.cat([ex.linear1.weight.reshape(-1), ex.linear1.bias, ex.linear2.weight.reshape(-1),
+                                           ex.linear2.bias]).detach().float().clone().contiguous()
+
+    def save_checkpoint(self, path, idx=0, **kw):
+        """Logger.log schema (src/utils/Logger.py:20-40) with the decoders AS TRAINED by the native loops."""
+        from . import checkpoint as CK
+        self.sync_decoders_from_theta()
+        torch.cuda.synchronize()
+        CK.save_checkpoint(path, self.npc, self.decoders, idx=idx, **kw)
+
+    def load_checkpoint(self, path_or_dict):
+        from . import checkpoint as CK
+        ck = torch.load(path_or_dict, map_location=self.device, weights_only=False) if isinstance(path_or_dict, str) \
+            else path_or_dict
+        CK.load_neural_point_cloud(self.npc, ck)
+        CK.load_decoders(self.decoders, ck)
+        self.sync_theta_from_decoders()
+        return ck
 
     # ------------------------------------------------------------------ tracking
     def track(self, frame: Frame, cam0: torch.Tensor, n_iters=None, n_pix=None) -> torch.Tensor:
@@ -119,11 +163,45 @@ class HipSLAM:
         fb = torch.zeros(n_iters, 2, 32, device=self.device).normal_(mean=0, std=0.01)
         return idx, fb
 
-    def _track_native(self, frame, cam0, n_iters, n_pix):
+    def grad_mag(self, frame: Frame):
+        if frame.grad_mag is None:
+            from . import frame_ops
+            _, _, frame.grad_mag = frame_ops.dynamic_radius_maps(frame.color, self.cfg, with_grad_mag=True)
+        return frame.grad_mag
+
+    def color_grad_draws(self, frame: Frame, n_iters, n_pix):
+        """sample_with_color_grad (Tracker.py:281-285,115-128): the top 15*n_pix gradient pixels inside the border with
+        sensor depth, then n_pix of them WITHOUT replacement per iteration (np.random.choice(..., replace=False))."""
+        from . import frame_ops
+        tr, cam = self.cfg["tracking"], self.cam
+        eh, ew = tr["ignore_edge_H"], tr["ignore_edge_W"]
+        sel, _ = frame_ops.get_selected_index_with_grad(self.npc, eh, cam["H"] - eh, ew, cam["W"] - ew, n_pix, frame.color,
+                                                        gt_depth=frame.depth, depth_limit=bool(tr.get("depth_limit", False)),
+                                                        grad_mag=self.grad_mag(frame))
+        if sel.numel() < n_pix:
+            raise RuntimeError(f"sample_with_color_grad: only {sel.numel()} candidate pixels for {n_pix} samples")
+        pick = torch.rand(n_iters, sel.numel(), device=self.device).topk(n_pix, dim=1).indices
+        return sel[pick].to(torch.int32).contiguous()
+
+    def _exposure_block(self, feats, lr_mlp, lr_feat=0.001):
+        """psl_exposure_args over the shared MLP blob and `feats` ([8] or [F,8]); returns (struct, keep-alive)."""
+        adam = torch.zeros(2, _lib.EXPOSURE_MLP_FLOATS + _lib.EXPOSURE_DIM, device=self.device)
+        e = _lib.psl_exposure_args(mlp=self.exposure_mlp.data_ptr(), feats=feats.data_ptr(), adam=adam.data_ptr(),
+                                   lr_mlp=lr_mlp, lr_feat=lr_feat, step0=0)
+        return e, (adam, feats)
+
+    def _track_native(self, frame, cam0, n_iters, n_pix, draws=None):
         L = _lib.lib()
         tr, cam = self.cfg["tracking"], self.cam
         eh, ew = tr["ignore_edge_H"], tr["ignore_edge_W"]
-        idx, fb = self._draws(n_iters, n_pix, (cam["H"] - 2 * eh) * (cam["W"] - 2 * ew))
+        full = bool(tr.get("sample_with_color_grad", False))
+        if draws is not None:
+            idx, fb = draws
+        elif full:
+            idx = self.color_grad_draws(frame, n_iters, n_pix)
+            fb = torch.zeros(n_iters, 2, 32, device=self.device).normal_(mean=0, std=0.01)
+        else:
+            idx, fb = self._draws(n_iters, n_pix, (cam["H"] - 2 * eh) * (cam["W"] - 2 * ew))
         need = int(L.psl_track_ws_floats(n_pix))
         if self._ws_track is None or self._ws_track.numel() < need:
             self._ws_track = torch.empty(need, device=self.device)
@@ -145,8 +223,16 @@ class HipSLAM:
         a.geo_feats, a.col_feats = self.npc.geo_feats.data_ptr(), self.npc.col_feats.data_ptr()
         a.params, a.col_embed_B = self.theta.data_ptr(), self.Bcol.data_ptr()
         a.ws, a.loss_out, a.best_out = self._ws_track.data_ptr(), losses.data_ptr(), best.data_ptr()
+        a.pix_full_image = 1 if full else 0
+        keep_ex = None
+        if self.encode_exposure:        # Tracker.py:269-271,305-311: latent cloned from the shared one, lr 0.001 for both
+            ex_feat = self.exposure_feat.clone().contiguous()
+            ex, keep_ex = self._exposure_block(ex_feat, 0.001)
+            a.exposure = C.pointer(ex)
         _lib.check(L.psl_track_iters(self.npc.handle, C.byref(a), _lib.stream_ptr()), "psl_track_iters")
-        self._keep = (idx, fb, cam_t, adam)          # alive until the stream has consumed them
+        if self.encode_exposure:
+            self.exposure_feat = ex_feat                 # exposure_feat_shared[0] = ... (Tracker.py:385-387)
+        self._keep = (idx, fb, cam_t, adam, keep_ex)     # alive until the stream has consumed them
         self.last_losses = losses
         self.last_cam = cam_t
         return best[:7]
@@ -197,21 +283,45 @@ class HipSLAM:
         return best
 
     # ------------------------------------------------------------------ mapping
-    def add_points(self, frame: Frame, c2w: torch.Tensor, n_pixels=None):
-        """Point adding of Mapper.optimize_map (Mapper.py:306-320): uniformly sampled pixels, dedupe radius
-        from the per-pixel dynamic r_add map."""
-        mp, cam, dev = self.cfg["mapping"], self.cam, self.device
-        n = n_pixels or mp["pixels_adding"]
-        idx = torch.randint(cam["H"] * cam["W"], (n,), device=dev)
+    def _add_batch(self, frame, c2w, idx, is_pts_grad):
+        cam = self.cam
         u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
         ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
         ui, vi = u.long(), v.long()
         gd, gc = frame.depth[vi, ui], frame.color[vi, ui]
-        rad = frame.r_add[vi, ui] if self.cfg["use_dynamic_radius"] else None
-        return int(self.npc.add_neural_points(ro.contiguous(), rd.contiguous(), gd, gc, dynamic_radius=rad))
+        keep = gd > 0                                            # depth_filter=True (Mapper.py:311-313)
+        rad = frame.r_add[vi, ui][keep] if self.cfg["use_dynamic_radius"] else None
+        return int(self.npc.add_neural_points(ro[keep].contiguous(), rd[keep].contiguous(), gd[keep], gc[keep],
+                                              is_pts_grad=is_pts_grad, dynamic_radius=rad))
+
+    def add_points(self, frame: Frame, c2w: torch.Tensor, n_pixels=None, first=False):
+        """Point adding of Mapper.optimize_map (Mapper.py:303-330): `pixels_adding` uniformly drawn pixels (scaled by
+        (median depth / 2.5)^2, clamped to [1,3]x, on the first frame) against the per-pixel r_add map, then
+        `pixels_based_on_color_grad` pixels from the top-gradient set against radius_min
+        (get_samples_with_pixel_grad, common.py:186-222).  Returns the number of new LOCATIONS."""
+        mp, cam, dev = self.cfg["mapping"], self.cam, self.device
+        n = n_pixels or mp["pixels_adding"]
+        if first:
+            valid = frame.depth[frame.depth > 0]
+            scale = float((valid.median() / 2.5) ** 2) if valid.numel() else 1.0
+            n = int(min(max(n * scale, n), 3 * n))
+        idx = torch.randint(cam["H"] * cam["W"], (n,), device=dev)
+        added = self._add_batch(frame, c2w, idx, False)
+        n_grad = int(mp.get("pixels_based_on_color_grad", 0))
+        if n_grad > 0:
+            # get_sample_uv_with_grad (common.py:92-113): n_grad of the top 5*n_grad gradient pixels, without replacement
+            from . import frame_ops
+            sel, _ = frame_ops.get_selected_index_with_grad(self.npc, 0, cam["H"], 0, cam["W"], n_grad, frame.color,
+                                                            ratio=5, grad_mag=self.grad_mag(frame))
+            if sel.numel() >= n_grad:
+                pick = torch.randperm(sel.numel(), device=dev)[:n_grad]
+                added += self._add_batch(frame, c2w, sel[pick], True)
+        return added
 
     def frustum_select(self, frame: Frame, c2w: torch.Tensor):
-        """Mapper.get_mask_from_c2w (Mapper.py:120-168) on the device: returns (sel int32[n_sel], row_map int32[N])."""
+        """Mapper.get_mask_from_c2w (Mapper.py:120-168) on the device: returns (sel int32[n_sel], row_map int32[N]).
+        Points whose bilinear depth lookup is 0 take the maximum over the per-point lookups (:161-162); the image
+        maximum bounds it from above and is what the kernel is given."""
         L = _lib.lib()
         N = self.npc.pts_num()
         sel = torch.empty(N, dtype=torch.int32, device=self.device)
@@ -225,33 +335,62 @@ class HipSLAM:
                    "psl_frustum_select_sync")
         return sel[:n_sel.value], row_map
 
-    def select_window(self, frame: Frame) -> List[Frame]:
-        """'global' keyframe selection (Mapper.py:263-276): window-2 random keyframes + last keyframe + current."""
-        k = self.cfg["mapping"]["mapping_window_size"] - 2
+    def select_window(self, frame: Frame, c2w=None) -> List[Frame]:
+        """Keyframe selection of Mapper.optimize_map (:263-276): mapping_window_size-2 keyframes among all but the last
+        one -- at random ('global', random_select) or among those that overlap the current view ('overlap',
+        keyframe_selection_overlap :170-235: 200 pixels x 8 frustum samples projected into every keyframe, the
+        overlapping ones in random order) -- then the last keyframe and the current frame."""
+        mp = self.cfg["mapping"]
+        k = mp["mapping_window_size"] - 2
         win: List[Frame] = []
         if len(self.keyframes) > 0:
-            if len(self.keyframes) > 1:
-                perm = torch.randperm(len(self.keyframes) - 1)[:k].tolist()
-                win += [self.keyframes[i] for i in perm]
+            older = self.keyframes[:-1]
+            if older and k > 0:
+                if mp.get("keyframe_selection_method", "overlap") == "overlap" and c2w is not None:
+                    from . import frame_ops
+                    cam = self.cam
+                    idx = torch.randint(cam["H"] * cam["W"], (200,), device=self.device)
+                    u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
+                    ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+                    gd = frame.depth[v.long(), u.long()]
+                    keep = gd > 0
+                    ids = frame_ops.keyframe_selection_overlap(ro[keep].contiguous(), rd[keep].contiguous(), gd[keep],
+                                                               [f.c2w for f in older], cam, k)
+                    win += [older[int(i)] for i in ids]
+                else:
+                    perm = torch.randperm(len(older))[:k].tolist()
+                    win += [older[i] for i in perm]
             win.append(self.keyframes[-1])
         win.append(frame)
         return win
 
-    def map(self, frame: Frame, c2w: torch.Tensor, n_iters=None, add=True):
+    def mapping_iters(self, n_iters, pts_added, first):
+        """Mapper.py:404-406: clip(iters * pts_added / 300, min_iter_ratio * iters, 2 * iters) after the first frame."""
+        if first:
+            return n_iters
+        lo = int(self.cfg["mapping"].get("min_iter_ratio", 0.95) * n_iters)
+        return int(min(max(int(n_iters * pts_added / 300), lo), 2 * n_iters))
+
+    def map(self, frame: Frame, c2w: torch.Tensor, n_iters=None, add=True, first=False, fixed_iters=False):
+        """One Mapper.optimize_map call.  first: the idx == 0 schedule (`iters_first`, `geo_iter_first`, `init` LRs)."""
         mp = self.cfg["mapping"]
         frame.c2w = c2w
-        added = self.add_points(frame, c2w) if add else 0
-        n_iters = n_iters or mp["iters"]
+        window = self.select_window(frame, c2w)
+        added = self.add_points(frame, c2w, first=first) if add else 0
+        n_iters = n_iters or (mp["iters_first"] if first else mp["iters"])
+        if not fixed_iters:
+            n_iters = self.mapping_iters(n_iters, added, first)
+        n_geo = mp["geo_iter_first"] if first else int(n_iters * mp["geo_iter_ratio"])
         sel, row_map = self.frustum_select(frame, c2w)
-        window = self.select_window(frame)
         pix_per_frame = mp["pixels"] // len(window)
         if self.engine == "native":
-            self._map_native(window, sel, row_map, n_iters, pix_per_frame)
+            self._map_native(window, sel, row_map, n_iters, pix_per_frame, n_geo=n_geo, first=first)
         else:
             self._map_dropin(window, sel, n_iters, pix_per_frame)
+        self.n_mapped += 1
         return added, int(sel.shape[0])
 
-    def _map_native(self, window, sel, row_map, n_iters, ppf, draws=None):
+    def _map_native(self, window, sel, row_map, n_iters, ppf, draws=None, n_geo=None, first=False):
         L = _lib.lib()
         mp, cam, dev = self.cfg["mapping"], self.cam, self.device
         W = len(window)
@@ -269,11 +408,11 @@ class HipSLAM:
         adam_par = torch.zeros(2, ncol, device=dev)
         losses = torch.empty(n_iters, 4, device=dev)
         views = (_lib.psl_frame_view * W)(*[f.view() for f in window])
-        st = mp["stage"]
+        st = mp["init" if first else "stage"]
         a = _lib.psl_map_args()
         a.cam = self.cam_intr
         a.n_frames, a.pix_per_frame, a.n_iters = W, ppf, n_iters
-        a.n_geo_iters = int(n_iters * mp["geo_iter_ratio"])
+        a.n_geo_iters = int(n_iters * mp["geo_iter_ratio"]) if n_geo is None else int(n_geo)
         a.frames = views
         a.pix_idx, a.fallback = idx.data_ptr(), fb.data_ptr()
         a.geo_feats, a.col_feats = self.npc.geo_feats.data_ptr(), self.npc.col_feats.data_ptr()
@@ -282,13 +421,25 @@ class HipSLAM:
         a.g_geo, a.g_col = g_geo.data_ptr(), g_col.data_ptr()
         a.adam_geo, a.adam_col, a.adam_params = adam_geo.data_ptr(), adam_col.data_ptr(), adam_par.data_ptr()
         a.step0_geo, a.step0_col = 0, 0
+        a.step0_params = (a.n_geo_iters + 1) if (self.adam_zero_grad_semantics == "torch1" and self.n_mapped > 0) else 0
         a.train_decoder = 0 if mp["fix_color_decoder"] else 1
         a.lr_geo_geo_stage, a.lr_geo_color_stage = st["geometry"]["geometry_lr"], st["color"]["geometry_lr"]
         a.lr_col, a.lr_decoder = st["color"]["color_lr"], st["color"]["decoders_lr"]
         a.w_color, a.sigmoid_coef = mp["w_color_loss"], self.cfg["rendering"]["sigmoid_coef_mapper"]
         a.ws, a.loss_out = self._ws_map.data_ptr(), losses.data_ptr()
+        keep_ex = None
+        if self.encode_exposure:
+            # one latent per window frame; the current frame's is cloned from the shared one, optimised (lr 0.001) and
+            # written back (Mapper.py:341-343,399-401,624-626)
+            feats = torch.stack([(f.exposure if f.exposure is not None else self.exposure_feat).to(dev).float()
+                                 for f in window[:-1]] + [self.exposure_feat.float()]).contiguous()
+            ex, keep_ex = self._exposure_block(feats, st["color"]["decoders_lr"])
+            a.exposure = C.pointer(ex)
         _lib.check(L.psl_map_iters(self.npc.handle, C.byref(a), _lib.stream_ptr()), "psl_map_iters")
-        self._keep_map = (idx, fb, g_geo, g_col, adam_geo, adam_col, adam_par, views, sel, row_map)
+        if self.encode_exposure:
+            self.exposure_feat = feats[-1].clone()
+            window[-1].exposure = feats[-1].clone()
+        self._keep_map = (idx, fb, g_geo, g_col, adam_geo, adam_col, adam_par, views, sel, row_map, keep_ex)
         self.last_losses = losses
 
     def _map_dropin(self, window, sel, n_iters, ppf, draws=None):

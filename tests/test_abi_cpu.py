@@ -116,3 +116,43 @@ def test_argument_errors_are_reported_not_thrown():
     assert L.psl_track_iters(none, None, none) < 0 and L.psl_map_iters(none, None, none) < 0
     with pytest.raises(_lib.PslError):
         _lib.check(L.psl_points_append(none, none, 1, none), "psl_points_append")
+
+
+def test_struct_layouts_match_ctypes(tmp_path):
+    """sizeof / offsetof of every boundary struct as gcc lays it out == the ctypes mirror in point_slam_amd/_lib.py
+    (a drifted binding would pass garbage pointers to the device)."""
+    import shutil
+    import subprocess
+    import ctypes as C
+    from point_slam_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = ["psl_config", "psl_render_args", "psl_render_grads", "psl_cam_intr", "psl_frame_view", "psl_exposure_args",
+               "psl_track_args", "psl_map_args"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "pointslam_hip.h"', "int main(void) {"]
+    for sname in structs:
+        cls = getattr(_lib, sname)
+        lines.append(f'  printf("{sname} %zu\\n", sizeof({sname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{sname}.{fname} %zu\\n", offsetof({sname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for sname in structs:
+        cls = getattr(_lib, sname)
+        assert int(got[sname]) == C.sizeof(cls), sname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{sname}.{fname}"]) == getattr(cls, fname).offset, (sname, fname)
+    # the header declares no field the binding lacks
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pointslam_hip.h")).read(), flags=re.S)
+    for sname in structs:
+        body = re.search(r"typedef struct " + sname + r" \{(.*?)\} " + sname + ";", hdr, flags=re.S).group(1)
+        n_decl = 0
+        for stmt in body.split(";"):
+            stmt = stmt.strip()
+            if stmt:
+                n_decl += stmt.count(",") + 1
+        assert n_decl == len(getattr(_lib, sname)._fields_), (sname, n_decl)

@@ -1,5 +1,7 @@
-"""CPU, world_size=2, gloo: the multi-GPU exchange step (all-gather-v of newly added neural points and the
-rank-ordered rebuild) -- the N>1 path that the driver runs on RCCL at round end."""
+"""CPU, world_size=2, gloo: the multi-GPU exchange step -- all-gather-v of newly added neural points, the cross-rank
+dedupe in rank order, the rank-ordered rebuild, and the reconciliation of features / colour decoder that several
+ranks optimised -- the N>1 path that the driver runs on RCCL at round end.  (The same code on the real
+HipNeuralPointCloud with two ranks sharing cuda:0: tests/test_hip_dist.py, -m gpu.)"""
 import os
 import socket
 
@@ -9,43 +11,71 @@ import torch.multiprocessing as mp
 
 
 class FakeCloud:
-    """Host stand-in with the HipNeuralPointCloud methods merge_new_points touches."""
+    """Host stand-in with the HipNeuralPointCloud methods the exchange touches (brute-force neighbour test)."""
 
-    def __init__(self, pos, geo, col):
+    def __init__(self, pos, geo, col, rad=None):
         self.pos, self.geo, self.col = pos, geo, col
+        self.rad = rad if rad is not None else torch.full((pos.shape[0],), 0.04)
 
     def pts_num(self): return self.pos.shape[0]
-    def cloud_pos(self): return self.pos
+    def cloud_pos_device(self, first=0, count=None): return self.pos[first:(None if count is None else first + count)]
     def get_geo_feats(self): return self.geo
     def get_col_feats(self): return self.col
+    def point_radius(self, first=0, count=None): return self.rad[first:(None if count is None else first + count)]
+
+    def locations_free(self, loc, radius):
+        d2 = ((loc[:, None, :] - self.pos[None]) ** 2).sum(-1)
+        return (d2 < (radius * radius)[:, None]).sum(1) == 0
 
     def truncate(self, n):
-        self.pos, self.geo, self.col = self.pos[:n], self.geo[:n], self.col[:n]
+        self.pos, self.geo, self.col, self.rad = self.pos[:n], self.geo[:n], self.col[:n], self.rad[:n]
 
-    def append_points(self, p, g, c):
-        self.pos, self.geo, self.col = torch.cat([self.pos, p]), torch.cat([self.geo, g]), torch.cat([self.col, c])
+    def append_points(self, p, g, c, build=True, radius=None):
+        r = radius if radius is not None else torch.full((p.shape[0],), 0.04)
+        self.pos, self.geo, self.col, self.rad = (torch.cat([self.pos, p]), torch.cat([self.geo, g]),
+                                                  torch.cat([self.col, c]), torch.cat([self.rad, r]))
+
+
+def _triplets(centres):
+    """3 points per location at 0.98 / 1.00 / 1.02 of the way from the origin (N_add = 3)."""
+    return (centres[:, None, :] * torch.tensor([0.98, 1.0, 1.02])[None, :, None]).reshape(-1, 3)
 
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from point_slam_amd.dist import exchange_new_points, frames_of_rank, merge_new_points
+    from point_slam_amd.dist import FrameParallelSync, frames_of_rank, merge_new_points
     g = torch.Generator().manual_seed(100)
-    base = torch.rand(10, 3, generator=g)
+    base = torch.rand(10, 3, generator=g) + 5.0
     bg, bc = torch.rand(10, 32, generator=g), torch.rand(10, 32, generator=g)
     gr = torch.Generator().manual_seed(rank + 1)
-    n_new = 3 * (rank + 1) if rank < 2 else 0                    # ragged: 3, 6 ; third exchange empty on rank 1
-    cloud = FakeCloud(torch.cat([base, torch.rand(n_new, 3, generator=gr)]),
-                      torch.cat([bg, torch.rand(n_new, 32, generator=gr)]),
+    # ragged blocks: 1 location on rank 0, 2 on rank 1; rank 1's FIRST location sits 1 cm from rank 0's -> duplicate
+    c0 = torch.tensor([[1.0, 1.0, 1.0]])
+    centres = c0 if rank == 0 else torch.cat([c0 + 0.01, torch.tensor([[2.0, 2.0, 2.0]])])
+    new = _triplets(centres)
+    n_new = new.shape[0]
+    cloud = FakeCloud(torch.cat([base, new]), torch.cat([bg, torch.rand(n_new, 32, generator=gr)]),
                       torch.cat([bc, torch.rand(n_new, 32, generator=gr)]))
     own = cloud.pos[10:].clone()
     counts = merge_new_points(cloud, 10)
-    # second exchange where one rank has nothing to contribute
+    n_after_dedupe = cloud.pts_num()
+    # second exchange where one rank has nothing to contribute, no dedupe
     n0 = cloud.pts_num()
     if rank == 0:
-        cloud.append_points(torch.ones(2, 3), torch.ones(2, 32), torch.ones(2, 32))
-    counts2 = merge_new_points(cloud, n0)
-    q.put((rank, counts, counts2, cloud.pos.clone(), cloud.geo.clone(), own, frames_of_rank(7, rank, world)))
+        cloud.append_points(torch.ones(3, 3) * 9, torch.ones(3, 32), torch.ones(3, 32))
+    counts2 = merge_new_points(cloud, n0, dedupe=False)
+
+    # features / decoder reconciliation: rank 0 changes rows 0,1; rank 1 changes rows 1,2; both change theta
+    theta = torch.arange(8, dtype=torch.float32)
+    sync = FrameParallelSync(cloud, theta, n_color=6)
+    geo_before = cloud.geo.clone()
+    if rank == 0:
+        cloud.geo[0] += 1.0; cloud.geo[1] += 2.0; theta[:6] += 1.0; theta[6:] += 100.0
+    else:
+        cloud.geo[1] += 4.0; cloud.geo[2] += 8.0; theta[:6] += 3.0
+    counts3 = sync.exchange(cloud, theta)
+    q.put((rank, counts, counts2, counts3, n_after_dedupe, cloud.pos.clone(), cloud.geo.clone(), own, geo_before,
+           theta.clone(), frames_of_rank(7, rank, world)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,9 +91,20 @@ def test_exchange_new_points_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, c0, c0b, pos0, geo0, own0, fr0), (r1, c1, c1b, pos1, geo1, own1, fr1) = res
-    assert c0 == c1 == [3, 6] and c0b == c1b == [2, 0]
+    (r0, c0, c0b, c0c, n0, pos0, geo0, own0, gb0, th0, fr0), (r1, c1, c1b, c1c, n1, pos1, geo1, own1, gb1, th1, fr1) = res
+    assert c0 == c1 == [3, 6] and c0b == c1b == [3, 0] and c0c == c1c == [0, 0]
+    # rank 1's duplicate location was dropped on BOTH ranks: 10 base + 3 (rank 0) + 3 (rank 1's second location)
+    assert n0 == n1 == 16
     assert torch.equal(pos0, pos1) and torch.equal(geo0, geo1)          # identical replicas, identical order
-    assert pos0.shape[0] == 10 + 9 + 2
-    assert torch.equal(pos0[10:13], own0) and torch.equal(pos0[13:19], own1)   # rank order
+    assert pos0.shape[0] == 16 + 3
+    assert torch.equal(pos0[10:13], own0) and torch.equal(pos0[13:16], own1[3:6])   # rank order, kept block
+    # min-distance invariant across ranks: no surface point of a later block inside 4 cm of an earlier block's points
+    assert float(((pos0[14] - pos0[10:13]) ** 2).sum(-1).min()) > 0.04 ** 2
+    # averaged CHANGES: row 0 only rank 0 (+1), row 1 both ((2+4)/2), row 2 only rank 1 (+8), others untouched
+    d = geo0[:3, 0] - gb0[:3, 0]
+    assert torch.allclose(d, torch.tensor([1.0, 3.0, 8.0]))
+    assert torch.equal(geo0[3:], gb0[3:])
+    # colour-decoder group: mean of the changes (+1, +3 -> +2); the geometry group is not exchanged
+    assert torch.allclose(th0[:6], torch.arange(6, dtype=torch.float32) + 2.0) and torch.equal(th0[:6], th1[:6])
+    assert th0[6] == 106.0 and th1[6] == 6.0
     assert fr0 == [0, 2, 4, 6] and fr1 == [1, 3, 5]
