@@ -1,0 +1,100 @@
+"""GPU: the multi-GPU exchange (point_slam_amd/dist.py) on the REAL HipNeuralPointCloud -- two ranks (gloo, both on
+cuda:0; RCCL refuses two ranks on one device) each with its own native context.  After the exchange both replicas
+hold the same points in the same order, answer kNN queries identically, satisfy the add-radius invariant across
+ranks, and hold reconciled features / decoder."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from point_slam_amd import synthetic as syn
+        from point_slam_amd.dist import FrameParallelSync
+        from point_slam_amd.neural_point import HipNeuralPointCloud
+        from tests.helpers import base_cfg
+        dev = torch.device("cuda:0")
+        cfg = base_cfg()
+        cfg["mapping"] = dict(cfg["mapping"], device="cuda:0")
+        cam = syn.intrinsics(320, 240)
+        npc = HipNeuralPointCloud(cfg, max_points=200000, device="cuda:0")
+        base = syn.seed_cloud(cam, 30000, n_views=4, seed=3)
+        g = torch.Generator().manual_seed(9)
+        npc.set_points(base.to(dev), torch.randn(base.shape[0], 32, generator=g).to(dev),
+                       torch.randn(base.shape[0], 32, generator=g).to(dev))
+        theta = torch.arange(16, dtype=torch.float32, device=dev)
+        sync = FrameParallelSync(npc, theta, n_color=12)
+        # two neighbouring frames (as frame t and t+1 of the frame-parallel split): heavily overlapping surfaces
+        c2w = syn.pose(400.0 + 0.5 * rank, dev)
+        depth, color = syn.render_frame(cam, c2w)
+        r_add, _ = syn.dynamic_radii(color, cfg)
+        gi = torch.Generator().manual_seed(50 + rank)
+        idx = torch.randint(cam["H"] * cam["W"], (4000,), generator=gi).to(dev)
+        from point_slam_amd import host_ops as H
+        u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
+        ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        gd, rad = depth[v.long(), u.long()], r_add[v.long(), u.long()]
+        n_base = npc.pts_num()
+        kept = int(npc.add_neural_points(ro.contiguous(), rd.contiguous(), gd, torch.zeros(4000, 3, device=dev),
+                                         dynamic_radius=rad))
+        # each rank also "optimises" some base rows and its decoder
+        npc.get_geo_feats()[rank:rank + 2] += 1.0 + rank
+        theta[:12] += 1.0 + 2 * rank
+        counts = sync.exchange(npc, theta)
+        torch.cuda.synchronize()
+        N = npc.pts_num()
+        pos = npc.cloud_pos()
+        qpts = pos[n_base:][:: max((N - n_base) // 500, 1)].to(dev) + 0.003
+        D, I, cnt = npc.find_neighbors_faiss(qpts, step="query")
+        # add-radius invariant of the merged tail: no surface point (middle of each triplet) has a point of an EARLIER
+        # location strictly inside its own radius
+        tail = pos[n_base:].reshape(-1, 3, 3)
+        rad_tail = npc.point_radius(n_base).cpu().reshape(-1, 3)[:, 1]
+        surf = tail[:, 1, :]
+        viol = 0
+        allp = pos
+        for j in range(0, surf.shape[0], 512):
+            d2 = ((surf[j:j + 512, None, :] - allp[None, :n_base + 3 * j, :]) ** 2).sum(-1) if j else None
+            if d2 is not None:
+                viol += int((d2 < (rad_tail[j:j + 512] ** 2)[:, None]).any(1).sum())
+        q.put((rank, kept, counts, N, n_base, pos, npc.get_geo_feats()[:4].cpu(), theta.cpu(), I.cpu(), cnt.cpu(), viol))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_on_real_point_cloud_two_ranks():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = res
+    kept0, kept1 = a[1], b[1]
+    assert a[2] == b[2] == [3 * kept0, 3 * kept1]
+    N, n_base = a[3], a[4]
+    assert N == b[3] and n_base == b[4]
+    # rank 0's block is admitted whole; rank 1's overlapping locations were dropped (neighbouring frames)
+    admitted1 = N - n_base - 3 * kept0
+    assert 0 < admitted1 < 3 * kept1, (kept0, kept1, admitted1)
+    assert torch.equal(a[5], b[5])                                     # same points, same order
+    assert torch.equal(a[6], b[6]) and torch.equal(a[7][:12], b[7][:12])
+    assert torch.equal(a[8], b[8]) and torch.equal(a[9], b[9])         # identical kNN answers on both replicas
+    assert a[10] == 0 and b[10] == 0                                   # min-distance invariant across ranks
+    # decoder: mean of the changes (+1, +3 -> +2)
+    assert torch.allclose(a[7][:12], torch.arange(12, dtype=torch.float32) + 2.0)
+    from tests.test_hip_parity import report
+    report(test="dist_real_cloud", kept=[kept0, kept1], admitted_rank1=admitted1 // 3, N=N)
