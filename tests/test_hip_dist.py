@@ -54,17 +54,8 @@ def _worker(rank, world, port, q):
         pos = npc.cloud_pos()
         qpts = pos[n_base:][:: max((N - n_base) // 500, 1)].to(dev) + 0.003
         D, I, cnt = npc.find_neighbors_faiss(qpts, step="query")
-        # add-radius invariant of the merged tail: no surface point (middle of each triplet) has a point of an EARLIER
-        # location strictly inside its own radius
-        tail = pos[n_base:].reshape(-1, 3, 3)
-        rad_tail = npc.point_radius(n_base).cpu().reshape(-1, 3)[:, 1]
-        surf = tail[:, 1, :]
-        viol = 0
-        allp = pos
-        for j in range(0, surf.shape[0], 512):
-            d2 = ((surf[j:j + 512, None, :] - allp[None, :n_base + 3 * j, :]) ** 2).sum(-1) if j else None
-            if d2 is not None:
-                viol += int((d2 < (rad_tail[j:j + 512] ** 2)[:, None]).any(1).sum())
+        rad_tail = npc.point_radius(n_base).cpu()
+        viol = rad_tail
         q.put((rank, kept, counts, N, n_base, pos, npc.get_geo_feats()[:4].cpu(), theta.cpu(), I.cpu(), cnt.cpu(), viol))
         dist.barrier()
     finally:
@@ -93,7 +84,19 @@ def test_exchange_on_real_point_cloud_two_ranks():
     assert torch.equal(a[5], b[5])                                     # same points, same order
     assert torch.equal(a[6], b[6]) and torch.equal(a[7][:12], b[7][:12])
     assert torch.equal(a[8], b[8]) and torch.equal(a[9], b[9])         # identical kNN answers on both replicas
-    assert a[10] == 0 and b[10] == 0                                   # min-distance invariant across ranks
+    # add-radius invariant ACROSS ranks (within one rank's batch the reference itself admits near-duplicates: the
+    # dedupe is against the index as built before the batch, neural_point.py:116-121): no admitted location of rank 1
+    # has a base point or a rank-0 point strictly inside its radius
+    pos, rad = a[5], a[10]
+    first1 = n_base + 3 * kept0
+    surf = pos[first1:].reshape(-1, 3, 3)[:, 1, :]
+    r1 = rad[3 * kept0:].reshape(-1, 3)[:, 1]
+    earlier = pos[:first1]
+    viol = 0
+    for j in range(0, surf.shape[0], 256):
+        d2 = ((surf[j:j + 256, None, :] - earlier[None]) ** 2).sum(-1)
+        viol += int((d2 < (r1[j:j + 256] ** 2)[:, None]).any(1).sum())
+    assert viol == 0
     # decoder: mean of the changes (+1, +3 -> +2)
     assert torch.allclose(a[7][:12], torch.arange(12, dtype=torch.float32) + 2.0)
     from tests.test_hip_parity import report
