@@ -95,11 +95,10 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         n_base = slam.npc.pts_num()
         slam.map(fr, c2w)
         state["mapped"] += 1
-        state["new_since"] += slam.npc.pts_num() - n_base
+        state["added"] += slam.npc.pts_num() - n_base
         if world > 1 and state["mapped"] % args.exchange_every == 0:
-            from point_slam_amd.dist import merge_new_points
-            merge_new_points(slam.npc, slam.npc.pts_num() - state["new_since"])
-            state["new_since"] = 0
+            # new points (cross-rank dedupe), features of shared rows and the colour decoder are reconciled
+            state["sync"].exchange(slam.npc, slam.theta)
         if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
             slam.keyframes.append(fr)
 
@@ -243,7 +242,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
-    state = dict(mapped=0, new_since=0)
+    state = dict(mapped=0, added=0)
+    if world > 1:
+        from point_slam_amd import params as P_
+        from point_slam_amd.dist import FrameParallelSync
+        state["sync"] = FrameParallelSync(slam.npc, slam.theta, n_color=P_.color_floats())
 
     def barrier():
         torch.cuda.synchronize()
