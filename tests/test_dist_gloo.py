@@ -41,6 +41,18 @@ def _triplets(centres):
     return (centres[:, None, :] * torch.tensor([0.98, 1.0, 1.02])[None, :, None]).reshape(-1, 3)
 
 
+def _np(x):
+    """tensors travel through the queue BY VALUE (numpy): torch's fd-sharing needs the sender alive at receive time"""
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return x
+
+
+def _t(x):
+    import numpy as np
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -74,8 +86,8 @@ def _worker(rank, world, port, q):
     else:
         cloud.geo[1] += 4.0; cloud.geo[2] += 8.0; theta[:6] += 3.0
     counts3 = sync.exchange(cloud, theta)
-    q.put((rank, counts, counts2, counts3, n_after_dedupe, cloud.pos.clone(), cloud.geo.clone(), own, geo_before,
-           theta.clone(), frames_of_rank(7, rank, world)))
+    q.put(tuple(_np(x) for x in (rank, counts, counts2, counts3, n_after_dedupe, cloud.pos.clone(), cloud.geo.clone(), own, geo_before,
+           theta.clone(), frames_of_rank(7, rank, world))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,7 +99,7 @@ def test_exchange_new_points_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    res = sorted([tuple(_t(x) for x in q.get(timeout=120)) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

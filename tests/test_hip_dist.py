@@ -12,6 +12,18 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _np(x):
+    """tensors travel through the queue BY VALUE (numpy): torch's fd-sharing needs the sender alive at receive time"""
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return x
+
+
+def _t(x):
+    import numpy as np
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -56,7 +68,7 @@ def _worker(rank, world, port, q):
         D, I, cnt = npc.find_neighbors_faiss(qpts, step="query")
         rad_tail = npc.point_radius(n_base).cpu()
         viol = rad_tail
-        q.put((rank, kept, counts, N, n_base, pos, npc.get_geo_feats()[:4].cpu(), theta.cpu(), I.cpu(), cnt.cpu(), viol))
+        q.put(tuple(_np(x) for x in (rank, kept, counts, N, n_base, pos, npc.get_geo_feats()[:4].cpu(), theta.cpu(), I.cpu(), cnt.cpu(), viol)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -69,7 +81,7 @@ def test_exchange_on_real_point_cloud_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda x: x[0])
+    res = sorted([tuple(_t(x) for x in q.get(timeout=600)) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

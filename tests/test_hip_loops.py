@@ -128,7 +128,8 @@ def test_track_iters_native_matches_reference_loop(case):
     assert rep["loss_rel_max"] < 5e-4
     assert rep["cam_abs"] < 0.5 * cfg["tracking"]["lr"] and rep["best_abs"] < 0.5 * cfg["tracking"]["lr"]
     if exposure:
-        assert rep["exposure_abs"] < 5e-4 and rep["exposure_mlp_abs"] < 5e-4
+        # six Adam steps of lr 0.001: weights whose gradient is at rounding-noise level take steps of noise-decided sign
+        assert rep["exposure_abs"] < 5e-4 and rep["exposure_mlp_abs"] < 3e-3
 
 
 def test_add_neural_points_matches_reference():
