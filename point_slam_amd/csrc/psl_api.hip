@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include "psl_decode.h"
+#include "psl_frag.h"
 
 namespace psl {
 
@@ -30,6 +31,7 @@ void set_error(const char* fmt, ...) {
 }
 
 int launch_decode_fwd(const DecodeArgs& a, hipStream_t s);
+int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s);
 int build_wt_index(psl_ctx* ctx, hipStream_t s);
 int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s);
 int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
@@ -167,7 +169,13 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta))); psl::poison(c->meta, sizeof(GridMeta));
   PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats)); psl::poison(c->wt, sizeof(float) * kWtFloats);
   PSL_HIP(hipMalloc(&c->wt_index, sizeof(int) * kColorFloats)); psl::poison(c->wt_index, sizeof(int) * kColorFloats);
-  { int rc = build_wt_index(c, nullptr); if (rc) return rc; PSL_HIP(hipStreamSynchronize(nullptr)); }
+  PSL_HIP(hipMalloc(&c->wf, sizeof(float) * kFFloats)); psl::poison(c->wf, sizeof(float) * kFFloats);
+  PSL_HIP(hipMalloc(&c->wb, sizeof(float) * kBFloats)); psl::poison(c->wb, sizeof(float) * kBFloats);
+  PSL_HIP(hipMalloc(&c->wf_index, sizeof(int) * kColorFloats));
+  PSL_HIP(hipMalloc(&c->wb_index, sizeof(int) * kColorFloats));
+  { const char* e = getenv("PSL_DECODE"); c->decode_version = (e && e[0] == '1') ? 1 : 2; }
+  { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
+    PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
@@ -181,7 +189,8 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipDeviceSynchronize();
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
-  (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
+  (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
+  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
@@ -202,12 +211,14 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   if (a->n_rays == 0) return PSL_OK;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
-  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc; }
+  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc;
+                rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
   if (!ctx->pre_I)
   { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
-  { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P); rc = launch_decode_fwd(d, s); if (rc) return rc; }
+  { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P);
+    rc = (ctx->decode_version >= 2) ? launch_decode_fwd2(ctx, d, s) : launch_decode_fwd(d, s); if (rc) return rc; }
   if (!ctx->fused_ray)     // psl_map_iters composites, takes the loss and back-propagates it in one kernel of its own
   { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
     rc = launch_composite_fwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,

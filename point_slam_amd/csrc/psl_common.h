@@ -141,6 +141,12 @@ struct psl_ctx {
   // forward-layout weights (rebuilt per render call from the master blob)
   float* wt;
   int* wt_index = nullptr;   // [kColorFloats] master element -> forward-layout element (or -1)
+  // fragment-major weight copies of the register-chained decode kernels (psl_frag.h) and their inverse maps
+  float* wf = nullptr;       // forward fragments + aligned biases
+  float* wb = nullptr;       // backward (transposed) fragments
+  int* wf_index = nullptr;   // [kColorFloats] master element -> element of wf (or -1)
+  int* wb_index = nullptr;   // [kColorFloats] master element -> element of wb (or -1)
+  int decode_version = 2;    // PSL_DECODE=1 selects the LDS-staged kernels of round 1 (A/B comparisons)
   // dW partial slabs
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
@@ -213,7 +219,8 @@ int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
 struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2; };
-struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt; };
+struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
+                    const int* wf_index; float* wf; const int* wb_index; float* wb; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
                     float lr_par, hipStream_t s, int step_par = -1);
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
@@ -223,6 +230,8 @@ int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_dept
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);
 int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);
+int repack_frags(psl_ctx* ctx, const float* master, hipStream_t s);
+int build_frag_index(psl_ctx* ctx, hipStream_t s);
 
 // workspace carving for render fwd/bwd (all sizes in floats, P = 5 * n_rays padded to TILE)
 struct RenderWs {

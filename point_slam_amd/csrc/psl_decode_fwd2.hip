@@ -1,0 +1,466 @@
+// Fused per-sample decode, forward, register-chained form (see psl_frag.h for the operand algebra).
+//
+// Reference: MLP_geometry / MLP_color .get_feature_at_pos + .forward and POINT.forward
+// (src/conv_onet/models/decoder.py:130-222, 341-449, 476-518).
+//
+// Two roles share one launch (no barrier couples them; they meet in `raw`, consumed by the next kernel):
+//  * colour role  -- one 512-thread workgroup per 16-sample tile.  Phase F: wavefront w evaluates F_theta for the 16
+//    (sample, neighbour) rows 16 w .. 16 w + 15 entirely in registers (gathered features and rel-pos sin/cos are B
+//    operands straight from the loads; hidden activations feed the second layer from the accumulators), reduces over
+//    the 8 neighbours of a sample with three DPP-style shuffles.  Phase T: the colour trunk, wavefront w owns output
+//    columns 16 w .. 16 w + 15 of every layer; the only shared state is the 8 KiB hidden tile, exchanged through LDS in
+//    fragment order (one ds_write_b128 + eight ds_read_b128 per lane per layer, ONE barrier per layer, two buffers).
+//  * geometry role -- one WAVEFRONT per 16-sample tile, 8 tiles per workgroup, no LDS and no barrier at all: inverse-
+//    distance weights, feature interpolation, 93 Fourier features and the five 32-wide layers stay in registers.
+//    In stage 'geometry' only this role is launched.
+// Weights are read as 1 KiB fragments (64 lanes x 16 B, fully coalesced) from the L2-resident fragment buffer.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include "psl_decode.h"
+#include "psl_frag.h"
+
+namespace psl {
+
+__device__ __forceinline__ f32x4 ldfrag(const float* __restrict__ WF, int frag, int lane) {
+  return *reinterpret_cast<const f32x4*>(WF + (size_t)frag * FRAG + lane * 4);
+}
+__device__ __forceinline__ f32x4 ldbias(const float* __restrict__ WF, int layer_bias_off, int nt, int g) {
+  return *reinterpret_cast<const f32x4*>(WF + layer_bias_off + nt * 16 + 4 * g);
+}
+// four k-steps: acc += A-fragment (4 floats) x B registers (4 floats)
+__device__ __forceinline__ void mma4(f32x4& acc, const f32x4& a, const f32x4& b) {
+  acc = mfma16(a[0], b[0], acc);
+  acc = mfma16(a[1], b[1], acc);
+  acc = mfma16(a[2], b[2], acc);
+  acc = mfma16(a[3], b[3], acc);
+}
+__device__ __forceinline__ float group8_sum(float v) {   // sum over the 8 lanes that share (lane & 15) >> 3 and lane >> 4
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  return v;
+}
+
+struct Fwd2Lds {
+  static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oCc = 720, oH = oCc + 2 * FRAG,
+                       total = oH + 2 * 8 * FRAG;     // 5.3 K floats = 21 KB
+};
+
+// ------------------------------------------------------------------------------------------------ geometry role
+// One wavefront, 16 samples: lane (rl = sample, g).  Writes raw[p].w (and xyz = 0 when `full_raw`), g_y, w (when asked).
+__device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __restrict__ WF, int p0, bool full_raw, bool save_w) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  const int p = min(p0 + rl, a.P - 1);
+  const bool live = p0 + rl < a.P;
+  const float* __restrict__ M = a.master;
+  const SampleGeom sg = sample_geom(a, p);
+  // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171)
+  int nb[K];
+  {
+    const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K);
+    const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K + 4);
+    nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
+  }
+  float w[K];
+  float wsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float D = __int_as_float(0x7F800000);
+    if (nb[k] >= 0) { const float4 q = a.pos[nb[k]]; D = dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z); }
+    w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+  }
+  // the reference sums the 8 weights with a pairwise tree inside F.normalize(p=1); any order is within 1 ulp
+  wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+  const float inv = fmaxf(wsum, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
+  if (save_w && live && g == 0) {
+    *reinterpret_cast<float4*>(a.ws.w + (size_t)p * K) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4*>(a.ws.w + (size_t)p * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
+  }
+  const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150)
+  f32x4 cg[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (nb[k] >= 0) {
+        const f32x4 f = *reinterpret_cast<const f32x4*>(a.geo_feats + (size_t)nb[k] * C + jt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = __fadd_rn(acc[r], __fmul_rn(w[k], f[r]));
+      }
+    }
+    if (!has) acc = *reinterpret_cast<const f32x4*>(a.fb_geo + jt * 16 + 4 * g);
+    cg[jt] = acc;
+  }
+  // ---- Fourier features sin(2 pi p . B) (decoder.py:8-37), channel 16 q + 4 g + r
+  const float* __restrict__ Bg = M + MO(PI_G_B);
+  f32x4 eg[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * q + 4 * g + r;
+      eg[q][r] = (f < EG) ? fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f)) : 0.f;
+    }
+  // ---- five blocks: h = relu(W_i h + b_i) + (Wc_i c + bc_i); the embedding is re-attached after block 2
+  f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    constexpr int FLs[5] = {FL_G0, FL_G1, FL_G2, FL_G3, FL_G4};
+    constexpr int FLf[5] = {FL_GF0, FL_GF1, FL_GF2, FL_GF3, FL_GF4};
+    const int L = FLs[i], Lf = FLf[i];
+    const int first = ffirst(L), nq = kFLayers[L].ngroups;
+    f32x4 acc[2], u[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { acc[nt] = ldbias(WF, fbias(L), nt, g); u[nt] = ldbias(WF, fbias(Lf), nt, g); }
+    if (i == 0 || i == 3) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) mma4(acc[nt], ldfrag(WF, first + nt * nq + q, lane), eg[q]);
+    }
+    if (i != 0) {
+      const int qo = (i == 3) ? 6 : 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) mma4(acc[nt], ldfrag(WF, first + nt * nq + qo + q, lane), h[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) mma4(u[nt], ldfrag(WF, ffirst(Lf) + nt * 2 + q, lane), cg[q]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { y[r] = fmaxf(acc[nt][r], 0.f); h[nt][r] = y[r] + u[nt][r]; }
+      if (a.ws.g_y && live) *reinterpret_cast<f32x4*>(a.ws.g_y + ((size_t)i * a.ws.Ppad + p) * HG + nt * 16 + 4 * g) = y;
+    }
+  }
+  // ---- output_linear 32 -> 1 as one padded tile: row 0 of the accumulator = occupancy logit of sample rl
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  mma4(o0, ldfrag(WF, ffirst(FL_GOUT) + 0, lane), h[0]);
+  mma4(o1, ldfrag(WF, ffirst(FL_GOUT) + 1, lane), h[1]);
+  if (g == 0 && live) {
+    // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
+    const float occ = has ? (o0[0] + o1[0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
+    if (full_raw) reinterpret_cast<float4*>(a.ws.raw)[p] = make_float4(0.f, 0.f, 0.f, occ);
+    else a.ws.raw[(size_t)p * 4 + 3] = occ;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ colour role
+__device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __restrict__ WF, float* smem, int p0) {
+  using L = Fwd2Lds;
+  int* sI = (int*)(smem + L::oI);           // [16][8]
+  float* sW = smem + L::oW;                 // [16][8]
+  float* sRel = smem + L::oRel;             // [16][8][3]
+  float* sPts = smem + L::oPts;             // [16][4]
+  int* sHas = (int*)(smem + L::oHas);       // [16]
+  float* sCc = smem + L::oCc;               // [2][64][4]   interpolated colour features, fragment order
+  float* sH = smem + L::oH;                 // [2][8][64][4] hidden tile, fragment order, double buffered
+  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool relpos = (a.flags & 0x10000) != 0;
+  const float* __restrict__ M = a.master;
+  auto live = [&](int s) { return p0 + s < a.P; };
+
+  // ---------------------------------------------------------------- phase 0: neighbours, weights (one thread per pair)
+  if (t < TILE * K) {
+    const int s = t >> 3, k = t & 7;
+    const int p = min(p0 + s, a.P - 1);
+    const SampleGeom sg = sample_geom(a, p);
+    const int i = a.ws.I[(size_t)p * K + k];
+    float nx = 0.f, ny = 0.f, nz = 0.f, D = __int_as_float(0x7F800000);
+    if (i >= 0) { const float4 q = a.pos[i]; nx = q.x; ny = q.y; nz = q.z; D = dist2(nx, ny, nz, sg.x, sg.y, sg.z); }
+    float w = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+    float sum = w;
+    sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+    w = w / fmaxf(sum, 1e-12f);
+    sI[t] = i; sW[t] = w;
+    sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(nx, sg.x) : 0.f;
+    sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(ny, sg.y) : 0.f;
+    sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(nz, sg.z) : 0.f;
+    if (live(s)) a.ws.w[(size_t)p * K + k] = w;
+    if (k == 0) {
+      sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
+      sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
+    }
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- phase F: colour features of the tile
+  {
+    const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane; 4 lanes (g) share a pair
+    const int s = row >> 3;
+    const int i = sI[row];
+    const float wgt = sW[row];
+    const size_t grow = (size_t)p0 * K + row;  // row of the per-pair save buffers
+    f32x4 xf[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+      xf[jt] = (i >= 0) ? *reinterpret_cast<const f32x4*>(a.col_feats + (size_t)i * C + jt * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cc[2];
+    if (relpos) {
+      // F_theta input [sin(10) cos(10) | feat(32)] (decoder.py:371-378); this lane holds sin or cos of f = 2 s + (g >> 1)
+      const float* __restrict__ Brel = M + MO(PI_C_BREL);
+      const float rx = sRel[row * 3], ry = sRel[row * 3 + 1], rz = sRel[row * 3 + 2];
+      f32x4 xe; float xe4;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const int f = 2 * ks + (g >> 1);
+        float sn, cs;
+        fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
+        const float v = (g & 1) ? cs : sn;
+        if (ks < 4) xe[ks] = v; else xe4 = v;
+        if (a.ws.n_x && live(s)) a.ws.n_x[grow * NX + (g & 1) * ERF + f] = v;
+      }
+      if (a.ws.n_x && live(s)) {
+        *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 4 * g) = xf[0];
+        *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 16 + 4 * g) = xf[1];
+      }
+      // linear1 52 -> 128: 8 independent accumulator tiles, 13 k-steps each
+      f32x4 hid[8];
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) hid[nt] = ldbias(WF, fbias(FL_N1), nt, g);
+      constexpr int f1 = ffirst(FL_N1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        f32x4 af[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) af[nt] = ldfrag(WF, f1 + nt * 4 + q, lane);
+        const f32x4 b = (q == 0) ? xf[0] : (q == 1 ? xf[1] : xe);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < 8; ++nt) hid[nt] = mfma16(af[nt][r], b[r], hid[nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) hid[nt] = mfma16(ldfrag(WF, f1 + nt * 4 + 3, lane)[0], xe4, hid[nt]);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100(hid[nt][r]);
+        if (a.ws.n_h1 && live(s)) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
+      }
+      // linear2 128 -> 32
+      f32x4 nf[2];
+      nf[0] = ldbias(WF, fbias(FL_N2), 0, g); nf[1] = ldbias(WF, fbias(FL_N2), 1, g);
+      constexpr int f2 = ffirst(FL_N2);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 a0 = ldfrag(WF, f2 + q, lane), a1 = ldfrag(WF, f2 + 8 + q, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[q][r], nf[0]); nf[1] = mfma16(a1[r], hid[q][r], nf[1]); }
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        if (a.ws.n_out && live(s)) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, nf[nt][r]));   // sum_k w_k F_theta(.)  (decoder.py:380-385)
+      }
+    } else {
+      // plain interpolation sum_k w_k f[I_k] (decoder.py:380-385 without the neighbour MLP)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, xf[nt][r]));
+    }
+    if ((rl & 7) == 0) {     // one lane per (sample, g) publishes the tile's colour features in fragment order
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 c = cc[nt];
+        if (!sHas[s]) c = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
+        *reinterpret_cast<f32x4*>(sCc + nt * FRAG + (g * 16 + s) * 4) = c;
+        if (live(s)) *reinterpret_cast<f32x4*>(a.ws.cc + (size_t)(p0 + s) * C + nt * 16 + 4 * g) = c;
+      }
+    }
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- phase T: colour trunk, wave w = output tile w
+  {
+    const int nt = wave;
+    const f32x4 ccb0 = *reinterpret_cast<const f32x4*>(sCc + lane * 4), ccb1 = *reinterpret_cast<const f32x4*>(sCc + FRAG + lane * 4);
+    // Fourier features of the sample position: frequencies f = 4 ks + g, sin and cos (decoder.py:8-37,411)
+    float sn[5], cs[5];
+    {
+      const float x = sPts[rl * 4], y = sPts[rl * 4 + 1], z = sPts[rl * 4 + 2];
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const int f = 4 * ks + g;
+        fast_sincosf(fourier_phase(x, y, z, a.Bcol, ECF, f), sn[ks], cs[ks]);
+        if (wave == 0 && a.ws.c_emb && live(rl)) {
+          a.ws.c_emb[(size_t)(p0 + rl) * EC + f] = sn[ks];
+          a.ws.c_emb[(size_t)(p0 + rl) * EC + ECF + f] = cs[ks];
+        }
+      }
+    }
+    const f32x4 esn = {sn[0], sn[1], sn[2], sn[3]}, ecs = {cs[0], cs[1], cs[2], cs[3]};
+    f32x4 hp[8];     // previous hidden tile, all 128 channels (B operands)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      constexpr int FLs[5] = {FL_C0, FL_C1, FL_C2, FL_C3, FL_C4};
+      constexpr int FLf[5] = {FL_CF0, FL_CF1, FL_CF2, FL_CF3, FL_CF4};
+      const int Lw = FLs[i], Lf = FLf[i];
+      const int nq = kFLayers[Lw].ngroups, base = ffirst(Lw) + nt * nq;
+      // three independent accumulator chains: even / odd k-groups of W_i h, and Wc_i c
+      f32x4 acc_a = ldbias(WF, fbias(Lw), nt, g), acc_b = {0.f, 0.f, 0.f, 0.f}, u = ldbias(WF, fbias(Lf), nt, g);
+      mma4(u, ldfrag(WF, ffirst(Lf) + nt * 2 + 0, lane), ccb0);
+      if (i == 0 || i == 3) {
+        const f32x4 w0 = ldfrag(WF, base + 0, lane), w1 = ldfrag(WF, base + 1, lane), w2 = ldfrag(WF, base + 2, lane),
+                    w3 = ldfrag(WF, base + 3, lane);
+        mma4(acc_a, w0, esn);
+        mma4(acc_b, w2, ecs);
+        acc_a = mfma16(w1[0], sn[4], acc_a);
+        acc_b = mfma16(w3[0], cs[4], acc_b);
+      }
+      mma4(u, ldfrag(WF, ffirst(Lf) + nt * 2 + 1, lane), ccb1);
+      if (i != 0) {
+        const int qo = (i == 3) ? 4 : 0;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          const f32x4 wa = ldfrag(WF, base + qo + q, lane), wb = ldfrag(WF, base + qo + q + 1, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { acc_a = mfma16(wa[r], hp[q][r], acc_a); acc_b = mfma16(wb[r], hp[q + 1][r], acc_b); }
+        }
+      }
+      f32x4 y, hh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { y[r] = softplus100(acc_a[r] + acc_b[r]); hh[r] = y[r] + u[r]; }
+      if (a.ws.c_y && live(rl)) {
+        const size_t o = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
+        *reinterpret_cast<f32x4*>(a.ws.c_y + o) = y;
+        if (a.ws.c_hin) *reinterpret_cast<f32x4*>(a.ws.c_hin + o) = hh;
+      }
+      float* buf = sH + (i & 1) * 8 * FRAG;
+      *reinterpret_cast<f32x4*>(buf + nt * FRAG + lane * 4) = hh;
+      lds_barrier();
+      if (i < 4 || wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hp[q] = *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4);
+      }
+    }
+    // ---- output_linear 128 -> 3 (one padded tile, wave 0) and the colour head (decoder.py:430-448)
+    if (wave == 0) {
+      f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+      constexpr int fo = ffirst(FL_COUT);
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) { mma4(oa, ldfrag(WF, fo + q, lane), hp[q]); mma4(ob, ldfrag(WF, fo + q + 1, lane), hp[q + 1]); }
+      if (g == 0 && live(rl)) {
+        const int p = p0 + rl;
+        float r0 = (oa[0] + ob[0]) + M[MO(PI_C_OUT + 1) + 0];
+        float r1 = (oa[1] + ob[1]) + M[MO(PI_C_OUT + 1) + 1];
+        float r2 = (oa[2] + ob[2]) + M[MO(PI_C_OUT + 1) + 2];
+        a.ws.out3[(size_t)p * 4 + 0] = r0; a.ws.out3[(size_t)p * 4 + 1] = r1; a.ws.out3[(size_t)p * 4 + 2] = r2;
+        if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
+          const float* A = a.affine;
+          const float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
+          const float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
+          const float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
+          r0 = q0; r1 = q1; r2 = q2;
+        }
+        if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
+        a.ws.raw[(size_t)p * 4 + 0] = r0; a.ws.raw[(size_t)p * 4 + 1] = r1; a.ws.raw[(size_t)p * 4 + 2] = r2;
+      }
+    }
+  }
+}
+
+// grid: [0, color_tiles) colour role (one tile per workgroup), then geometry role (8 tiles per workgroup).
+// COLOR = false is the stage-'geometry' launch (geometry role only); two instantiations so that profiles tell them apart.
+template <bool COLOR>
+__global__ __launch_bounds__(WG, 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (COLOR && (int)blockIdx.x < color_tiles) {
+    color_tile(a, WF, smem, blockIdx.x * TILE);
+  } else {
+    const int tile = ((int)blockIdx.x - color_tiles) * 8 + (int)(threadIdx.x >> 6);
+    const int p0 = tile * TILE;
+    if (p0 >= a.P) return;
+    geo_tile(a, WF, p0, !COLOR, !COLOR);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ fragment buffers
+// element e of the forward fragment buffer <- master blob (one thread per element; also used to build the inverse
+// index that lets the Adam kernel keep the fragments in step with the master copy)
+__device__ __forceinline__ int ffrag_source(int e) {     // master offset feeding element e, or -1 (zero padding)
+  if (e >= kFFrags * FRAG) {   // bias area
+    int li = 0;
+#pragma unroll
+    for (int j = 1; j < FL_COUNT; ++j) if (e >= fbias(j)) li = j;
+    const int n = e - fbias(li);
+    return n < kFLayers[li].N ? poff(kFLayers[li].pi + 1) + n : -1;
+  }
+  const int frag = e / FRAG, lane = (e % FRAG) >> 2, r = e & 3;
+  int li = 0;
+#pragma unroll
+  for (int j = 1; j < FL_COUNT; ++j) if (frag >= ffirst(j)) li = j;
+  const FLayer Ld = kFLayers[li];
+  const int loc = frag - ffirst(li);
+  const int nt = loc / Ld.ngroups, q = loc - nt * Ld.ngroups;
+  const int out = nt * 16 + (lane & 15);
+  const int ch = frag_chan(kFGroups[Ld.g0 + q], lane >> 4, r);
+  if (out >= Ld.N || ch < 0 || ch >= Ld.K) return -1;
+  return poff(Ld.pi) + out * Ld.K + ch;
+}
+__device__ __forceinline__ int bfrag_source(int e) {
+  const int frag = e / FRAG, lane = (e % FRAG) >> 2, r = e & 3;
+  int li = 0;
+#pragma unroll
+  for (int j = 1; j < BL_COUNT; ++j) if (frag >= bfirst(j)) li = j;
+  const BLayer Ld = kBLayers[li];
+  const int loc = frag - bfirst(li);
+  const int it = loc / Ld.ngroups, q = loc - it * Ld.ngroups;
+  const BTile bt = kBTiles[Ld.t0 + it];
+  const int in = bt.in0 + (lane & 15);
+  const int out = 16 * q + 4 * (lane >> 4) + r;
+  if (in >= bt.lim || out >= Ld.N) return -1;
+  return poff(Ld.pi) + out * Ld.K + in;
+}
+
+__global__ __launch_bounds__(256) void k_frag_repack(const float* __restrict__ master, float* __restrict__ wf, float* __restrict__ wb) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < kFFloats) { const int s = ffrag_source(e); wf[e] = s >= 0 ? master[s] : 0.f; }
+  if (e < kBFloats) { const int s = bfrag_source(e); wb[e] = s >= 0 ? master[s] : 0.f; }
+}
+// inverse maps for the colour group: master element -> its forward / backward fragment element (or -1)
+__global__ __launch_bounds__(256) void k_frag_index(int* __restrict__ wf_index, int* __restrict__ wb_index) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < kFFloats) { const int s = ffrag_source(e); if (s >= 0 && s < kColorFloats) wf_index[s] = e; }
+  if (e < kBFloats) { const int s = bfrag_source(e); if (s >= 0 && s < kColorFloats) wb_index[s] = e; }
+}
+
+int build_frag_index(psl_ctx* ctx, hipStream_t s) {
+  PSL_HIP(hipMemsetAsync(ctx->wf_index, 0xFF, sizeof(int) * kColorFloats, s));
+  PSL_HIP(hipMemsetAsync(ctx->wb_index, 0xFF, sizeof(int) * kColorFloats, s));
+  const int n = std::max(kFFloats, kBFloats);
+  hipLaunchKernelGGL(k_frag_index, dim3((n + 255) / 256), dim3(256), 0, s, ctx->wf_index, ctx->wb_index);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int repack_frags(psl_ctx* ctx, const float* master, hipStream_t s) {
+  const int n = std::max(kFFloats, kBFloats);
+  hipLaunchKernelGGL(k_frag_repack, dim3((n + 255) / 256), dim3(256), 0, s, master, ctx->wf, ctx->wb);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s) {
+  if (a.P <= 0) return PSL_OK;
+  const size_t lds = sizeof(float) * Fwd2Lds::total;
+  const int tiles = (a.P + TILE - 1) / TILE;
+  const int geo_wgs = (tiles + 7) / 8;
+  if (a.flags & PSL_STAGE_COLOR)
+    hipLaunchKernelGGL(k_decode_fwd2<true>, dim3(tiles + geo_wgs), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
+  else
+    hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(geo_wgs), dim3(WG), 0, s, a, (const float*)ctx->wf, 0);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+}  // namespace psl

@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
     const int w = par.wt_index[i];
     if (w >= 0) par.wt[w] = pp;
+    const int wf = par.wf_index[i], wb = par.wb_index[i];
+    if (wf >= 0) par.wf[wf] = pp;
+    if (wb >= 0) par.wb[wb] = pp;
   }
 }
 

@@ -618,7 +618,7 @@ static int64_t map_prefetch_floats(int n_rays) {
 extern "C" int64_t psl_map_ws_floats(int n_rays, int n_frames) {
   if (n_rays < 0 || n_frames < 0) return PSL_ERR_ARG;
   return map_prefetch_floats(n_rays) + rays_floats(map_knn_block(n_rays) * n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
-         (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 16 + psl_param_master_floats();
+         (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 32 + psl_param_master_floats();
 }
 
 extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) {
@@ -652,7 +652,8 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   };
   p += 64;
   FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) * m->n_frames + 3) / 4 + 4;
-  float* g_params = p; p += psl_param_master_floats();
+  float* g_params = p; p += (psl_param_master_floats() + 3) / 4 * 4;
+  p = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);   // neighbour lists are read as 16-byte vectors
   int* pre_I = (int*)p; p += (size_t)kblock * n * S * K;
   int* pre_cnt = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
@@ -755,6 +756,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
         if (m->train_decoder) {
           sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
           sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
+          sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
         }
       }
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
