@@ -40,8 +40,8 @@ int launch_composite_fwd(const float4* raw, const float* z, const float* gt_dept
 int launch_composite_bwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float coef,
                          const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, float* zero64,
                          hipStream_t s);
-int launch_ray_grad(const float4* dp, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
-                    float* g_d, hipStream_t s);
+int launch_ray_grad(const float4* dp, const float4* dp2, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays,
+                    float* g_o, float* g_d, hipStream_t s);
 
 static inline int64_t al4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -70,6 +70,7 @@ RenderWs carve_ws(float* base, int n_rays, int flags) {
     w.g_y = take(Pp * 5 * HG);
     w.d_raw = take(Pp * 4);
     w.dp = take(Pp * 4);
+    w.dp2 = take(Pp * 4);
     if (color) {
       w.c_y = take(Pp * 5 * HC);
       w.d_out3 = take(Pp * 4);
@@ -174,6 +175,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->wf_index, sizeof(int) * kColorFloats));
   PSL_HIP(hipMalloc(&c->wb_index, sizeof(int) * kColorFloats));
   { const char* e = getenv("PSL_DECODE"); c->decode_version = (e && e[0] == '1') ? 1 : 2; }
+  { const char* e = getenv("PSL_DECODE_BWD"); c->decode_bwd_version = (e && e[0] == '1') ? 1 : 2; }
   { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
@@ -247,7 +249,8 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
   if (rc) return rc;
   if ((a->flags & PSL_PTS_GRAD) && (g->g_rays_o || g->g_rays_d)) {
     ProfScope ps(ctx, PROF_MISC, s);
-    rc = launch_ray_grad((const float4*)d.ws.dp, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
+    rc = launch_ray_grad((const float4*)d.ws.dp, ctx->decode_bwd_version >= 2 ? (const float4*)d.ws.dp2 : nullptr, a->z_vals,
+                         a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
     if (rc) return rc;
   }
   return PSL_OK;

@@ -146,7 +146,8 @@ struct psl_ctx {
   float* wb = nullptr;       // backward (transposed) fragments
   int* wf_index = nullptr;   // [kColorFloats] master element -> element of wf (or -1)
   int* wb_index = nullptr;   // [kColorFloats] master element -> element of wb (or -1)
-  int decode_version = 2;    // PSL_DECODE=1 selects the LDS-staged kernels of round 1 (A/B comparisons)
+  int decode_version = 2;    // PSL_DECODE=1 selects the LDS-staged forward of round 1 (A/B comparisons)
+  int decode_bwd_version = 2;   // PSL_DECODE_BWD=1: the LDS-staged backward of round 1
   // dW partial slabs
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
@@ -260,6 +261,7 @@ struct RenderWs {
   float* n_dnf;      // [Ppad][8][32]
   float* d_out3;     // [Ppad][4]
   float* dp;         // [Ppad][4]
+  float* dp2;        // [Ppad][4]  geometry-branch share of dL/dp (register-chained backward: written by another workgroup)
   int64_t total;
 };
 RenderWs carve_ws(float* base, int n_rays, int flags);

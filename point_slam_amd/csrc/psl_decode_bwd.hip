@@ -540,6 +540,7 @@ __global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd(DecodeArgs a, B
 }
 
 int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g_brel, hipStream_t s);
+int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, float* small, hipStream_t s);
 
 template <bool PTSG>
 static int launch_bwd_t(const DecodeArgs& a, const BwdOut& o, int tiles, hipStream_t s) {
@@ -575,7 +576,9 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
   {
     ProfScope ps(ctx, PROF_DECODE_BWD, s, bwd_flops_per_sample(a.flags) * a.P);
-    int rc = (a.flags & PSL_PTS_GRAD) ? launch_bwd_t<true>(a2, o, tiles, s) : launch_bwd_t<false>(a2, o, tiles, s);
+    int rc;
+    if (ctx->decode_bwd_version >= 2) rc = launch_decode_bwd2(ctx, a2, g, small, s);
+    else rc = (a.flags & PSL_PTS_GRAD) ? launch_bwd_t<true>(a2, o, tiles, s) : launch_bwd_t<false>(a2, o, tiles, s);
     if (rc) return rc;
   }
   if (dbg_on) {

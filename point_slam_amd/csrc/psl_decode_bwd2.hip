@@ -1,0 +1,601 @@
+// Fused per-sample decode, backward, register-chained form (operand algebra: psl_frag.h; forward: psl_decode_fwd2.hip).
+//
+// Mirrors autograd through MLP_color / MLP_geometry / get_feature_at_pos (src/conv_onet/models/decoder.py:130-222,
+// 341-449): gradients w.r.t. the interpolated features (scatter-added to the neural-point feature rows), w.r.t. the
+// sample positions (-> camera pose, tracker) and the per-layer dZ / G tiles that the parameter-gradient GEMM
+// (psl_dw.hip) contracts over all samples.
+//
+// dX^T[in][sample] = sum_out W[out][in] dZ^T[out][sample] is the same MFMA with A = W^T (backward fragments, k walks the
+// layer's OUTPUT channels in accumulator order) and B = dZ^T straight from the registers that hold it.  Roles as in
+// the forward:
+//  * colour role: one 512-thread workgroup per 16-sample tile; wavefront w owns hidden channels 16 w .. 16 w + 15 of
+//    every dL/dh tile (one LDS exchange of dZ and one barrier per layer); d/dc is accumulated K-split (each wavefront
+//    contracts its own 16 channels, the eight partial tiles meet once at the end); F_theta's backward is again private
+//    to the wavefront that owns the 16 (sample, neighbour) rows.
+//  * geometry role: one wavefront per tile, registers only.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <type_traits>
+#include "psl_decode.h"
+#include "psl_frag.h"
+
+namespace psl {
+
+__device__ __forceinline__ f32x4 ldfragb(const float* __restrict__ WB, int frag, int lane) {
+  return *reinterpret_cast<const f32x4*>(WB + (size_t)frag * FRAG + lane * 4);
+}
+__device__ __forceinline__ void mma4b(f32x4& acc, const f32x4& a, const f32x4& b) {
+  acc = mfma16(a[0], b[0], acc);
+  acc = mfma16(a[1], b[1], acc);
+  acc = mfma16(a[2], b[2], acc);
+  acc = mfma16(a[3], b[3], acc);
+}
+__device__ __forceinline__ void sched_fence_b() { __builtin_amdgcn_sched_barrier(0); }
+
+struct Bwd2Out {
+  float* g_geo; float* g_col; const int* row_map;
+  float* g_brel;     // [30] accumulated with atomics (pre-zeroed)
+  float* g_affine;   // [12] accumulated with atomics (pre-zeroed)
+};
+
+constexpr int LD_E2 = 44;   // colour d(embedding) tile [16][40] (PTSG)
+constexpr int LD_X2 = 22;   // rel-pos part of F_theta's dX1, per wave [16][20]
+struct Bwd2Lds {
+  static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oDO = 720, oDB = 784, oAffP = 816,
+                       oGW = oAffP + 16 * 12, oDP = oGW + 128, oDcc = oDP + 64, oDccP = oDcc + 2 * FRAG,
+                       oDZ = oDccP + 16 * FRAG, oDE = oDZ + 2 * 8 * FRAG, oXe = oDE + 16 * LD_E2,
+                       total = oXe + 8 * 16 * LD_X2;       // ~13 K floats = 52 KB
+};
+
+// ------------------------------------------------------------------------------------------------ geometry role
+// One wavefront per tile.  d_occ flows for masked samples too (straight-through of the -100 write, Renderer.py:189-190).
+template <bool PTSG>
+__device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  const int p = min(p0 + rl, a.P - 1);
+  const bool live = p0 + rl < a.P;
+  const float* __restrict__ M = a.master;
+  const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
+  const SampleGeom sg = sample_geom(a, p);
+  int nb[K];
+  {
+    const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K);
+    const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K + 4);
+    nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
+  }
+  float w[K];
+  {
+    const float4 w0 = *reinterpret_cast<const float4*>(a.ws.w + (size_t)p * K), w1 = *reinterpret_cast<const float4*>(a.ws.w + (size_t)p * K + 4);
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+  }
+  const bool has = live && a.ws.cnt[p] >= a.min_nn;
+  const float docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  // G = d_occ * w_out (output_linear.weight [1][32]), channel 16 nt + 4 g + r
+  f32x4 G[2], dcg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[nt][r] = docc * M[MO(PI_G_OUT) + nt * 16 + 4 * g + r];
+  f32x4 dE[6];
+  if constexpr (PTSG) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dE[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    constexpr int BLs[5] = {BL_G0, BL_G1, BL_G2, BL_G3, BL_G4};
+    constexpr int BLf[5] = {BL_GF0, BL_GF1, BL_GF2, BL_GF3, BL_GF4};
+    sched_fence_b();
+    f32x4 dz[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(a.ws.g_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HG + nt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[nt][r] = (y[r] > 0.f) ? G[nt][r] : 0.f;      // ReLU
+    }
+    // dL/dc += Wc_i^T G   (fc_c.i.weight [32][32])
+    const int ff = bfirst(BLf[i]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) mma4b(dcg[it], ldfragb(WB, ff + it * 2 + q, lane), G[q]);
+    // dL/d(input of layer i) = W_i^T dz
+    const int fb = bfirst(BLs[i]);
+    if (i > 0) {
+      f32x4 Gn[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) mma4b(Gn[it], ldfragb(WB, fb + it * 2 + q, lane), dz[q]);   // hidden tiles come first
+      if (PTSG && i == 3) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int it = 0; it < 6; ++it) mma4b(dE[it], ldfragb(WB, fb + (2 + it) * 2 + q, lane), dz[q]);
+      }
+      G[0] = Gn[0]; G[1] = Gn[1];
+    } else if (PTSG) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int it = 0; it < 6; ++it) mma4b(dE[it], ldfragb(WB, fb + it * 2 + q, lane), dz[q]);
+    }
+  }
+  sched_fence_b();
+  // ---- scatter w_k * dC into the geometry feature rows; dL/dw_k for the pose gradient
+  float gw[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    gw[k] = 0.f;
+    const int i = nb[k];
+    if (i >= 0 && has) {
+      if (featg && w[k] != 0.f) {
+        const int row = o.row_map ? o.row_map[i] : i;
+        if (row >= 0) {
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_geo[(size_t)row * C + jt * 16 + 4 * g + r], w[k] * dcg[jt][r]);
+        }
+      }
+      if constexpr (PTSG) {
+        const float* frow = a.geo_feats + (size_t)i * C + 4 * g;
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow), f1 = *reinterpret_cast<const f32x4*>(frow + 16);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v += f0[r] * dcg[0][r] + f1[r] * dcg[1][r];
+        gw[k] = v;
+      }
+    }
+  }
+  if constexpr (PTSG) {
+    // (1) interpolation weights: w = a/S, a = [D<=r2]/(D+1e-10), D = |x_k - p|^2   (decoder.py:143-160)
+    float px = 0.f, py = 0.f, pz = 0.f;
+    float av[K], rx[K], ry[K], rz[K];
+    float S1 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      gw[k] += __shfl_xor(gw[k], 16); gw[k] += __shfl_xor(gw[k], 32);       // over the four channel groups
+      const float4 q = a.pos[max(nb[k], 0)];
+      rx[k] = (nb[k] >= 0) ? __fsub_rn(q.x, sg.x) : 0.f; ry[k] = (nb[k] >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
+      rz[k] = (nb[k] >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
+      const float D = (nb[k] >= 0) ? __fadd_rn(__fadd_rn(__fmul_rn(rx[k], rx[k]), __fmul_rn(ry[k], ry[k])), __fmul_rn(rz[k], rz[k]))
+                                   : __int_as_float(0x7F800000);
+      av[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+      S1 += av[k];
+      gw[k] = has ? gw[k] : 0.f;
+      dot += gw[k] * w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float da = (gw[k] - dot) / fmaxf(S1, 1e-12f);
+      const float dD = -da * av[k] * av[k];
+      px += -2.f * dD * rx[k]; py += -2.f * dD * ry[k]; pz += -2.f * dD * rz[k];
+    }
+    // (2) Fourier embedding sin(2 pi p . B) (93 frequencies), this lane's 24 channels
+    const float* __restrict__ Bg = M + MO(PI_G_B);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * q + 4 * g + r;
+        if (f < EG) {
+          const float dy2 = TWO_PI * dE[q][r] * fast_cosf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
+          ax += dy2 * Bg[f]; ay += dy2 * Bg[EG + f]; az += dy2 * Bg[2 * EG + f];
+        }
+      }
+    ax += __shfl_xor(ax, 16); ax += __shfl_xor(ax, 32);
+    ay += __shfl_xor(ay, 16); ay += __shfl_xor(ay, 32);
+    az += __shfl_xor(az, 16); az += __shfl_xor(az, 32);
+    if (g == 0 && live) reinterpret_cast<float4*>(a.ws.dp2)[p] = make_float4(px + ax, py + ay, pz + az, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ colour role
+template <bool PTSG>
+__device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0) {
+  using L = Bwd2Lds;
+  int* sI = (int*)(smem + L::oI);           // [16][8]
+  float* sW = smem + L::oW;                 // [16][8] normalised weights
+  float* sRel = smem + L::oRel;             // [16][8][3]
+  float* sPts = smem + L::oPts;             // [16][4]
+  int* sHas = (int*)(smem + L::oHas);       // [16]
+  float* sDO = smem + L::oDO;               // [16][4] dL/d colour logits (pre-affine)
+  float* sDB = smem + L::oDB;               // [32]    dL/dB_rel (30 used)
+  float* sAffP = smem + L::oAffP;           // [16][12] per-sample dL/d affine
+  float* sGW = smem + L::oGW;               // [16][8]  dL/dw            (PTSG)
+  float* sDP = smem + L::oDP;               // [16][4]  dL/dp            (PTSG)
+  float* sDcc = smem + L::oDcc;             // [2][64][4] dL/dc_col, fragment order
+  float* sDccP = smem + L::oDccP;           // [8][2][64][4] per-wave partial tiles
+  float* sDZ = smem + L::oDZ;               // [2][8][64][4] dz tile, fragment order, double buffered
+  float* sDE = smem + L::oDE;               // [16][44] dL/d colour embedding (PTSG)
+  float* sXe = smem + L::oXe;               // [8][16][22] rel-pos part of F_theta's dX1, per wave
+  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool relpos = (a.flags & 0x10000) != 0;
+  const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
+  const bool parg = (a.flags & PSL_PARAM_GRAD) != 0;
+  const float* __restrict__ M = a.master;
+
+  // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
+  if (t < TILE * K) {
+    const int s = t >> 3, k = t & 7;
+    const int p = min(p0 + s, a.P - 1);
+    const SampleGeom sg = sample_geom(a, p);
+    const int i = a.ws.I[(size_t)p * K + k];
+    const float4 q = a.pos[max(i, 0)];
+    sI[t] = i;
+    sW[t] = a.ws.w[(size_t)p * K + k];
+    sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f;
+    sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
+    sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
+    if constexpr (PTSG) sGW[t] = 0.f;
+    if (k == 0) {
+      sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
+      // samples past the end of the batch behave as "no neighbours, zero gradient"
+      sHas[s] = (p0 + s < a.P && a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
+    }
+  } else if (t < TILE * K + TILE) {
+    // ---- d(logits): sigmoid and exposure-affine backward (decoder.py:432-448), one thread per sample
+    const int s = t - TILE * K;
+    const int p = p0 + s;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    float ag[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ag[j] = 0.f;
+    if (p < a.P) {
+      const float4 dr = reinterpret_cast<const float4*>(a.ws.d_raw)[p];
+      const float4 rw = reinterpret_cast<const float4*>(a.ws.raw)[p];
+      d0 = dr.x; d1 = dr.y; d2 = dr.z;
+      if (!(a.flags & PSL_NO_SIGMOID)) { d0 *= rw.x * (1.f - rw.x); d1 *= rw.y * (1.f - rw.y); d2 *= rw.z * (1.f - rw.z); }
+      if (a.flags & PSL_HAS_AFFINE) {
+        const float* A = a.affine;
+        const float o0 = a.ws.out3[(size_t)p * 4], o1 = a.ws.out3[(size_t)p * 4 + 1], o2 = a.ws.out3[(size_t)p * 4 + 2];
+        // out' = out @ A + t : dA[i][j] = out_i d_j ; dt_j = d_j ; d out_i = sum_j A[i][j] d_j
+        ag[0] = o0 * d0; ag[1] = o0 * d1; ag[2] = o0 * d2; ag[3] = o1 * d0; ag[4] = o1 * d1; ag[5] = o1 * d2;
+        ag[6] = o2 * d0; ag[7] = o2 * d1; ag[8] = o2 * d2; ag[9] = d0; ag[10] = d1; ag[11] = d2;
+        const float e0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
+        const float e1 = A[3] * d0 + A[4] * d1 + A[5] * d2;
+        const float e2 = A[6] * d0 + A[7] * d1 + A[8] * d2;
+        d0 = e0; d1 = e1; d2 = e2;
+      }
+      if (a.ws.d_out3) reinterpret_cast<float4*>(a.ws.d_out3)[p] = make_float4(d0, d1, d2, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) sAffP[s * 12 + j] = ag[j];
+    sDO[s * 4] = d0; sDO[s * 4 + 1] = d1; sDO[s * 4 + 2] = d2; sDO[s * 4 + 3] = 0.f;
+  } else if (t < TILE * K + TILE + 32) {
+    sDB[t - TILE * K - TILE] = 0.f;
+  } else if (PTSG && t < TILE * K + TILE + 32 + 64) {
+    sDP[t - TILE * K - TILE - 32] = 0.f;
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- colour trunk, wave w = hidden channel tile w
+  {
+    const int nt = wave;
+    // G = d_out3 * W_out  (output_linear.weight [3][128]), channel 16 nt + 4 g + r
+    f32x4 G;
+    {
+      const float d0 = sDO[rl * 4], d1 = sDO[rl * 4 + 1], d2 = sDO[rl * 4 + 2];
+      const float* wo = M + MO(PI_C_OUT) + nt * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G[r] = d0 * wo[r] + d1 * wo[HC + r] + d2 * wo[2 * HC + r];
+    }
+    f32x4 dccp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dEc = {0.f, 0.f, 0.f, 0.f};       // waves 0..2: dL/d(colour embedding) tile (PTSG)
+    auto ld_y = [&](int i) {
+      return *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g);
+    };
+    f32x4 ynext = ld_y(4);
+    auto layer = [&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      constexpr int BLs[5] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4};
+      constexpr int BLf[5] = {BL_CF0, BL_CF1, BL_CF2, BL_CF3, BL_CF4};
+      sched_fence_b();
+      // this layer's weight fragments: hidden-part tile nt of W_i^T (8 groups), the two fc_c tiles for group nt
+      f32x4 wq[8], wc[2];
+      const int fb = bfirst(BLs[i]);
+      if (i > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, fb + nt * 8 + q, lane);
+      }
+      wc[0] = ldfragb(WB, bfirst(BLf[i]) + 0 * 8 + nt, lane);
+      wc[1] = ldfragb(WB, bfirst(BLf[i]) + 1 * 8 + nt, lane);
+      const f32x4 y = ynext;
+      if (i > 0) ynext = ld_y(i > 0 ? i - 1 : 0);
+      sched_fence_b();
+      // step A: dz = G * act'(y)
+      f32x4 dz;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[r] = G[r] * softplus100_grad_from_out(y[r]);
+      if (parg) {
+        const size_t o_ = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
+        *reinterpret_cast<f32x4*>(a.ws.c_dz + o_) = dz;
+        *reinterpret_cast<f32x4*>(a.ws.c_g + o_) = G;
+      }
+      float* buf = sDZ + (i & 1) * 8 * FRAG;
+      *reinterpret_cast<f32x4*>(buf + nt * FRAG + lane * 4) = dz;
+      // step B (K-split): dL/dc partial += Wc_i^T[:, own 16 channels] G
+      mma4b(dccp[0], wc[0], G);
+      mma4b(dccp[1], wc[1], G);
+      lds_barrier();
+      // step C: dL/d(input of layer i) = W_i^T dz, hidden part (this wave's 16 channels), all 128 dz channels
+      if (i > 0) {
+        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+        f32x4 z0 = *reinterpret_cast<const f32x4*>(buf + lane * 4), z1 = *reinterpret_cast<const f32x4*>(buf + FRAG + lane * 4);
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          sched_fence_b();
+          const f32x4 c0 = z0, c1 = z1;
+          if (q < 6) {
+            z0 = *reinterpret_cast<const f32x4*>(buf + (q + 2) * FRAG + lane * 4);
+            z1 = *reinterpret_cast<const f32x4*>(buf + (q + 3) * FRAG + lane * 4);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { ga = mfma16(wq[q][r], c0[r], ga); gb = mfma16(wq[q + 1][r], c1[r], gb); }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[r] = ga[r] + gb[r];
+      }
+      if (PTSG && (i == 3 || i == 0) && wave < 3) {   // embedding part: input tiles 8..10 of the skip layer, 0..2 of layer 0
+        const int tile0 = (i == 3) ? 8 : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          mma4b(dEc, ldfragb(WB, fb + (tile0 + wave) * 8 + q, lane), *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4));
+      }
+    };
+    layer(std::integral_constant<int, 4>{});
+    layer(std::integral_constant<int, 3>{});
+    layer(std::integral_constant<int, 2>{});
+    layer(std::integral_constant<int, 1>{});
+    layer(std::integral_constant<int, 0>{});
+    // the eight K-split partial tiles of dL/dc meet in LDS
+    *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 0) * FRAG + lane * 4) = dccp[0];
+    *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 1) * FRAG + lane * 4) = dccp[1];
+    if (PTSG && wave < 3) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int e = 16 * wave + 4 * g + r; if (e < EC) sDE[rl * LD_E2 + e] = dEc[r]; }
+    }
+  }
+  lds_barrier();
+  {   // 512 threads, 512 elements [it][lane][r]: sum over the waves, mask samples without neighbours
+    const int e = t;
+    float v = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) v += sDccP[w8 * 2 * FRAG + e];
+    const int s = (e >> 2) & 15;
+    sDcc[e] = sHas[s] ? v : 0.f;
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- colour features: scatter / F_theta backward
+  {
+    const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane
+    const int s = row >> 3;
+    const int i = sI[row];
+    const float wgt = sW[row];
+    const bool has = sHas[s] != 0;
+    const size_t grow = (size_t)p0 * K + row;
+    const bool live = (p0 + s) < a.P;
+    f32x4 dc[2];     // dL/dc_col of this row's sample, channels 16 jt + 4 g + r
+    dc[0] = *reinterpret_cast<const f32x4*>(sDcc + (g * 16 + s) * 4);
+    dc[1] = *reinterpret_cast<const f32x4*>(sDcc + FRAG + (g * 16 + s) * 4);
+    int dst = -1;
+    if (i >= 0 && has && wgt != 0.f) dst = o.row_map ? o.row_map[i] : i;
+    if (!relpos) {
+      // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
+      if (featg && dst >= 0) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], wgt * dc[jt][r]);
+      }
+      if constexpr (PTSG) {
+        float v = 0.f;
+        if (i >= 0 && has) {
+          const float* frow = a.col_feats + (size_t)i * C + 4 * g;
+          const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow), f1 = *reinterpret_cast<const f32x4*>(frow + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v += f0[r] * dc[0][r] + f1[r] * dc[1][r];
+        }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (g == 0) sGW[row] = v;
+      }
+    } else {
+      // ---- F_theta backward, rows private to this wave.  d_nf[row][ch] = w[row] * dC[s][ch]
+      f32x4 dnf[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dnf[jt][r] = wgt * dc[jt][r];
+        if (parg) *reinterpret_cast<f32x4*>(a.ws.n_dnf + grow * C + jt * 16 + 4 * g) = dnf[jt];
+      }
+      if constexpr (PTSG) {   // dL/dw[s][k] = sum_ch nf[row][ch] dC[s][ch]
+        float v = 0.f;
+        if (live) {
+          const f32x4 n0 = *reinterpret_cast<const f32x4*>(a.ws.n_out + grow * C + 4 * g);
+          const f32x4 n1 = *reinterpret_cast<const f32x4*>(a.ws.n_out + grow * C + 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v += n0[r] * dc[0][r] + n1[r] * dc[1][r];
+        }
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        if (g == 0) sGW[row] = v;
+      }
+      // dH1^T[hid][row] = W2^T d_nf^T (linear2.weight [32][128]): 8 hidden tiles, 2 k-groups
+      f32x4 dh[8];
+      constexpr int b2 = bfirst(BL_N2);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        sched_fence_b();
+        f32x4 wf8[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) wf8[it] = ldfragb(WB, b2 + it * 2 + q, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int it = 0; it < 8; ++it) dh[it] = mfma16(wf8[it][r], dnf[q][r], dh[it]);
+      }
+      // dz1 = dH1 * softplus'(h1)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow * HC + it * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[it][r] = live ? dh[it][r] * softplus100_grad_from_out(h1[r]) : 0.f;
+        if (parg) *reinterpret_cast<f32x4*>(a.ws.n_dz1 + grow * HC + it * 16 + 4 * g) = dh[it];
+      }
+      // dX1^T[x][row] = W1^T dz1^T (linear1.weight [128][52]): input tiles (feat 0..15, feat 16..31, rel 0..15, rel 16..19)
+      f32x4 dx[4];
+      constexpr int b1 = bfirst(BL_N1);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) dx[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool need_rel = parg || PTSG;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        sched_fence_b();
+        f32x4 wf4[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) wf4[it] = ldfragb(WB, b1 + it * 8 + q, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dx[0] = mfma16(wf4[0][r], dh[q][r], dx[0]);
+          dx[1] = mfma16(wf4[1][r], dh[q][r], dx[1]);
+          if (need_rel) { dx[2] = mfma16(wf4[2][r], dh[q][r], dx[2]); dx[3] = mfma16(wf4[3][r], dh[q][r], dx[3]); }
+        }
+      }
+      // feature part -> scattered into the colour feature rows straight from the accumulators
+      if (featg && dst >= 0) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], dx[jt][r]);
+      }
+      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]; one (row, frequency) pair per lane
+      if (need_rel) {
+        float* xw = sXe + wave * 16 * LD_X2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xw[rl * LD_X2 + 4 * g + r] = dx[2][r];
+          if (g == 0) xw[rl * LD_X2 + 16 + r] = dx[3][r];
+        }
+        wave_lds_sync();
+        const float* Brel = M + MO(PI_C_BREL);
+        for (int e = lane; e < 16 * ERF; e += 64) {
+          const int r2 = e / ERF, f = e - r2 * ERF;
+          const int row2 = 16 * wave + r2, s2 = row2 >> 3;
+          const bool lv = (p0 + s2) < a.P && sI[row2] >= 0;
+          if (!lv) continue;
+          const float rx = sRel[row2 * 3], ry = sRel[row2 * 3 + 1], rz = sRel[row2 * 3 + 2];
+          float sn, cs;
+          if (a.ws.n_x) {     // the forward pass saved [sin | cos] in the first 20 columns of F_theta's input
+            const float* xr = a.ws.n_x + ((size_t)p0 * K + row2) * NX;
+            sn = xr[f]; cs = xr[ERF + f];
+          } else {
+            fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
+          }
+          const float dy2 = TWO_PI * (xw[r2 * LD_X2 + f] * cs - xw[r2 * LD_X2 + ERF + f] * sn);
+          if (parg) {
+            atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
+            atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
+          }
+          if constexpr (PTSG) {   // rel = x_k - p  =>  dp -= d_rel
+            atomic_add_f32(&sDP[s2 * 4], -dy2 * Brel[f]); atomic_add_f32(&sDP[s2 * 4 + 1], -dy2 * Brel[ERF + f]);
+            atomic_add_f32(&sDP[s2 * 4 + 2], -dy2 * Brel[2 * ERF + f]);
+          }
+        }
+      }
+    }
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- position gradient of the colour branch (tracker)
+  if constexpr (PTSG) {
+    // (1) interpolation weights: w = a/S, a = [D<=r2]/(D+1e-10), D = |x_k - p|^2   (decoder.py:143-160)
+    if (t < TILE * K) {
+      const int s = t >> 3;
+      const float rx = sRel[t * 3], ry = sRel[t * 3 + 1], rz = sRel[t * 3 + 2];
+      const float D = (sI[t] >= 0) ? __fadd_rn(__fadd_rn(__fmul_rn(rx, rx), __fmul_rn(ry, ry)), __fmul_rn(rz, rz))
+                                   : __int_as_float(0x7F800000);
+      const float av = (D > sPts[s * 4 + 3]) ? 0.f : 1.0f / (D + 1e-10f);
+      float S1 = av;
+      S1 += __shfl_xor(S1, 1); S1 += __shfl_xor(S1, 2); S1 += __shfl_xor(S1, 4);
+      const float gw = sHas[s] ? sGW[t] : 0.f;
+      float dot = gw * sW[t];
+      dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+      const float da = (gw - dot) / fmaxf(S1, 1e-12f);
+      const float dD = -da * av * av;                 // a = 1/(D+eps) -> da/dD = -a^2 ; masked slots: a = 0
+      float px = -2.f * dD * rx, py = -2.f * dD * ry, pz = -2.f * dD * rz;      // dD/dp = -2 (x_k - p)
+      px += __shfl_xor(px, 1); px += __shfl_xor(px, 2); px += __shfl_xor(px, 4);
+      py += __shfl_xor(py, 1); py += __shfl_xor(py, 2); py += __shfl_xor(py, 4);
+      pz += __shfl_xor(pz, 1); pz += __shfl_xor(pz, 2); pz += __shfl_xor(pz, 4);
+      if ((t & 7) == 0) { atomic_add_f32(&sDP[s * 4], px); atomic_add_f32(&sDP[s * 4 + 1], py); atomic_add_f32(&sDP[s * 4 + 2], pz); }
+    } else if (t < TILE * K + TILE * ECF) {
+      // (2) colour Fourier embedding [sin, cos] (20 + 20): one (sample, frequency) pair per thread
+      const int e = t - TILE * K;
+      const int s = e / ECF, f = e - s * ECF;
+      float sn, cs;
+      fast_sincosf(fourier_phase(sPts[s * 4], sPts[s * 4 + 1], sPts[s * 4 + 2], a.Bcol, ECF, f), sn, cs);
+      const float dy2 = TWO_PI * (sDE[s * LD_E2 + f] * cs - sDE[s * LD_E2 + ECF + f] * sn);
+      atomic_add_f32(&sDP[s * 4], dy2 * a.Bcol[f]); atomic_add_f32(&sDP[s * 4 + 1], dy2 * a.Bcol[ECF + f]);
+      atomic_add_f32(&sDP[s * 4 + 2], dy2 * a.Bcol[2 * ECF + f]);
+    }
+    lds_barrier();
+    if (t < TILE && p0 + t < a.P)
+      reinterpret_cast<float4*>(a.ws.dp)[p0 + t] = make_float4(sDP[t * 4], sDP[t * 4 + 1], sDP[t * 4 + 2], 0.f);
+  }
+  // tile-level reductions that go out with a handful of global atomics
+  if (parg && relpos && t < 3 * ERF && o.g_brel) atomic_add_f32(&o.g_brel[t], sDB[t]);
+  if ((a.flags & PSL_HAS_AFFINE) && t < 12 && o.g_affine) {
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < TILE; ++s) v += sAffP[s * 12 + t];
+    atomic_add_f32(&o.g_affine[t], v);
+  }
+}
+
+template <bool PTSG, bool COLOR>
+__global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (COLOR && (int)blockIdx.x < color_tiles) {
+    color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE);
+  } else {
+    const int tile = ((int)blockIdx.x - color_tiles) * 8 + (int)(threadIdx.x >> 6);
+    const int p0 = tile * TILE;
+    if (p0 >= a.P) return;
+    geo_tile_bwd<PTSG>(a, o, WB, p0);
+  }
+}
+
+int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, float* small, hipStream_t s) {
+  Bwd2Out o;
+  o.g_geo = g.g_geo_feats; o.g_col = g.g_col_feats; o.row_map = g.feat_row_map;
+  o.g_brel = small;
+  o.g_affine = small + 32;
+  const int tiles = (a.P + TILE - 1) / TILE;
+  const int geo_wgs = (tiles + 7) / 8;
+  const bool color = a.flags & PSL_STAGE_COLOR;
+  const bool ptsg = a.flags & PSL_PTS_GRAD;
+  const size_t lds = sizeof(float) * Bwd2Lds::total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const float* WB = ctx->wb;
+  if (color) {
+    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(tiles + geo_wgs), dim3(WG), lds, s, a, o, WB, tiles);
+    else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(tiles + geo_wgs), dim3(WG), lds, s, a, o, WB, tiles);
+  } else {
+    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(geo_wgs), dim3(WG), 0, s, a, o, WB, 0);
+    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(geo_wgs), dim3(WG), 0, s, a, o, WB, 0);
+  }
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+}  // namespace psl

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 #include "psl_decode.h"
 #include "psl_frag.h"
 
@@ -35,6 +36,9 @@ __device__ __forceinline__ void mma4(f32x4& acc, const f32x4& a, const f32x4& b)
   acc = mfma16(a[2], b[2], acc);
   acc = mfma16(a[3], b[3], acc);
 }
+// nothing is scheduled across this point: pins the hand-written order "request the fragments of step s + D, then issue
+// the MFMAs of step s" (left alone, the scheduler hoists every data-independent weight load to the top and spills)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ float group8_sum(float v) {   // sum over the 8 lanes that share (lane & 15) >> 3 and lane >> 4
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
   return v;
@@ -46,14 +50,46 @@ struct Fwd2Lds {
 };
 
 // ------------------------------------------------------------------------------------------------ geometry role
+// The geometry decoder of one tile as a flat list of "steps" (one k-group = 4 k-steps for both 16-column output tiles):
+// fragment indices, which registers feed the B operand, which accumulator pair receives.  The list is walked fully
+// unrolled with the weight fragments of step s + GEO_AHEAD requested before the MFMAs of step s (the weights do not
+// depend on the data, so the prefetch runs across layer boundaries).
+struct GStep { int f0, f1, bsel, dst, layer_end; };   // bsel: 0..5 embedding groups, 6..7 hidden, 8..9 interpolated feature
+struct GSteps { GStep s[40]; int n; };
+constexpr GSteps make_geo_steps() {
+  GSteps g{};
+  int n = 0;
+  const int FLs[5] = {FL_G0, FL_G1, FL_G2, FL_G3, FL_G4};
+  const int FLf[5] = {FL_GF0, FL_GF1, FL_GF2, FL_GF3, FL_GF4};
+  for (int i = 0; i < 5; ++i) {
+    const int L = FLs[i], nq = kFLayers[L].ngroups, first = ffirst(L);
+    for (int q = 0; q < nq; ++q) {
+      int bsel = 0;
+      if (i == 0) bsel = q;
+      else if (i == 3) bsel = q < 6 ? q : 6 + (q - 6);
+      else bsel = 6 + q;
+      g.s[n++] = GStep{first + q, first + nq + q, bsel, 0, 0};
+    }
+    const int ff = ffirst(FLf[i]);
+    for (int q = 0; q < 2; ++q) g.s[n++] = GStep{ff + q, ff + 2 + q, 8 + q, 1, q == 1 ? i + 1 : 0};
+  }
+  for (int q = 0; q < 2; ++q) g.s[n++] = GStep{ffirst(FL_GOUT) + q, -1, 6 + q, 2, 0};
+  g.n = n;
+  return g;
+}
+constexpr GSteps kGeo = make_geo_steps();
+constexpr int GEO_AHEAD = 2;
+
 // One wavefront, 16 samples: lane (rl = sample, g).  Writes raw[p].w (and xyz = 0 when `full_raw`), g_y, w (when asked).
 __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __restrict__ WF, int p0, bool full_raw, bool save_w) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
-  const bool live = p0 + rl < a.P;
   const float* __restrict__ M = a.master;
+  f32x4 W0[kGeo.n], W1[kGeo.n];
+  PSL_STAMP(32);
   const SampleGeom sg = sample_geom(a, p);
-  // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171)
+  // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171); no control flow:
+  // absent neighbours (index -1) read point 0 and get weight 0
   int nb[K];
   {
     const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K);
@@ -61,38 +97,49 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
     nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
   }
   float w[K];
-  float wsum = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    float D = __int_as_float(0x7F800000);
-    if (nb[k] >= 0) { const float4 q = a.pos[nb[k]]; D = dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z); }
+    const float4 q = a.pos[max(nb[k], 0)];
+    const float D = (nb[k] >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
     w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
   }
-  // the reference sums the 8 weights with a pairwise tree inside F.normalize(p=1); any order is within 1 ulp
-  wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+  // the reference sums the 8 weights inside F.normalize(p=1); any order is within 1 ulp
+  const float wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
   const float inv = fmaxf(wsum, 1e-12f);
 #pragma unroll
   for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
-  if (save_w && live && g == 0) {
-    *reinterpret_cast<float4*>(a.ws.w + (size_t)p * K) = make_float4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<float4*>(a.ws.w + (size_t)p * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
+  if (save_w && g == 0) {     // rows up to Ppad exist in every workspace buffer: no bounds test on stores
+    *reinterpret_cast<float4*>(a.ws.w + (size_t)(p0 + rl) * K) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4*>(a.ws.w + (size_t)(p0 + rl) * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
   }
   const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150)
-  f32x4 cg[2];
+  PSL_STAMP(33);
+  f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int jt = 0; jt < 2; ++jt) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    if ((k & 3) == 0) sched_fence();      // four neighbour rows (8 vector loads) in flight at a time
+    const float* row = a.geo_feats + (size_t)max(nb[k], 0) * C + 4 * g;
+    const f32x4 f0 = *reinterpret_cast<const f32x4*>(row), f1 = *reinterpret_cast<const f32x4*>(row + 16);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (nb[k] >= 0) {
-        const f32x4 f = *reinterpret_cast<const f32x4*>(a.geo_feats + (size_t)nb[k] * C + jt * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = __fadd_rn(acc[r], __fmul_rn(w[k], f[r]));
-      }
+    for (int r = 0; r < 4; ++r) {
+      cg[0][r] = __fadd_rn(cg[0][r], __fmul_rn(w[k], f0[r]));
+      cg[1][r] = __fadd_rn(cg[1][r], __fmul_rn(w[k], f1[r]));
     }
-    if (!has) acc = *reinterpret_cast<const f32x4*>(a.fb_geo + jt * 16 + 4 * g);
-    cg[jt] = acc;
   }
+  {
+    const f32x4 fb0 = *reinterpret_cast<const f32x4*>(a.fb_geo + 4 * g), fb1 = *reinterpret_cast<const f32x4*>(a.fb_geo + 16 + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
+  }
+  sched_fence();
+  PSL_STAMP(34);
+  // weight fragments of the first steps: their L2 latency elapses behind the 24 sine evaluations
+#pragma unroll
+  for (int st = 0; st < GEO_AHEAD; ++st) {
+    W0[st] = ldfrag(WF, kGeo.s[st].f0, lane);
+    if (kGeo.s[st].f1 >= 0) W1[st] = ldfrag(WF, kGeo.s[st].f1, lane);
+  }
+  sched_fence();
   // ---- Fourier features sin(2 pi p . B) (decoder.py:8-37), channel 16 q + 4 g + r
   const float* __restrict__ Bg = M + MO(PI_G_B);
   f32x4 eg[6];
@@ -100,58 +147,80 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
   for (int q = 0; q < 6; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = 16 * q + 4 * g + r;
-      eg[q][r] = (f < EG) ? fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f)) : 0.f;
+      const int f = min(16 * q + 4 * g + r, EG - 1);
+      const float v = fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
+      eg[q][r] = (16 * q + 4 * g + r < EG) ? v : 0.f;
     }
+  PSL_STAMP(35);
   // ---- five blocks: h = relu(W_i h + b_i) + (Wc_i c + bc_i); the embedding is re-attached after block 2
   f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[2], u[2], oo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = ldbias(WF, fbias(FL_G0), 0, g); acc[1] = ldbias(WF, fbias(FL_G0), 1, g);
+  u[0] = ldbias(WF, fbias(FL_GF0), 0, g); u[1] = ldbias(WF, fbias(FL_GF0), 1, g);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    constexpr int FLs[5] = {FL_G0, FL_G1, FL_G2, FL_G3, FL_G4};
-    constexpr int FLf[5] = {FL_GF0, FL_GF1, FL_GF2, FL_GF3, FL_GF4};
-    const int L = FLs[i], Lf = FLf[i];
-    const int first = ffirst(L), nq = kFLayers[L].ngroups;
-    f32x4 acc[2], u[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { acc[nt] = ldbias(WF, fbias(L), nt, g); u[nt] = ldbias(WF, fbias(Lf), nt, g); }
-    if (i == 0 || i == 3) {
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) mma4(acc[nt], ldfrag(WF, first + nt * nq + q, lane), eg[q]);
+  for (int st = 0; st < kGeo.n; ++st) {
+    sched_fence();
+    if (st + GEO_AHEAD < kGeo.n) {
+      W0[st + GEO_AHEAD] = ldfrag(WF, kGeo.s[st + GEO_AHEAD].f0, lane);
+      if (kGeo.s[st + GEO_AHEAD].f1 >= 0) W1[st + GEO_AHEAD] = ldfrag(WF, kGeo.s[st + GEO_AHEAD].f1, lane);
     }
-    if (i != 0) {
-      const int qo = (i == 3) ? 6 : 0;
+    const int bs = kGeo.s[st].bsel;
+    const f32x4 b = bs < 6 ? eg[bs < 6 ? bs : 0] : (bs < 8 ? h[bs < 8 ? (bs >= 6 ? bs - 6 : 0) : 0] : cg[bs >= 8 ? bs - 8 : 0]);
+    if (kGeo.s[st].dst == 0) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+      for (int r = 0; r < 4; ++r) { acc[0] = mfma16(W0[st][r], b[r], acc[0]); acc[1] = mfma16(W1[st][r], b[r], acc[1]); }
+    } else if (kGeo.s[st].dst == 1) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) mma4(acc[nt], ldfrag(WF, first + nt * nq + qo + q, lane), h[q]);
+      for (int r = 0; r < 4; ++r) { u[0] = mfma16(W0[st][r], b[r], u[0]); u[1] = mfma16(W1[st][r], b[r], u[1]); }
+    } else {
+      mma4(oo[st & 1], W0[st], b);
     }
+    if (kGeo.s[st].layer_end) {
+      const int i = kGeo.s[st].layer_end - 1;
+      PSL_STAMP(36 + i);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 y;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) mma4(u[nt], ldfrag(WF, ffirst(Lf) + nt * 2 + q, lane), cg[q]);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      f32x4 y;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { y[r] = fmaxf(acc[nt][r], 0.f); h[nt][r] = y[r] + u[nt][r]; }
-      if (a.ws.g_y && live) *reinterpret_cast<f32x4*>(a.ws.g_y + ((size_t)i * a.ws.Ppad + p) * HG + nt * 16 + 4 * g) = y;
+        for (int r = 0; r < 4; ++r) { y[r] = fmaxf(acc[nt][r], 0.f); h[nt][r] = y[r] + u[nt][r]; }
+        if (a.ws.g_y) *reinterpret_cast<f32x4*>(a.ws.g_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HG + nt * 16 + 4 * g) = y;
+      }
+      if (i < 4) {
+        constexpr int FLs[5] = {FL_G0, FL_G1, FL_G2, FL_G3, FL_G4};
+        constexpr int FLf[5] = {FL_GF0, FL_GF1, FL_GF2, FL_GF3, FL_GF4};
+        acc[0] = ldbias(WF, fbias(FLs[i + 1]), 0, g); acc[1] = ldbias(WF, fbias(FLs[i + 1]), 1, g);
+        u[0] = ldbias(WF, fbias(FLf[i + 1]), 0, g); u[1] = ldbias(WF, fbias(FLf[i + 1]), 1, g);
+      }
     }
   }
+  PSL_STAMP(41);
   // ---- output_linear 32 -> 1 as one padded tile: row 0 of the accumulator = occupancy logit of sample rl
-  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-  mma4(o0, ldfrag(WF, ffirst(FL_GOUT) + 0, lane), h[0]);
-  mma4(o1, ldfrag(WF, ffirst(FL_GOUT) + 1, lane), h[1]);
-  if (g == 0 && live) {
+  if (g == 0 && p0 + rl < a.P) {
     // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
-    const float occ = has ? (o0[0] + o1[0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
+    const float occ = has ? (oo[0][0] + oo[1][0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
     if (full_raw) reinterpret_cast<float4*>(a.ws.raw)[p] = make_float4(0.f, 0.f, 0.f, occ);
     else a.ws.raw[(size_t)p * 4 + 3] = occ;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ colour role
+// weights of trunk layer i for output tile nt: up to 12 fragments of W_i and 2 of the fc_c layer
+// (layer 3 has 12: its last four are requested once the four embedding fragments have been consumed, see below)
+struct TrunkW { f32x4 w[8]; f32x4 c[2]; f32x4 bias, cbias; };
+constexpr int kTrunkL[5] = {FL_C0, FL_C1, FL_C2, FL_C3, FL_C4};
+constexpr int kTrunkF[5] = {FL_CF0, FL_CF1, FL_CF2, FL_CF3, FL_CF4};
+template <int I>
+__device__ __forceinline__ void load_trunk(TrunkW& t, const float* __restrict__ WF, int nt, int lane, int g) {
+  constexpr int nq = kFLayers[kTrunkL[I]].ngroups;
+  const int base = ffirst(kTrunkL[I]) + nt * nq;
+#pragma unroll
+  for (int q = 0; q < (nq < 8 ? nq : 8); ++q) t.w[q] = ldfrag(WF, base + q, lane);
+  t.c[0] = ldfrag(WF, ffirst(kTrunkF[I]) + nt * 2 + 0, lane);
+  t.c[1] = ldfrag(WF, ffirst(kTrunkF[I]) + nt * 2 + 1, lane);
+  t.bias = ldbias(WF, fbias(kTrunkL[I]), nt, g);
+  t.cbias = ldbias(WF, fbias(kTrunkF[I]), nt, g);
+}
+
 __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __restrict__ WF, float* smem, int p0) {
   using L = Fwd2Lds;
   int* sI = (int*)(smem + L::oI);           // [16][8]
@@ -165,7 +234,17 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool relpos = (a.flags & 0x10000) != 0;
   const float* __restrict__ M = a.master;
-  auto live = [&](int s) { return p0 + s < a.P; };
+  // Every workspace buffer holds Ppad (a multiple of the tile) rows, so saves need no bounds test; slots past the end
+  // of the batch compute on a clamped sample and their rows are never read.
+
+  PSL_STAMP(0);
+  // F_theta's first weight fragments do not depend on anything: requested before the neighbour set-up
+  constexpr int f1 = ffirst(FL_N1);
+  f32x4 afn[4];
+  if (relpos) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + j * 4 + 0, lane);
+  }
 
   // ---------------------------------------------------------------- phase 0: neighbours, weights (one thread per pair)
   if (t < TILE * K) {
@@ -173,24 +252,26 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     const int p = min(p0 + s, a.P - 1);
     const SampleGeom sg = sample_geom(a, p);
     const int i = a.ws.I[(size_t)p * K + k];
-    float nx = 0.f, ny = 0.f, nz = 0.f, D = __int_as_float(0x7F800000);
-    if (i >= 0) { const float4 q = a.pos[i]; nx = q.x; ny = q.y; nz = q.z; D = dist2(nx, ny, nz, sg.x, sg.y, sg.z); }
+    const float4 q = a.pos[max(i, 0)];
+    const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
     float w = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
     float sum = w;
     sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
     w = w / fmaxf(sum, 1e-12f);
     sI[t] = i; sW[t] = w;
-    sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(nx, sg.x) : 0.f;
-    sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(ny, sg.y) : 0.f;
-    sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(nz, sg.z) : 0.f;
-    if (live(s)) a.ws.w[(size_t)p * K + k] = w;
+    sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f;
+    sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
+    sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
+    a.ws.w[(size_t)(p0 + s) * K + k] = w;
     if (k == 0) {
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
       sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
     }
   }
   lds_barrier();
+  PSL_STAMP(1);
 
+  TrunkW tw;
   // ---------------------------------------------------------------- phase F: colour features of the tile
   {
     const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane; 4 lanes (g) share a pair
@@ -199,15 +280,18 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     const float wgt = sW[row];
     const size_t grow = (size_t)p0 * K + row;  // row of the per-pair save buffers
     f32x4 xf[2];
+    {
+      const float* frow = a.col_feats + (size_t)max(i, 0) * C + 4 * g;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(frow), v1 = *reinterpret_cast<const f32x4*>(frow + 16);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-      xf[jt] = (i >= 0) ? *reinterpret_cast<const f32x4*>(a.col_feats + (size_t)i * C + jt * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? v0[r] : 0.f; xf[1][r] = (i >= 0) ? v1[r] : 0.f; }
+    }
     f32x4 cc[2];
     if (relpos) {
       // F_theta input [sin(10) cos(10) | feat(32)] (decoder.py:371-378); this lane holds sin or cos of f = 2 s + (g >> 1)
       const float* __restrict__ Brel = M + MO(PI_C_BREL);
       const float rx = sRel[row * 3], ry = sRel[row * 3 + 1], rz = sRel[row * 3 + 2];
-      f32x4 xe; float xe4;
+      f32x4 xe; float xe4 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) {
         const int f = 2 * ks + (g >> 1);
@@ -215,53 +299,73 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
         const float v = (g & 1) ? cs : sn;
         if (ks < 4) xe[ks] = v; else xe4 = v;
-        if (a.ws.n_x && live(s)) a.ws.n_x[grow * NX + (g & 1) * ERF + f] = v;
+        if (a.ws.n_x) a.ws.n_x[grow * NX + (g & 1) * ERF + f] = v;
       }
-      if (a.ws.n_x && live(s)) {
+      if (a.ws.n_x) {
         *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 4 * g) = xf[0];
         *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 16 + 4 * g) = xf[1];
       }
-      // linear1 52 -> 128: 8 independent accumulator tiles, 13 k-steps each
+      PSL_STAMP(2);
+      // linear1 52 -> 128 in two halves of four output tiles; the fragments of step + 1 are in flight during step
       f32x4 hid[8];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) hid[nt] = ldbias(WF, fbias(FL_N1), nt, g);
-      constexpr int f1 = ffirst(FL_N1);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        f32x4 af[8];
+      for (int st = 0; st < 8; ++st) {
+        sched_fence();
+        const int half = st >> 2, q = st & 3;
+        f32x4 af[4];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) af[nt] = ldfrag(WF, f1 + nt * 4 + q, lane);
-        const f32x4 b = (q == 0) ? xf[0] : (q == 1 ? xf[1] : xe);
+        for (int j = 0; j < 4; ++j) af[j] = afn[j];
+        if (st < 7) {
+          const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+          for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + (4 * h2 + j) * 4 + q2, lane);
+        }
+        if (q < 3) {
+          const f32x4 b = (q == 0) ? xf[0] : (q == 1 ? xf[1] : xe);
 #pragma unroll
-          for (int nt = 0; nt < 8; ++nt) hid[nt] = mfma16(af[nt][r], b[r], hid[nt]);
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][r], b[r], hid[4 * half + j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][0], xe4, hid[4 * half + j]);
+        }
       }
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) hid[nt] = mfma16(ldfrag(WF, f1 + nt * 4 + 3, lane)[0], xe4, hid[nt]);
+      PSL_STAMP(3);
+      // linear2's fragments: two per hidden group, the next pair in flight
+      constexpr int f2 = ffirst(FL_N2);
+      f32x4 a0n = ldfrag(WF, f2 + 0, lane), a1n = ldfrag(WF, f2 + 8 + 0, lane);
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100(hid[nt][r]);
-        if (a.ws.n_h1 && live(s)) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
+        for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100_nb(hid[nt][r]);
+        if (a.ws.n_h1) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
       }
+      PSL_STAMP(4);
       // linear2 128 -> 32
       f32x4 nf[2];
       nf[0] = ldbias(WF, fbias(FL_N2), 0, g); nf[1] = ldbias(WF, fbias(FL_N2), 1, g);
-      constexpr int f2 = ffirst(FL_N2);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 a0 = ldfrag(WF, f2 + q, lane), a1 = ldfrag(WF, f2 + 8 + q, lane);
+        sched_fence();
+        const f32x4 a0 = a0n, a1 = a1n;
+        if (q < 7) { a0n = ldfrag(WF, f2 + q + 1, lane); a1n = ldfrag(WF, f2 + 8 + q + 1, lane); }
 #pragma unroll
         for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[q][r], nf[0]); nf[1] = mfma16(a1[r], hid[q][r], nf[1]); }
       }
+      sched_fence();
+      PSL_STAMP(5);
+      load_trunk<0>(tw, WF, wave, lane, g);     // the trunk's first layer: in flight across the reduction and the barrier
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        if (a.ws.n_out && live(s)) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
+        if (a.ws.n_out) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, nf[nt][r]));   // sum_k w_k F_theta(.)  (decoder.py:380-385)
       }
     } else {
+      load_trunk<0>(tw, WF, wave, lane, g);
       // plain interpolation sum_k w_k f[I_k] (decoder.py:380-385 without the neighbour MLP)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -269,16 +373,21 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, xf[nt][r]));
     }
     if ((rl & 7) == 0) {     // one lane per (sample, g) publishes the tile's colour features in fragment order
+      const bool has = sHas[s] != 0;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        f32x4 c = cc[nt];
-        if (!sHas[s]) c = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
+        f32x4 c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = has ? cc[nt][r] : fb[r];
         *reinterpret_cast<f32x4*>(sCc + nt * FRAG + (g * 16 + s) * 4) = c;
-        if (live(s)) *reinterpret_cast<f32x4*>(a.ws.cc + (size_t)(p0 + s) * C + nt * 16 + 4 * g) = c;
+        *reinterpret_cast<f32x4*>(a.ws.cc + (size_t)(p0 + s) * C + nt * 16 + 4 * g) = c;
       }
     }
   }
+  PSL_STAMP(6);
   lds_barrier();
+  PSL_STAMP(7);
 
   // ---------------------------------------------------------------- phase T: colour trunk, wave w = output tile w
   {
@@ -292,64 +401,85 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       for (int ks = 0; ks < 5; ++ks) {
         const int f = 4 * ks + g;
         fast_sincosf(fourier_phase(x, y, z, a.Bcol, ECF, f), sn[ks], cs[ks]);
-        if (wave == 0 && a.ws.c_emb && live(rl)) {
+        if (wave == 0 && a.ws.c_emb) {
           a.ws.c_emb[(size_t)(p0 + rl) * EC + f] = sn[ks];
           a.ws.c_emb[(size_t)(p0 + rl) * EC + ECF + f] = cs[ks];
         }
       }
     }
     const f32x4 esn = {sn[0], sn[1], sn[2], sn[3]}, ecs = {cs[0], cs[1], cs[2], cs[3]};
-    f32x4 hp[8];     // previous hidden tile, all 128 channels (B operands)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      constexpr int FLs[5] = {FL_C0, FL_C1, FL_C2, FL_C3, FL_C4};
-      constexpr int FLf[5] = {FL_CF0, FL_CF1, FL_CF2, FL_CF3, FL_CF4};
-      const int Lw = FLs[i], Lf = FLf[i];
-      const int nq = kFLayers[Lw].ngroups, base = ffirst(Lw) + nt * nq;
+    auto layer = [&](auto I_) {
+      constexpr int i = decltype(I_)::value;
+      const float* bufp = sH + ((i + 1) & 1) * 8 * FRAG;      // the previous layer's hidden tile
       // three independent accumulator chains: even / odd k-groups of W_i h, and Wc_i c
-      f32x4 acc_a = ldbias(WF, fbias(Lw), nt, g), acc_b = {0.f, 0.f, 0.f, 0.f}, u = ldbias(WF, fbias(Lf), nt, g);
-      mma4(u, ldfrag(WF, ffirst(Lf) + nt * 2 + 0, lane), ccb0);
+      f32x4 acc_a = tw.bias, acc_b = {0.f, 0.f, 0.f, 0.f}, u = tw.cbias;
+      f32x4 hq0, hq1;
+      if (i != 0) { hq0 = *reinterpret_cast<const f32x4*>(bufp + lane * 4); hq1 = *reinterpret_cast<const f32x4*>(bufp + FRAG + lane * 4); }
+      sched_fence();
+      mma4(u, tw.c[0], ccb0);
       if (i == 0 || i == 3) {
-        const f32x4 w0 = ldfrag(WF, base + 0, lane), w1 = ldfrag(WF, base + 1, lane), w2 = ldfrag(WF, base + 2, lane),
-                    w3 = ldfrag(WF, base + 3, lane);
-        mma4(acc_a, w0, esn);
-        mma4(acc_b, w2, ecs);
-        acc_a = mfma16(w1[0], sn[4], acc_a);
-        acc_b = mfma16(w3[0], cs[4], acc_b);
+        mma4(acc_a, tw.w[0], esn);
+        mma4(acc_b, tw.w[2], ecs);
+        acc_a = mfma16(tw.w[1][0], sn[4], acc_a);
+        acc_b = mfma16(tw.w[3][0], cs[4], acc_b);
       }
-      mma4(u, ldfrag(WF, ffirst(Lf) + nt * 2 + 1, lane), ccb1);
+      mma4(u, tw.c[1], ccb1);
       if (i != 0) {
-        const int qo = (i == 3) ? 4 : 0;
+        // slot of hidden group q: layer 3 keeps groups 0..3 in slots 4..7 and fetches groups 4..7 into slots 0..3, which
+        // its embedding fragments have just left
+        if (i == 3) {
+          sched_fence();
+          const int base = ffirst(FL_C3) + nt * 12;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tw.w[q] = ldfrag(WF, base + 8 + q, lane);
+        }
 #pragma unroll
         for (int q = 0; q < 8; q += 2) {
-          const f32x4 wa = ldfrag(WF, base + qo + q, lane), wb = ldfrag(WF, base + qo + q + 1, lane);
+          sched_fence();
+          const f32x4 h0 = hq0, h1 = hq1;
+          if (q < 6) {
+            hq0 = *reinterpret_cast<const f32x4*>(bufp + (q + 2) * FRAG + lane * 4);
+            hq1 = *reinterpret_cast<const f32x4*>(bufp + (q + 3) * FRAG + lane * 4);
+          }
+          const int s0 = (i == 3) ? (q < 4 ? 4 + q : q - 4) : q;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { acc_a = mfma16(wa[r], hp[q][r], acc_a); acc_b = mfma16(wb[r], hp[q + 1][r], acc_b); }
+          for (int r = 0; r < 4; ++r) { acc_a = mfma16(tw.w[s0][r], h0[r], acc_a); acc_b = mfma16(tw.w[s0 + 1][r], h1[r], acc_b); }
         }
       }
+      sched_fence();
+      PSL_STAMP(10 + 3 * i);
+      // the next layer's weights are requested now: their L2 latency elapses behind the epilogue and the barrier
+      if constexpr (i < 4) load_trunk<(i < 4 ? i + 1 : 4)>(tw, WF, nt, lane, g);
+      sched_fence();
       f32x4 y, hh;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { y[r] = softplus100(acc_a[r] + acc_b[r]); hh[r] = y[r] + u[r]; }
-      if (a.ws.c_y && live(rl)) {
+      for (int r = 0; r < 4; ++r) { y[r] = softplus100_nb(acc_a[r] + acc_b[r]); hh[r] = y[r] + u[r]; }
+      if (a.ws.c_y) {
         const size_t o = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
         *reinterpret_cast<f32x4*>(a.ws.c_y + o) = y;
         if (a.ws.c_hin) *reinterpret_cast<f32x4*>(a.ws.c_hin + o) = hh;
       }
-      float* buf = sH + (i & 1) * 8 * FRAG;
-      *reinterpret_cast<f32x4*>(buf + nt * FRAG + lane * 4) = hh;
+      *reinterpret_cast<f32x4*>(sH + (i & 1) * 8 * FRAG + nt * FRAG + lane * 4) = hh;
+      PSL_STAMP(10 + 3 * i + 1);
       lds_barrier();
-      if (i < 4 || wave == 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) hp[q] = *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4);
-      }
-    }
+      PSL_STAMP(10 + 3 * i + 2);
+    };
+    layer(std::integral_constant<int, 0>{});
+    layer(std::integral_constant<int, 1>{});
+    layer(std::integral_constant<int, 2>{});
+    layer(std::integral_constant<int, 3>{});
+    layer(std::integral_constant<int, 4>{});
     // ---- output_linear 128 -> 3 (one padded tile, wave 0) and the colour head (decoder.py:430-448)
     if (wave == 0) {
+      const float* buf = sH;     // layer 4 wrote buffer 0
       f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
       constexpr int fo = ffirst(FL_COUT);
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) { mma4(oa, ldfrag(WF, fo + q, lane), hp[q]); mma4(ob, ldfrag(WF, fo + q + 1, lane), hp[q + 1]); }
-      if (g == 0 && live(rl)) {
+      for (int q = 0; q < 8; q += 2) {
+        mma4(oa, ldfrag(WF, fo + q, lane), *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4));
+        mma4(ob, ldfrag(WF, fo + q + 1, lane), *reinterpret_cast<const f32x4*>(buf + (q + 1) * FRAG + lane * 4));
+      }
+      if (g == 0 && p0 + rl < a.P) {
         const int p = p0 + rl;
         float r0 = (oa[0] + ob[0]) + M[MO(PI_C_OUT + 1) + 0];
         float r1 = (oa[1] + ob[1]) + M[MO(PI_C_OUT + 1) + 1];
@@ -365,6 +495,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
         a.ws.raw[(size_t)p * 4 + 0] = r0; a.ws.raw[(size_t)p * 4 + 1] = r1; a.ws.raw[(size_t)p * 4 + 2] = r2;
       }
+      PSL_STAMP(26);
     }
   }
 }
@@ -372,7 +503,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 // grid: [0, color_tiles) colour role (one tile per workgroup), then geometry role (8 tiles per workgroup).
 // COLOR = false is the stage-'geometry' launch (geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
-__global__ __launch_bounds__(WG, 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+__global__ __launch_bounds__(WG, 4) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x < color_tiles) {
     color_tile(a, WF, smem, blockIdx.x * TILE);
@@ -450,8 +581,17 @@ int repack_frags(psl_ctx* ctx, const float* master, hipStream_t s) {
   return PSL_OK;
 }
 
-int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s) {
-  if (a.P <= 0) return PSL_OK;
+int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
+  if (a_in.P <= 0) return PSL_OK;
+  static unsigned long long* dbg = nullptr;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  DecodeArgs a = a_in;
+  if (dbg_on) {
+    if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long)));
+    PSL_HIP(hipMemsetAsync(dbg, 0, 64 * sizeof(unsigned long long), s));
+    a.dbg = dbg;
+  }
   const size_t lds = sizeof(float) * Fwd2Lds::total;
   const int tiles = (a.P + TILE - 1) / TILE;
   const int geo_wgs = (tiles + 7) / 8;
@@ -460,6 +600,24 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s) {
   else
     hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(geo_wgs), dim3(WG), 0, s, a, (const float*)ctx->wf, 0);
   PSL_LAUNCH_CHECK();
+  if (dbg_on) {
+    unsigned long long h[64];
+    PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    if (a.flags & PSL_STAGE_COLOR) {
+      fprintf(stderr, "[psl fwd2 colour P=%d] phase0 %llu | F: gather+sincos %llu lin1 %llu softplus %llu lin2 %llu reduce %llu barrier %llu |",
+              a.P, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6]);
+      unsigned long long prev = h[7];
+      for (int i = 0; i < 5; ++i) {
+        fprintf(stderr, " L%d: mfma %llu epi %llu bar %llu |", i, h[10 + 3 * i] - prev, h[11 + 3 * i] - h[10 + 3 * i], h[12 + 3 * i] - h[11 + 3 * i]);
+        prev = h[12 + 3 * i];
+      }
+      fprintf(stderr, " out %llu | total %llu\n", h[26] - prev, h[26] - h[0]);
+    } else {
+      fprintf(stderr, "[psl fwd2 geo P=%d] nbr+weights %llu gather %llu sin %llu | L0 %llu L1 %llu L2 %llu L3 %llu L4 %llu | total %llu\n", a.P,
+              h[33] - h[32], h[34] - h[33], h[35] - h[34], h[36] - h[35], h[37] - h[36], h[38] - h[37], h[39] - h[38], h[40] - h[39],
+              h[41] - h[32]);
+    }
+  }
   return PSL_OK;
 }
 

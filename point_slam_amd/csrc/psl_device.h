@@ -43,6 +43,17 @@ __device__ __forceinline__ float softplus100(float x) {
                                : __builtin_amdgcn_logf(1.0f + t) * 0.69314718055994531f;
   return l * 0.01f;
 }
+// The same function without control flow (selects only): inside the register-chained kernels a branch per activation
+// splits the instruction stream into small blocks and stops the scheduler from overlapping weight loads with MFMAs.
+// Bit-identical to softplus100 (same expressions; the unused one is discarded by the select).
+__device__ __forceinline__ float softplus100_nb(float x) {
+  const float bx = 100.0f * x;
+  const float t = __builtin_amdgcn_exp2f(fminf(bx, 20.0f) * 1.44269504088896341f);
+  const float ls = t * (1.0f - t * (0.5f - t * 0.33333333f));
+  const float lb = __builtin_amdgcn_logf(1.0f + t) * 0.69314718055994531f;
+  const float l = (t < 9.765625e-4f) ? ls : lb;
+  return (bx > 20.0f) ? x : l * 0.01f;
+}
 // derivative of softplus100 expressed through its OUTPUT y: sigmoid(100 z) = 1 - exp(-100 y)
 __device__ __forceinline__ float softplus100_grad_from_out(float y) {
   return (100.0f * y > 20.0f) ? 1.0f : 1.0f - __builtin_amdgcn_exp2f(-144.269504088896341f * y);
@@ -53,7 +64,13 @@ __device__ __forceinline__ float softplus100_grad_from_out(float y) {
 // kept for huge or non-finite arguments.  The decode kernels are VALU-issue bound, and they evaluate ~3000 of
 // these per 16-sample tile.
 __device__ __forceinline__ void fast_sincosf(float x, float& sn, float& cs) {
-  if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) { sincosf(x, &sn, &cs); return; }
+  // huge or non-finite arguments (never produced by the Fourier phases of a room-scale scene): one double-precision
+  // reduction by 2 pi first -- a dozen instructions instead of the library's Payne-Hanek path, which inlined at every
+  // call site made the unrolled kernels several times larger than the instruction cache; NaN / inf come out as NaN
+  if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) {
+    const double xd = (double)x;
+    x = (float)fma(-rint(xd * 0.15915494309189535), 6.283185307179586, xd);
+  }
   const float j = rintf(__fmul_rn(x, 0.636619772f));
   float r = fmaf(j, -1.57079601e+00f, x);
   r = fmaf(j, -3.13916473e-07f, r);

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float4* __restrict_
 }
 
 // g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (pts = o + d*z, Renderer.py:172-173)
-__global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp, const float* __restrict__ z_in,
+__global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp, const float4* __restrict__ dp2, const float* __restrict__ z_in,
                                                   const float* __restrict__ gt_depth, float near_s, float far_s, int n_rays, float* __restrict__ g_o,
                                                   float* __restrict__ g_d) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp,
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     float4 g = dp[r * S + s];
+    if (dp2) { const float4 g2 = dp2[r * S + s]; g.x += g2.x; g.y += g2.y; g.z += g2.z; }   // colour + geometry branch
     float z = z_in ? z_in[r * S + s] : sample_z(gt_depth[r], s, near_s, far_s);
     o0 += g.x; o1 += g.y; o2 += g.z;
     d0 += z * g.x; d1 += z * g.y; d2 += z * g.z;
@@ -263,10 +264,10 @@ int launch_composite_bwd(const float4* raw, const float* z, const float* gt_dept
   return PSL_OK;
 }
 
-int launch_ray_grad(const float4* dp, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays, float* g_o,
-                    float* g_d, hipStream_t s) {
+int launch_ray_grad(const float4* dp, const float4* dp2, const float* z, const float* gt_depth, float near_s, float far_s, int n_rays,
+                    float* g_o, float* g_d, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_ray_grad, dim3((n_rays + 255) / 256), dim3(256), 0, s, dp, z, gt_depth, near_s, far_s, n_rays,
+  hipLaunchKernelGGL(k_ray_grad, dim3((n_rays + 255) / 256), dim3(256), 0, s, dp, dp2, z, gt_depth, near_s, far_s, n_rays,
                      g_o, g_d);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
