@@ -113,7 +113,8 @@ def kernel_profile(slam):
     return {L.psl_profile_name(i).decode(): dict(ms=ms[i], launches=cnt[i], work=work[i]) for i in range(n)}
 
 
-MFMA_CLASSES = ("decode_fwd", "decode_bwd", "dw_gemm")
+MFMA_CLASSES = ("decode_fwd", "decode_bwd", "dw_gemm", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
+                "decode_bwd_track")
 
 
 def roofline_of(prof):

@@ -219,7 +219,7 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
-  { ProfScope ps(ctx, PROF_DECODE_FWD, s, fwd_flops_per_sample(d.flags) * d.P);
+  { ProfScope ps(ctx, prof_decode_slot(d.flags, false), s, fwd_flops_per_sample(d.flags) * d.P);
     rc = (ctx->decode_version >= 2) ? launch_decode_fwd2(ctx, d, s) : launch_decode_fwd(d, s); if (rc) return rc; }
   if (!ctx->fused_ray)     // psl_map_iters composites, takes the loss and back-propagates it in one kernel of its own
   { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
@@ -271,7 +271,8 @@ extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
 }
 
 static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
-                                         "adam", "misc"};
+                                         "adam", "misc", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
+                                         "decode_bwd_track"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 

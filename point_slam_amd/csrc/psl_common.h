@@ -117,8 +117,16 @@ struct GridMeta {      // lives in device memory; written by k_grid_meta
 };
 
 // --------------------------------------------------------------------- context
+// decode classes are kept apart by launch type: colour-stage mapper batch, geometry-stage mapper batch (13x fewer
+// FLOP per sample, another kernel), tracker batch (a fifth of the samples, pose gradients)
 enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BWD, PROF_DECODE_BWD, PROF_DW,
-                PROF_ADAM, PROF_MISC, PROF_N };
+                PROF_ADAM, PROF_MISC, PROF_DECODE_FWD_GEO, PROF_DECODE_BWD_GEO, PROF_DECODE_FWD_TRK, PROF_DECODE_BWD_TRK,
+                PROF_N };
+inline int prof_decode_slot(int flags, bool bwd) {
+  if (!(flags & PSL_STAGE_COLOR)) return bwd ? PROF_DECODE_BWD_GEO : PROF_DECODE_FWD_GEO;
+  if (flags & PSL_PTS_GRAD) return bwd ? PROF_DECODE_BWD_TRK : PROF_DECODE_FWD_TRK;
+  return bwd ? PROF_DECODE_BWD : PROF_DECODE_FWD;
+}
 constexpr int PROF_RING = 4096;
 
 }  // namespace psl

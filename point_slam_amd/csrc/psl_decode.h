@@ -34,7 +34,19 @@ inline double fwd_flops_per_sample(int flags) {
   if (flags & PSL_STAGE_COLOR) m += MAC_COL + MAC_INTERP + ((flags & 0x10000) ? MAC_NBR : 0.0);
   return 2.0 * m;
 }
-inline double bwd_flops_per_sample(int flags) { return fwd_flops_per_sample(flags); }   // dX chain mirrors the forward
+// dX chain: mirrors the forward for the tracker instantiation (pose gradient: every input of every layer); the mapper
+// instantiation never differentiates w.r.t. the Fourier embeddings or the rel-pos rows unless parameter gradients need
+// dB_rel, and never w.r.t. the first colour layer's input -- those products are not issued and not counted
+inline double bwd_flops_per_sample(int flags) {
+  if (flags & PSL_PTS_GRAD) return fwd_flops_per_sample(flags);
+  const bool color = flags & PSL_STAGE_COLOR, relpos = flags & 0x10000, parg = flags & PSL_PARAM_GRAD;
+  double m = (MAC_GEO - 93.0 * 32.0 * 2.0) + MAC_INTERP;            // geometry: no d/d(embedding) (layers 0 and 3)
+  if (color) {
+    m += (MAC_COL - 40.0 * 128.0 * 2.0) + MAC_INTERP;               // colour trunk without the two embedding products
+    if (relpos) m += MAC_NBR - (parg ? 0.0 : 8.0 * 20.0 * 128.0);   // F_theta; rel-pos rows only for dB_rel
+  }
+  return 2.0 * m;
+}
 inline double dw_flops_per_sample(int flags) {
   return (flags & PSL_STAGE_COLOR) ? 2.0 * (MAC_COL + ((flags & 0x10000) ? MAC_NBR : 0.0)) : 0.0;
 }

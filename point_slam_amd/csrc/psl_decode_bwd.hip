@@ -575,7 +575,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   DecodeArgs a2 = a;
   if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
   {
-    ProfScope ps(ctx, PROF_DECODE_BWD, s, bwd_flops_per_sample(a.flags) * a.P);
+    ProfScope ps(ctx, prof_decode_slot(a.flags, true), s, bwd_flops_per_sample(a.flags) * a.P);
     int rc;
     if (ctx->decode_bwd_version >= 2) rc = launch_decode_bwd2(ctx, a2, g, small, s);
     else rc = (a.flags & PSL_PTS_GRAD) ? launch_bwd_t<true>(a2, o, tiles, s) : launch_bwd_t<false>(a2, o, tiles, s);

@@ -557,16 +557,15 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   }
 }
 
+// grid as in the forward: [0, color_tiles) colour role, then one geometry-role WAVEFRONT per tile in a workgroup of its own
 template <bool PTSG, bool COLOR>
-__global__ __launch_bounds__(WG, PTSG ? 2 : 4) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
+__global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x < color_tiles) {
     color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE);
   } else {
-    const int tile = ((int)blockIdx.x - color_tiles) * 8 + (int)(threadIdx.x >> 6);
-    const int p0 = tile * TILE;
-    if (p0 >= a.P) return;
-    geo_tile_bwd<PTSG>(a, o, WB, p0);
+    if (threadIdx.x >= 64) return;
+    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE);
   }
 }
 
@@ -576,7 +575,6 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
   o.g_brel = small;
   o.g_affine = small + 32;
   const int tiles = (a.P + TILE - 1) / TILE;
-  const int geo_wgs = (tiles + 7) / 8;
   const bool color = a.flags & PSL_STAGE_COLOR;
   const bool ptsg = a.flags & PSL_PTS_GRAD;
   const size_t lds = sizeof(float) * Bwd2Lds::total;
@@ -588,11 +586,11 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
   }
   const float* WB = ctx->wb;
   if (color) {
-    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(tiles + geo_wgs), dim3(WG), lds, s, a, o, WB, tiles);
-    else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(tiles + geo_wgs), dim3(WG), lds, s, a, o, WB, tiles);
+    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
+    else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
   } else {
-    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(geo_wgs), dim3(WG), 0, s, a, o, WB, 0);
-    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(geo_wgs), dim3(WG), 0, s, a, o, WB, 0);
+    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
+    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
   }
   PSL_LAUNCH_CHECK();
   return PSL_OK;

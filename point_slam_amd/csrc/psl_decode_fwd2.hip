@@ -39,8 +39,16 @@ __device__ __forceinline__ void mma4(f32x4& acc, const f32x4& a, const f32x4& b)
 // nothing is scheduled across this point: pins the hand-written order "request the fragments of step s + D, then issue
 // the MFMAs of step s" (left alone, the scheduler hoists every data-independent weight load to the top and spills)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-__device__ __forceinline__ float group8_sum(float v) {   // sum over the 8 lanes that share (lane & 15) >> 3 and lane >> 4
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+// sum over the 8 consecutive lanes that hold the 8 neighbours of one sample, as three DPP moves (full-rate VALU; the
+// __shfl_xor form goes through ds_bpermute: ~100 cycles of LDS latency per step, 24 steps per wave here)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_mov<0x141>(v);    // row_half_mirror: lane i <-> 7 - i inside each group of 8 (both quads hold their own sum)
   return v;
 }
 
@@ -78,9 +86,11 @@ constexpr GSteps make_geo_steps() {
   return g;
 }
 constexpr GSteps kGeo = make_geo_steps();
-constexpr int GEO_AHEAD = 2;
 
 // One wavefront, 16 samples: lane (rl = sample, g).  Writes raw[p].w (and xyz = 0 when `full_raw`), g_y, w (when asked).
+// GEO_AHEAD: prefetch distance in steps (4 in the stage-'geometry' kernel, which may use 256 registers; 2 inside the
+// colour-stage kernel, whose 128-register budget is set by the colour role).
+template <int GEO_AHEAD>
 __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __restrict__ WF, int p0, bool full_raw, bool save_w) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
@@ -306,10 +316,19 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 16 + 4 * g) = xf[1];
       }
       PSL_STAMP(2);
-      // linear1 52 -> 128 in two halves of four output tiles; the fragments of step + 1 are in flight during step
+      // linear1 52 -> 128 in two halves of four output tiles; the fragments of step + 1 are in flight during step.
+      // The softplus of a finished tile (~70 VALU instructions) is written next to the 16 MFMAs of a later step: a
+      // wavefront issues about five VALU instructions in the shadow of every MFMA, so the activation costs no time.
       f32x4 hid[8];
 #pragma unroll
       for (int nt = 0; nt < 8; ++nt) hid[nt] = ldbias(WF, fbias(FL_N1), nt, g);
+      auto activate = [&](int nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100_nb(hid[nt][r]);
+        if (a.ws.n_h1) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
+      };
+      constexpr int f2 = ffirst(FL_N2);
+      f32x4 a0n, a1n;
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         sched_fence();
@@ -321,6 +340,8 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
           const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
 #pragma unroll
           for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + (4 * h2 + j) * 4 + q2, lane);
+        } else {
+          a0n = ldfrag(WF, f2 + 0, lane); a1n = ldfrag(WF, f2 + 8 + 0, lane);     // linear2's first pair
         }
         if (q < 3) {
           const f32x4 b = (q == 0) ? xf[0] : (q == 1 ? xf[1] : xe);
@@ -332,19 +353,11 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 #pragma unroll
           for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][0], xe4, hid[4 * half + j]);
         }
+        if (half == 1) activate(q);            // tile q of the first half: complete since step 3
       }
       PSL_STAMP(3);
-      // linear2's fragments: two per hidden group, the next pair in flight
-      constexpr int f2 = ffirst(FL_N2);
-      f32x4 a0n = ldfrag(WF, f2 + 0, lane), a1n = ldfrag(WF, f2 + 8 + 0, lane);
-#pragma unroll
-      for (int nt = 0; nt < 8; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100_nb(hid[nt][r]);
-        if (a.ws.n_h1) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
-      }
       PSL_STAMP(4);
-      // linear2 128 -> 32
+      // linear2 128 -> 32; two fragments per hidden group, the next pair in flight
       f32x4 nf[2];
       nf[0] = ldbias(WF, fbias(FL_N2), 0, g); nf[1] = ldbias(WF, fbias(FL_N2), 1, g);
 #pragma unroll
@@ -352,6 +365,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         sched_fence();
         const f32x4 a0 = a0n, a1 = a1n;
         if (q < 7) { a0n = ldfrag(WF, f2 + q + 1, lane); a1n = ldfrag(WF, f2 + 8 + q + 1, lane); }
+        if (q < 4) activate(4 + q);            // second half: needed from q = 4 on
 #pragma unroll
         for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[q][r], nf[0]); nf[1] = mfma16(a1[r], hid[q][r], nf[1]); }
       }
@@ -500,18 +514,20 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   }
 }
 
-// grid: [0, color_tiles) colour role (one tile per workgroup), then geometry role (8 tiles per workgroup).
-// COLOR = false is the stage-'geometry' launch (geometry role only); two instantiations so that profiles tell them apart.
+// grid: [0, color_tiles) colour role (one tile per workgroup), then the geometry role: ONE WAVEFRONT per tile, each in a
+// workgroup of its own so that the tiles spread over all CUs (eight tiles in one workgroup would sit on one CU and share
+// its L1 port and its four SIMDs).  In the colour-stage launch the workgroup size is the colour role's 512: the seven
+// idle wavefronts of a geometry workgroup exit at once.  COLOR = false is the stage-'geometry' launch (64-thread
+// workgroups, geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
-__global__ __launch_bounds__(WG, 4) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x < color_tiles) {
     color_tile(a, WF, smem, blockIdx.x * TILE);
   } else {
-    const int tile = ((int)blockIdx.x - color_tiles) * 8 + (int)(threadIdx.x >> 6);
-    const int p0 = tile * TILE;
-    if (p0 >= a.P) return;
-    geo_tile(a, WF, p0, !COLOR, !COLOR);
+    if (threadIdx.x >= 64) return;
+    const int p0 = ((int)blockIdx.x - color_tiles) * TILE;
+    geo_tile<COLOR ? 2 : 4>(a, WF, p0, !COLOR, !COLOR);
   }
 }
 
@@ -594,11 +610,10 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
   }
   const size_t lds = sizeof(float) * Fwd2Lds::total;
   const int tiles = (a.P + TILE - 1) / TILE;
-  const int geo_wgs = (tiles + 7) / 8;
   if (a.flags & PSL_STAGE_COLOR)
-    hipLaunchKernelGGL(k_decode_fwd2<true>, dim3(tiles + geo_wgs), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
+    hipLaunchKernelGGL(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
   else
-    hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(geo_wgs), dim3(WG), 0, s, a, (const float*)ctx->wf, 0);
+    hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
   PSL_LAUNCH_CHECK();
   if (dbg_on) {
     unsigned long long h[64];
