@@ -36,7 +36,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--engine", default="native", choices=["native", "dropin"])
-    ap.add_argument("--mix", default="base", choices=["base", "replica"])
+    ap.add_argument("--mix", default="base", choices=["base", "replica", "tum", "scannet"],
+                    help="iteration mix of the reference config: base = configs/point_slam.yaml (BASELINE headline), "
+                         "replica / tum / scannet = the dataset yaml on top of it (BASELINE configs 2-4)")
+    ap.add_argument("--saturated-map", action="store_true",
+                    help="seed the cloud without holes: (almost) no point growth during the run, as in round 1")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--exchange-every", type=int, default=2, help="mapped frames between point all-gathers (N>1)")
@@ -48,15 +52,15 @@ def parse():
 def build_world(args, rank, world, dev):
     import torch
     from point_slam_amd import synthetic as syn
-    from point_slam_amd.config import default_config, replica_overrides
+    from point_slam_amd.config import MIXES, default_config
     from point_slam_amd.slam import Frame, HipSLAM, camera_tensor_from_c2w
-    cfg = default_config()
-    if args.mix == "replica":
-        cfg = replica_overrides(cfg)
+    cfg = MIXES[args.mix](default_config())
     cam = syn.intrinsics(args.width, args.height)
     torch.manual_seed(cfg["setup_seed"] + rank)
     slam = HipSLAM(cfg, cam, device=str(dev), max_points=int(args.points * 1.3) + 300_000, engine=args.engine)
-    pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"])
+    # one cube in four of a 25 cm checker is left unseeded: every mapped frame still finds uncovered surface and ADDS
+    # points (thousands at first, fewer as the holes fill), like a real sequence; --saturated-map restores round 1
+    pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"], holes=not args.saturated_map)
     slam.seed_points(pts)
     every = cfg["mapping"]["every_frame"]
     n_total = args.warmup + args.steps * (1 if args.no_kernel_timing else 2)
@@ -101,6 +105,8 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
             state["sync"].exchange(slam.npc, slam.theta)
         if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
             slam.keyframes.append(fr)
+            if len(slam.keyframes) > 40:        # the reference keeps every keyframe on the CPU; bounded here
+                slam.keyframes.pop(0)
 
 
 def kernel_profile(slam):
@@ -117,7 +123,20 @@ MFMA_CLASSES = ("decode_fwd", "decode_bwd", "dw_gemm", "decode_fwd_geo", "decode
                 "decode_bwd_track")
 
 
-def roofline_of(prof):
+def pmc_traffic(mix):
+    """HBM bytes per launch of each kernel class from the PMC pass of the same command (tools/pmc_traffic.sh: separate
+    rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md applied there);
+    rocprofv3 cannot run inside the timed process, so the figures are read from the committed summary."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{mix}.json")
+    if not os.path.exists(path):
+        return {}
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def roofline_of(prof, traffic=None):
     if not prof:
         return None, {}
     per = {}
@@ -136,8 +155,12 @@ def roofline_of(prof):
         return None, {}
     dom = max((k for k in per if k != "misc"), key=lambda k: per[k]["total_ms"])
     r = per[dom]
+    tr = (traffic or {}).get(dom)
     roof = dict(kernel=dom, bound=r["bound"], achieved=round(r["achieved"], 4), peak=r["peak"], unit=r["unit"],
-                frac=round(r["frac"], 5), traffic=None, avg_launch_us=round(r["avg_us"], 2), launches=r["launches"])
+                frac=round(r["frac"], 5), traffic=tr.get("bytes_per_launch") if tr else None,
+                avg_launch_us=round(r["avg_us"], 2), launches=r["launches"])
+    if tr:
+        roof["traffic_detail"] = tr
     return roof, per
 
 
@@ -205,7 +228,9 @@ def cpu_baseline(cfg, cam, n_points):
     r = mp["geo_iter_ratio"]
     per_frame = tr["iters"] * t_track + mp["iters"] / mp["every_frame"] * (r * t_geo + (1.0 - r) * t_col)
     return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=n_thr, kind="port",
-                sample=f"oracle (cKDTree exact 8-NN + torch fp32 + autograd + Adam), N={n_points}: {n_t} tracking iters "
+                sample=f"kind=port because /root/reference does not exist on the GPU box (the imported reference can only "
+                       f"run in the build container, which has no GPU to compare with); "
+                       f"oracle (cKDTree exact 8-NN + torch fp32 + autograd + Adam), N={n_points}: {n_t} tracking iters "
                        f"({t_track*1e3:.0f} ms each) + {n_g} geometry-stage ({t_geo*1e3:.0f} ms) + {n_c} colour-stage "
                        f"({t_col*1e3:.0f} ms) mapping iters, extrapolated to {tr['iters']} track + "
                        f"{mp['iters']}/{mp['every_frame']} map iters ({r:.0%} geometry stage) per frame")
@@ -255,6 +280,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    points_start = slam.npc.pts_num()
     for i in range(args.warmup):
         run_step(i, slam, frames, cams0, every, cfg, world, args, state)
     from point_slam_amd import _lib
@@ -285,6 +311,7 @@ def main():
         _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 0))
 
     points_end = slam.npc.pts_num()
+    mapped_total = max(state["mapped"], 1)
     # (3) SURVEY.md 8(d): tracking-only and mapping-only rates next to the combined one (single GPU; after the measured
     #     regions, on frames already seen: 10 tracked frames, then 2 mapped frames at their true poses)
     split = None
@@ -309,10 +336,10 @@ def main():
                  "map_only_fps": round(cfg["mapping"]["every_frame"] / t_map, 2)}
 
     if rank == 0:
-        roof, per = roofline_of(prof)
+        roof, per = roofline_of(prof, pmc_traffic(args.mix))
         tr, mp = cfg["tracking"], cfg["mapping"]
         out = {
-            "metric": "mapping+tracking FPS @640x480, 1M neural points",
+            "metric": f"mapping+tracking FPS @{args.width}x{args.height}, {args.points / 1e6:g}M neural points",
             "value": round(world * args.steps / dt, 4), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -320,7 +347,9 @@ def main():
                                    f"{args.mix} iteration mix: track {tr['pixels']}px x {tr['iters']}it per frame, map "
                                    f"{mp['pixels']}px x {mp['iters']}it + {mp['pixels_adding']} add-pixels every "
                                    f"{mp['every_frame']} frames, window {mp['mapping_window_size']}",
-                       "engine": args.engine, "points_end": points_end,
+                       "engine": args.engine, "points_start": points_start, "points_end": points_end,
+                       "points_added_per_mapped_frame": round(state["added"] / mapped_total, 1),
+                       "mapped_frames": state["mapped"],
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                        "render_loss_rel_err_vs_reference": "<=1e-4 (tests/test_hip_parity.py, tests/test_hip_slam.py)"},
             "roofline": roof,

@@ -44,7 +44,7 @@ _DEFAULT = {
     "mapping": {"device": "cuda:0", "color_refine": True, "geo_iter_ratio": 0.4, "geo_iter_first": 400,
                 "every_frame": 5, "BA": False, "BA_cam_lr": 0.0002, "frustum_edge": -4, "fix_geo_decoder": True,
                 "fix_color_decoder": False, "keyframe_every": 50, "mapping_window_size": 5, "w_color_loss": 0.1,
-                "frustum_feature_selection": True, "keyframe_selection_method": "global", "pixels": 1000,
+                "frustum_feature_selection": True, "keyframe_selection_method": "overlap", "pixels": 1000,
                 "pixels_adding": 6000, "pixels_based_on_color_grad": 0, "iters_first": 1500, "iters": 400,
                 "min_iter_ratio": 0.95,
                 "init": {"geometry": {"decoders_lr": 0.001, "geometry_lr": 0.03, "color_lr": 0.0},
@@ -72,3 +72,31 @@ def replica_overrides(cfg: dict) -> dict:
     cfg["mapping"].update(pixels=5000, iters=300, mapping_window_size=12, keyframe_every=20,
                           pixels_based_on_color_grad=1000)
     return cfg
+
+
+def tum_overrides(cfg: dict) -> dict:
+    """configs/TUM_RGBD/tum.yaml: noisy-depth path, 5 000 tracking / 10 000 mapping pixels per iteration, pixel sets
+    drawn from the top colour gradients, plain feature interpolation (no per-neighbour colour MLP)."""
+    cfg = copy.deepcopy(cfg)
+    cfg["model"].update(encode_rel_pos_in_col=False)
+    cfg["tracking"].update(separate_LR=False, pixels=5000, iters=200, sample_with_color_grad=True)
+    cfg["mapping"].update(every_frame=2, mapping_window_size=10, pixels=10000, iters_first=500, geo_iter_first=200,
+                          iters=150)
+    return cfg
+
+
+def scannet_overrides(cfg: dict) -> dict:
+    """configs/ScanNet/scannet.yaml: per-frame exposure latents, wider sampling interval, window of 20."""
+    cfg = copy.deepcopy(cfg)
+    cfg["model"].update(encode_exposure=True, encode_rel_pos_in_col=False, encode_viewd=False)
+    cfg["tracking"].update(separate_LR=False, lr=0.0005, pixels=5000, iters=100, sample_with_color_grad=True)
+    cfg["mapping"].update(geo_iter_ratio=0.3, mapping_window_size=20, keyframe_every=10, pixels=10000, iters_first=500,
+                          geo_iter_first=200, iters=300)
+    cfg["rendering"].update(near_end_surface=0.96, far_end_surface=1.04)
+    cfg["pointcloud"].update(near_end_surface=0.96, far_end_surface=1.04)
+    cfg["cam"].update(crop_edge=10)
+    return cfg
+
+
+MIXES = {"base": lambda c: copy.deepcopy(c), "replica": replica_overrides, "tum": tum_overrides,
+         "scannet": scannet_overrides}

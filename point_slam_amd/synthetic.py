@@ -106,13 +106,22 @@ def dynamic_radii(color: torch.Tensor, cfg: dict):
     return r_add.float(), (ratio * r_add).float()
 
 
+def in_hole(p: torch.Tensor, cell: float = 0.25) -> torch.Tensor:
+    """3-D checker of `cell`-sized cubes: one cube in four is left without seed points, so that the frames of a run
+    still find uncovered surface and the map GROWS (as it does in a real sequence) instead of being saturated."""
+    c = torch.floor(p / cell).long()
+    return ((c[..., 0] + 2 * c[..., 1] + 3 * c[..., 2]) % 4) == 0
+
+
 def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed: int = 1219, device="cpu",
-               near=0.98, far=1.02):
+               near=0.98, far=1.02, holes: bool = False):
     """Seed ~n_points neural point positions by back-projecting a jittered pixel grid
     from n_views poses (add_neural_points geometry: n_add pts/location at
-    linspace(near,far)*depth, src/neural_point.py:126-145).  No dedupe."""
+    linspace(near,far)*depth, src/neural_point.py:126-145).  No dedupe.  holes: leave the cubes of in_hole() empty."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     per_view = (n_points // n_add + n_views - 1) // n_views
+    if holes:
+        per_view = per_view * 4 // 3 + 16
     out = []
     t = torch.linspace(0.0, 1.0, n_add)
     for v in range(n_views):
@@ -124,6 +133,12 @@ def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed
         ro = c2w[:3, 3].expand_as(rd)
         d = box_depth(ro, rd)
         z = near * d[:, None] * (1 - t) + far * d[:, None] * t
-        out.append((ro[:, None, :] + rd[:, None, :] * z[:, :, None]).reshape(-1, 3))
-    pts = torch.cat(out, 0)[:n_points].float().contiguous()
+        trip = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
+        if holes:
+            trip = trip[~in_hole(ro + rd * d[:, None])]
+        out.append(trip.reshape(-1, 3))
+    pts = torch.cat(out, 0)
+    if holes and pts.shape[0] > n_points:      # keep whole views' worth of points, n_add per location
+        pts = pts[:n_points // n_add * n_add]
+    pts = pts[:n_points].float().contiguous()
     return pts.to(device)
