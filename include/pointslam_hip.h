@@ -330,6 +330,10 @@ int psl_sync(psl_ctx* ctx, void* stream);
  * enable, run, then read per class: total ms, launch count, algorithmic work (FLOP for the MFMA-bound
  * classes decode_fwd/decode_bwd/dw_gemm, bytes for the HBM-bound ones). psl_profile_read synchronises. */
 int psl_profile_enable(psl_ctx* ctx, int on);
+/* candidates (16-byte sorted-position records) the ray k-NN examined since the previous call: the k-NN's roofline is
+ * 16 B x candidates / kernel time against the L2 bandwidth (its traffic is index-dependent).
+ * Synchronises the device and resets the counter. */
+int64_t psl_knn_candidates(psl_ctx* ctx);
 int psl_profile_classes(void);
 const char* psl_profile_name(int i);
 int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, double* work_out, int cap);

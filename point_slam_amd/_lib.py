@@ -133,6 +133,7 @@ _SIGS = {
                                           C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "psl_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "psl_knn_candidates": (C.c_int64, [C.c_void_p]),
     "psl_profile_classes": (C.c_int, []),
     "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "psl_profile_name": (C.c_char_p, [C.c_int]),

@@ -178,6 +178,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   { const char* e = getenv("PSL_DECODE_BWD"); c->decode_bwd_version = (e && e[0] == '1') ? 1 : 2; }
   { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
+  PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
@@ -192,7 +193,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
   (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
-  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
+  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
@@ -275,6 +276,16 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
                                          "decode_bwd_track"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
+
+// candidates (16-byte position records) the ray k-NN has examined since the previous call; synchronises and resets
+extern "C" int64_t psl_knn_candidates(psl_ctx* ctx) {
+  if (!ctx) return PSL_ERR_ARG;
+  unsigned long long v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return PSL_ERR_HIP;
+  if (hipMemcpy(&v, ctx->knn_cand, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return PSL_ERR_HIP;
+  if (hipMemset(ctx->knn_cand, 0, sizeof(v)) != hipSuccess) return PSL_ERR_HIP;
+  return (int64_t)v;
+}
 
 extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
   if (!ctx) return PSL_ERR_ARG;

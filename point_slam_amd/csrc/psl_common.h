@@ -160,6 +160,7 @@ struct psl_ctx {
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
   // small device scratch
+  unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read
   int* d_counter;
   int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
   int* pre_cnt = nullptr;

@@ -13,6 +13,7 @@
 //   * only candidates with d2 <= r2 are ever admitted: slots beyond the query radius are
 //     reported as (inf, -1) -- they carry weight 0 everywhere in the reference
 //     (decoder.py:157,367; neural_point.py:210-213).
+#include <cstdlib>
 #include "psl_common.h"
 #include "psl_device.h"
 
@@ -324,6 +325,167 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   if (lane == 0) cnt_out[p] = cnt;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ray mode, one wavefront per RAY.  The five samples of a ray lie within +-2 % (4 %) of the sensor depth of each
+// other -- a few centimetres -- while the query radius is 4..16 cm, so their search cubes overlap almost entirely:
+// the cells are read ONCE and every candidate is tested against all five samples.
+//  * the rows of the (union) cell box are walked four at a time, 16 lanes per row: rows hold ~10..40 points, a
+//    64-wide step per row would leave most lanes idle and serialise one memory latency per row;
+//  * the five sorted top-8 lists live ACROSS lanes (list s in lanes 8 s .. 8 s + 7, one 64-bit key per lane): an
+//    insertion is one DPP shift plus two 64-bit selects for all five lists at once, one candidate per list per step,
+//    instead of an 8-deep compare/select chain on wave-uniform registers per candidate;
+//  * results are the same keys (distance bits << 32 | index) as in the one-query kernel: bit-identical answers.
+__device__ __forceinline__ unsigned dpp_shr1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+}
+
+__global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                   const int* __restrict__ cell_start,
+                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                   const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                                   const float* __restrict__ r_query,
+                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
+                                                   int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                                   unsigned long long* __restrict__ cand_counter) {
+  const int ray = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (ray >= n_rays) return;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+  const GridMeta m = *meta;
+  float r, r2;
+  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  float qx[S], qy[S], qz[S];
+  float lox = 3.0e38f, loy = 3.0e38f, loz = 3.0e38f, hix = -3.0e38f, hiy = -3.0e38f, hiz = -3.0e38f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float zq = z_vals ? z_vals[ray * S + s] : sample_z(depth[ray], s, near_s, far_s);
+    sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+                 rays_d[ray * 3 + 2], zq, qx[s], qy[s], qz[s]);
+    lox = fminf(lox, qx[s]); loy = fminf(loy, qy[s]); loz = fminf(loz, qz[s]);
+    hix = fmaxf(hix, qx[s]); hiy = fmaxf(hiy, qy[s]); hiz = fmaxf(hiz, qz[s]);
+  }
+  // this lane's slot of the five lists: list = lane >> 3 (lanes >= 40 idle), entry = lane & 7
+  const int my_list = lane >> 3;
+  u64 mine = ~0ull;
+  unsigned done_mask = 0;                      // bit s: list s is final
+  unsigned long long n_cand = 0;
+  float rho = m.cell;
+  for (;;) {
+    const bool last = rho >= r;
+    const float re = last ? r : rho;
+    const float t2 = last ? r2 : __fmul_rn(rho, rho);
+    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
+    // lists that are not final start over with the new threshold
+    if (my_list < S && !((done_mask >> my_list) & 1u)) mine = sentinel;
+    u64 thr[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) thr[s] = ((done_mask >> s) & 1u) ? 0ull : sentinel;     // a final list admits nothing
+    // union of the five cubes [q_s - re, q_s + re]: a superset of every sample's own cube
+    const float rr = re * 1.0001f + 1e-6f;
+    const int bx0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx), bx1 = cell_coord(hix + rr, m.ox, m.inv_cell, m.nx);
+    const int by0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny), by1 = cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny);
+    const int bz0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz), bz1 = cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz);
+    const int ny_b = by1 - by0 + 1;
+    const int nrows = (bz1 - bz0 + 1) * ny_b;
+    // [begin, end) of the first four rows
+    auto row_range = [&](int row, int& beg, int& end) {
+      beg = 0; end = 0;
+      if (row < nrows) {
+        const int cz = bz0 + row / ny_b, cy = by0 + row % ny_b;
+        const int rowbase = (cz * m.ny + cy) * m.nx;
+        beg = cell_start[rowbase + bx0];
+        end = cell_start[rowbase + bx1 + 1];
+      }
+    };
+    int beg, end, nbeg, nend;
+    row_range(grp, beg, end);
+    for (int rb = 0; rb < nrows; rb += 4) {
+      row_range(rb + 4 + grp, nbeg, nend);      // next step's ranges are in flight while this step's rows are scanned
+      int j = beg + l16;
+      float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      while (__ballot(j < end)) {
+        const bool valid = j < end;
+        const int jn = j + 16;
+        const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row
+        n_cand += (unsigned long long)__popcll(__ballot(valid));
+        const unsigned idx = __float_as_uint(c.w);
+        u64 key[S], pend[S];
+        u64 any = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          key[s] = ((u64)__float_as_uint(dist2(c.x, c.y, c.z, qx[s], qy[s], qz[s])) << 32) | idx;
+          pend[s] = __ballot(valid && key[s] < thr[s]);
+          any |= pend[s];
+        }
+        while (any) {
+          // one candidate per list: the lowest pending lane of each list broadcasts its key to that list's lanes
+          u64 kk = ~0ull;
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            if (pend[s]) {
+              const int l = __builtin_ctzll(pend[s]);
+              const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key[s] >> 32), l);
+              const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key[s] & 0xFFFFFFFFull), l);
+              if (my_list == s) kk = ((u64)khi << 32) | klo;
+              pend[s] &= pend[s] - 1;
+            }
+          }
+          // sorted insertion across the 8 lanes of a list: b[j] <- kk < b[j-1] ? b[j-1] : (kk < b[j] ? kk : b[j])
+          const unsigned plo = dpp_shr1((unsigned)(mine & 0xFFFFFFFFull)), phi = dpp_shr1((unsigned)(mine >> 32));
+          const u64 prev = ((lane & 7) == 0) ? 0ull : (((u64)phi << 32) | plo);
+          mine = (kk < prev) ? prev : ((kk < mine) ? kk : mine);
+          // new thresholds = last entry of every list; candidates that no longer qualify are dropped
+          any = 0;
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            if (pend[s]) {
+              const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), 8 * s + 7);
+              const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), 8 * s + 7);
+              thr[s] = ((u64)thi << 32) | tlo;
+              pend[s] &= __ballot(valid && key[s] < thr[s]);
+              any |= pend[s];
+            }
+          }
+        }
+        // thresholds for the next chunk (lists that received entries above but drained their queue)
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          if (!((done_mask >> s) & 1u)) {
+            const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), 8 * s + 7);
+            const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), 8 * s + 7);
+            thr[s] = ((u64)thi << 32) | tlo;
+          }
+        }
+        j = jn; c = cn;
+      }
+      beg = nbeg; end = nend;
+    }
+    // a list is final when 8 entries were found inside rho (every unscanned point is farther), or after the r pass
+    unsigned all_done = 1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      if (!((done_mask >> s) & 1u)) {
+        const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), 8 * s + 7);
+        const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xFFFFFFFFull), 8 * s + 7);
+        if (last || (((u64)thi << 32) | tlo) != sentinel) done_mask |= 1u << s;
+        else all_done = 0;
+      }
+    }
+    if (all_done) break;
+    rho *= 2.0f;
+  }
+  // emit: lane 8 s + j holds entry j of sample s; count = #(index valid && d2 < r2)  (neural_point.py:207-213)
+  if (lane < S * K) {
+    const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull);
+    I_out[(size_t)ray * S * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
+  }
+  {
+    const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
+    const u64 inr = __ballot(lane < S * K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2));
+    if (lane < S) cnt_out[ray * S + lane] = __popcll((inr >> (8 * lane)) & 0xFFull);
+  }
+  if (cand_counter && lane == 0) atomicAdd(cand_counter, n_cand);
+}
+
 // sample_near_pcl marching test (src/neural_point.py:232-249): one wave per (ray, step); a step "hits" when at least
 // one neural point lies strictly inside the query radius (nearest of the 8-NN has D < r^2).  First hit ends the scan.
 __global__ __launch_bounds__(256) void k_near_pcl_hits(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
@@ -398,6 +560,15 @@ static inline float r2_of(float r) { return (float)((double)r * (double)r); }   
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
+  static int version = -1;     // PSL_KNN=1: the one-wavefront-per-sample kernel of round 1 (A/B comparisons)
+  if (version < 0) { const char* e = getenv("PSL_KNN"); version = (e && e[0] == '1') ? 1 : 2; }
+  if (version >= 2) {
+    hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand);
+    PSL_LAUNCH_CHECK();
+    return PSL_OK;
+  }
   int blocks = (n_rays * S + 3) / 4;
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -136,3 +136,43 @@ def test_add_points_is_idempotent(world):
     report(test="fullsize_add", added_first=a1, added_second=a2, points=n1)
     assert a1 > 500 and n1 == n0 + 3 * a1 and a2 == 0 and s.npc.pts_num() == n1
     assert s.npc.get_geo_feats().shape[0] == n1
+
+
+@pytest.mark.parametrize("n_rays,seed", [(1500, 4), (37, 5)])
+def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
+    """The ray-mode k-NN inside psl_render_fwd (one wavefront per ray, five samples share the candidate scan): neighbour
+    lists and counts read back from the render workspace == exact 8-NN of the oracle, bit for bit."""
+    import ctypes as C
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import _lib
+    w = world
+    s, dev = w["slam"], w["dev"]
+    ro, rd, gd, gc, rq = _rays(w, n_rays, seed)
+    L = _lib.lib()
+    R = n_rays
+    ws = torch.zeros(int(L.psl_render_ws_floats(R, 0)), device=dev)
+    depth = torch.empty(R, device=dev); var = torch.empty(R, device=dev); rgb = torch.empty(R, 3, device=dev)
+    valid = torch.empty(R, device=dev, dtype=torch.uint8)
+    fb = torch.zeros(2, 32, device=dev)
+    a = _lib.psl_render_args(n_rays=R, flags=0, sigmoid_coef=0.1, rays_o=ro.data_ptr(), rays_d=rd.data_ptr(),
+                             gt_depth=gd.data_ptr(), r_query=rq.data_ptr(), geo_feats=s.npc.geo_feats.data_ptr(),
+                             col_feats=s.npc.col_feats.data_ptr(), params=s.theta.data_ptr(),
+                             col_embed_B=s.Bcol.data_ptr(), fallback_geo=fb[0].data_ptr(), fallback_col=fb[1].data_ptr(),
+                             exposure_affine=None, ws=ws.data_ptr(), depth=depth.data_ptr(), var=var.data_ptr(),
+                             rgb=rgb.data_ptr(), valid_ray=valid.data_ptr())
+    _lib.check(L.psl_render_fwd(s.npc.handle, C.byref(a), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    P = 5 * R
+    Ppad = (P + 15) // 16 * 16
+    I = ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long()
+    cnt = ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu()
+    z = O.z_samples(gd.cpu(), 0.98, 1.02, 5)
+    q = O.sample_points(ro.cpu(), rd.cpu(), z)
+    r = rq.cpu().repeat_interleave(5)
+    Do, Io = O.knn_exact(w["pts"], q, 8)
+    inr = Do <= (r * r)[:, None]
+    Io_m = torch.where(inr, Io, torch.full_like(Io, -1))
+    bad = int((I != Io_m).any(1).sum())
+    report(test="fullsize_ray_knn", rays=R, mismatched_samples=bad, mean_cnt=float(cnt.float().mean()))
+    assert bad == 0
+    assert torch.equal(cnt, O.neighbor_count(Do, r))

@@ -98,6 +98,52 @@ def test_knn_fixed_radius_and_add_step(dev):
         assert torch.equal(cnt.cpu(), O.neighbor_count(Do, rad))
 
 
+def test_ray_knn_sparse_cloud_matches_oracle(dev):
+    """Ray-mode k-NN on a SPARSE cloud (the expanding search needs several passes; many samples have fewer than 8 or no
+    neighbours inside the radius) through the render workspace; fixed query radius."""
+    import ctypes as C
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import _lib, params as P_
+    g = torch.Generator().manual_seed(17)
+    n_pts, R = 1500, 333
+    cloud = torch.rand(n_pts, 3, generator=g) * torch.tensor([2.0, 2.0, 0.4]) + torch.tensor([0.0, 0.0, 1.8])
+    cfg = cfg_variant("tum")
+    npc = make_npc(cfg, cloud, torch.zeros(n_pts, 32), torch.zeros(n_pts, 32), dev, max_points=n_pts + 8)
+    dec = make_decoders(cfg, "tum", dev)
+    theta = P_.pack_master(dec).detach().contiguous()
+    Bcol = P_.color_embed_B(dec).to(dev).float().contiguous()
+    ro = torch.zeros(R, 3) + torch.tensor([1.0, 1.0, 0.0])
+    rd = torch.cat([(torch.rand(R, 2, generator=g) - 0.5) * 0.9, torch.ones(R, 1)], 1)
+    gd = 1.8 + 0.4 * torch.rand(R, generator=g)
+    L = _lib.lib()
+    ro_d, rd_d, gd_d = ro.to(dev).contiguous(), rd.to(dev).contiguous(), gd.to(dev).contiguous()
+    ws = torch.zeros(int(L.psl_render_ws_floats(R, 0)), device=dev)
+    depth = torch.empty(R, device=dev); var = torch.empty(R, device=dev); rgb = torch.empty(R, 3, device=dev)
+    valid = torch.empty(R, device=dev, dtype=torch.uint8)
+    fb = torch.zeros(2, 32, device=dev)
+    feats = torch.zeros(n_pts, 32, device=dev)
+    a = _lib.psl_render_args(n_rays=R, flags=0, sigmoid_coef=0.1, rays_o=ro_d.data_ptr(), rays_d=rd_d.data_ptr(),
+                             gt_depth=gd_d.data_ptr(), r_query=None, geo_feats=feats.data_ptr(), col_feats=feats.data_ptr(),
+                             params=theta.data_ptr(), col_embed_B=Bcol.data_ptr(), fallback_geo=fb[0].data_ptr(),
+                             fallback_col=fb[1].data_ptr(), exposure_affine=None, ws=ws.data_ptr(), depth=depth.data_ptr(),
+                             var=var.data_ptr(), rgb=rgb.data_ptr(), valid_ray=valid.data_ptr())
+    _lib.check(L.psl_render_fwd(npc.handle, C.byref(a), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    P = 5 * R
+    Ppad = (P + 15) // 16 * 16
+    I = ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long()
+    cnt = ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu()
+    q = O.sample_points(ro, rd, O.z_samples(gd, 0.98, 1.02, 5))
+    rq = cfg["pointcloud"]["radius_query"]
+    Do, Io = O.knn_exact(cloud, q, 8)
+    Io_m = torch.where(Do <= rq * rq, Io, torch.full_like(Io, -1))
+    cnt_o = O.neighbor_count(Do, rq)
+    report(test="ray_knn_sparse", empty_frac=float((cnt_o == 0).float().mean()), full_frac=float((cnt_o == 8).float().mean()),
+           mismatched=int((I != Io_m).any(1).sum()))
+    assert 0.02 < float((cnt_o == 0).float().mean()) and float((cnt_o == 8).float().mean()) < 0.9
+    assert torch.equal(I, Io_m) and torch.equal(cnt, cnt_o)
+
+
 # ------------------------------------------------------------------------------ compositing
 def test_composite_matches_oracle(dev):
     import ctypes as C
