@@ -334,6 +334,8 @@ int psl_profile_enable(psl_ctx* ctx, int on);
  * 16 B x candidates / kernel time against the L2 bandwidth (its traffic is index-dependent).
  * Synchronises the device and resets the counter. */
 int64_t psl_knn_candidates(psl_ctx* ctx);
+/* run-time A/B switches for tests and profiling ("knn": 1 = one wavefront per sample, 2 = one per ray) */
+int psl_debug_option(const char* name, int value);
 int psl_profile_classes(void);
 const char* psl_profile_name(int i);
 int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, double* work_out, int cap);

@@ -134,6 +134,7 @@ _SIGS = {
     "psl_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_knn_candidates": (C.c_int64, [C.c_void_p]),
+    "psl_debug_option": (C.c_int, [C.c_char_p, C.c_int]),
     "psl_profile_classes": (C.c_int, []),
     "psl_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "psl_profile_name": (C.c_char_p, [C.c_int]),

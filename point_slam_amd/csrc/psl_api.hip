@@ -277,6 +277,15 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
+namespace psl { extern int g_knn_version; }
+// debug / A-B switch settable at run time (tests compare kernel generations inside one process)
+extern "C" int psl_debug_option(const char* name, int value) {
+  if (!name) return PSL_ERR_ARG;
+  if (!strcmp(name, "knn")) { psl::g_knn_version = value; return PSL_OK; }
+  set_error("psl_debug_option: unknown option %s", name);
+  return PSL_ERR_ARG;
+}
+
 // candidates (16-byte position records) the ray k-NN has examined since the previous call; synchronises and resets
 extern "C" int64_t psl_knn_candidates(psl_ctx* ctx) {
   if (!ctx) return PSL_ERR_ARG;

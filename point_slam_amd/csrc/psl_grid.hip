@@ -555,14 +555,14 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
 }
 
+int g_knn_version = -1;      // PSL_KNN=1 / psl_debug_option("knn", 1): the one-wavefront-per-sample kernel of round 1
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  static int version = -1;     // PSL_KNN=1: the one-wavefront-per-sample kernel of round 1 (A/B comparisons)
-  if (version < 0) { const char* e = getenv("PSL_KNN"); version = (e && e[0] == '1') ? 1 : 2; }
-  if (version >= 2) {
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] == '1') ? 1 : 2; }
+  if (g_knn_version >= 2) {
     hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand);

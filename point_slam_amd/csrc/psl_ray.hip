@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
   if (zero64 && blockIdx.x == 0 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   double lg = 0.0, lc = 0.0, lcnt = 0.0;
+  float ga[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) ga[j] = 0.f;
   if (r < n_rays) {
     float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
     float T = 1.0f, wsum = 0.f;
@@ -196,15 +199,11 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
     if (A) {
       // through the sigmoid, then out' = out @ A + t: dA[i][j] = out_i d_j, dt_j = d_j, d out_i = sum_j A[i][j] d_j
       const float q0 = gr0 * e0 * (1.f - e0), q1 = gr1 * e1 * (1.f - e1), q2 = gr2 * e2 * (1.f - e2);
-      float ga[12] = {m0 * q0, m0 * q1, m0 * q2, m1 * q0, m1 * q1, m1 * q2, m2 * q0, m2 * q1, m2 * q2, q0, q1, q2};
+      ga[0] = m0 * q0; ga[1] = m0 * q1; ga[2] = m0 * q2; ga[3] = m1 * q0; ga[4] = m1 * q1; ga[5] = m1 * q2;
+      ga[6] = m2 * q0; ga[7] = m2 * q1; ga[8] = m2 * q2; ga[9] = q0; ga[10] = q1; ga[11] = q2;
       gr0 = A[0] * q0 + A[1] * q1 + A[2] * q2;
       gr1 = A[3] * q0 + A[4] * q1 + A[5] * q2;
       gr2 = A[6] * q0 + A[7] * q1 + A[8] * q2;
-      float* dst = g_frame_affine + 12 * (r / pix_per_frame);
-      if (q0 != 0.f || q1 != 0.f || q2 != 0.f) {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) atomic_add_f32(dst + j, ga[j]);
-      }
     }
     // compositing backward (no variance cotangent in the mapper loss)
     float gw[S];
@@ -219,6 +218,23 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
       float ws = w[s] / W;
       d_raw[r * S + s] = make_float4(gr0 * ws, gr1 * ws, gr2 * ws, gocc);
       suffix += gw[s] * w[s];
+    }
+  }
+  if (frame_affine && color_stage) {
+    // d(loss)/d(affine of the ray's frame): a wavefront's 64 rays almost always belong to ONE window frame, so the twelve
+    // sums are reduced across the wave and leave as 12 atomics; a wave that straddles two frames falls back to per-lane
+    // atomics (one atomic per ray and entry would serialise thousands of updates on F x 12 addresses)
+    const int fr = min(r, n_rays - 1) / pix_per_frame;
+    const int fr0 = __builtin_amdgcn_readfirstlane(fr);
+    if (__ballot(fr != fr0) == 0ull) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const float v = wave_sum(ga[j]);
+        if ((threadIdx.x & 63) == 0 && v != 0.f) atomic_add_f32(g_frame_affine + 12 * fr0 + j, v);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) if (ga[j] != 0.f) atomic_add_f32(g_frame_affine + 12 * fr + j, ga[j]);
     }
   }
 #pragma unroll

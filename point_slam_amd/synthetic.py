@@ -109,7 +109,7 @@ def dynamic_radii(color: torch.Tensor, cfg: dict):
 def in_hole(p: torch.Tensor, cell: float = 0.25) -> torch.Tensor:
     """3-D checker of `cell`-sized cubes: one cube in four is left without seed points, so that the frames of a run
     still find uncovered surface and the map GROWS (as it does in a real sequence) instead of being saturated."""
-    c = torch.floor(p / cell).long()
+    c = torch.floor((p + 0.5 * cell) / cell).long()     # half-cell offset: the room's walls lie on multiples of the cell
     return ((c[..., 0] + 2 * c[..., 1] + 3 * c[..., 2]) % 4) == 0
 
 

@@ -160,12 +160,17 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
                              col_embed_B=s.Bcol.data_ptr(), fallback_geo=fb[0].data_ptr(), fallback_col=fb[1].data_ptr(),
                              exposure_affine=None, ws=ws.data_ptr(), depth=depth.data_ptr(), var=var.data_ptr(),
                              rgb=rgb.data_ptr(), valid_ray=valid.data_ptr())
-    _lib.check(L.psl_render_fwd(s.npc.handle, C.byref(a), _lib.stream_ptr()))
-    torch.cuda.synchronize()
     P = 5 * R
     Ppad = (P + 15) // 16 * 16
-    I = ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long()
-    cnt = ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu()
+    got = {}
+    for ver in (1, 2):          # round-1 kernel (one wavefront per sample) and the per-ray kernel
+        _lib.check(L.psl_debug_option(b"knn", ver))
+        ws.zero_()
+        _lib.check(L.psl_render_fwd(s.npc.handle, C.byref(a), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        got[ver] = (ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long().clone(),
+                    ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu().clone())
+    I, cnt = got[2]
     z = O.z_samples(gd.cpu(), 0.98, 1.02, 5)
     q = O.sample_points(ro.cpu(), rd.cpu(), z)
     r = rq.cpu().repeat_interleave(5)
@@ -173,6 +178,13 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
     inr = Do <= (r * r)[:, None]
     Io_m = torch.where(inr, Io, torch.full_like(Io, -1))
     bad = int((I != Io_m).any(1).sum())
-    report(test="fullsize_ray_knn", rays=R, mismatched_samples=bad, mean_cnt=float(cnt.float().mean()))
+    bad1 = int((got[1][0] != Io_m).any(1).sum())
+    diag = []
+    for p_ in torch.nonzero((I != Io_m).any(1)).flatten()[:4].tolist():
+        diag.append(dict(sample=p_, s=p_ % 5, r=float(r[p_]), want=Io_m[p_].tolist(), got=I[p_].tolist(),
+                         v1=got[1][0][p_].tolist(), D=[float(x) for x in Do[p_]]))
+    report(test="fullsize_ray_knn", rays=R, mismatched_samples=bad, mismatched_v1=bad1, mean_cnt=float(cnt.float().mean()),
+           diag=diag)
+    assert bad1 == 0
     assert bad == 0
     assert torch.equal(cnt, O.neighbor_count(Do, r))
