@@ -68,7 +68,8 @@ def build_world(args, rank, world, dev):
     frames, cams0 = [], []
     g = torch.Generator().manual_seed(1000 + rank)
     for i in range(-4, n_total):
-        t = float(rank + world * max(i, 0)) * 1.0 if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
+        # 2 trajectory units per frame = ~5.6 cm and ~0.4 degrees ("5 cm / 1 deg per frame"): every mapped frame sees new surface
+        t = float(rank + world * max(i, 0)) * 2.0 if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
         t = t + 200.0 if i >= 0 else t + 170.0
         c2w = syn.pose(t, dev)
         depth, color = syn.render_frame(cam, c2w)

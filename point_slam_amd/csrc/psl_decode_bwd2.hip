@@ -219,6 +219,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   const bool parg = (a.flags & PSL_PARAM_GRAD) != 0;
   const float* __restrict__ M = a.master;
 
+  PSL_STAMP(0);
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -272,6 +273,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     sDP[t - TILE * K - TILE - 32] = 0.f;
   }
   lds_barrier();
+  PSL_STAMP(1);
 
   // ---------------------------------------------------------------- colour trunk, wave w = hidden channel tile w
   {
@@ -321,7 +323,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       // step B (K-split): dL/dc partial += Wc_i^T[:, own 16 channels] G
       mma4b(dccp[0], wc[0], G);
       mma4b(dccp[1], wc[1], G);
+      PSL_STAMP(2 + 3 * (4 - i));
       lds_barrier();
+      PSL_STAMP(3 + 3 * (4 - i));
       // step C: dL/d(input of layer i) = W_i^T dz, hidden part (this wave's 16 channels), all 128 dz channels
       if (i > 0) {
         f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
@@ -340,6 +344,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
         for (int r = 0; r < 4; ++r) G[r] = ga[r] + gb[r];
       }
+      PSL_STAMP(4 + 3 * (4 - i));
       if (PTSG && (i == 3 || i == 0) && wave < 3) {   // embedding part: input tiles 8..10 of the skip layer, 0..2 of layer 0
         const int tile0 = (i == 3) ? 8 : 0;
 #pragma unroll
@@ -360,6 +365,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       for (int r = 0; r < 4; ++r) { const int e = 16 * wave + 4 * g + r; if (e < EC) sDE[rl * LD_E2 + e] = dEc[r]; }
     }
   }
+  PSL_STAMP(17);
   lds_barrier();
   {   // 512 threads, 512 elements [it][lane][r]: sum over the waves, mask samples without neighbours
     const int e = t;
@@ -371,6 +377,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   }
   lds_barrier();
 
+  PSL_STAMP(18);
   // ---------------------------------------------------------------- colour features: scatter / F_theta backward
   {
     const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane
@@ -440,6 +447,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
           for (int it = 0; it < 8; ++it) dh[it] = mfma16(wf8[it][r], dnf[q][r], dh[it]);
       }
+      PSL_STAMP(19);
       // dz1 = dH1 * softplus'(h1)
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
@@ -448,6 +456,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         for (int r = 0; r < 4; ++r) dh[it][r] = live ? dh[it][r] * softplus100_grad_from_out(h1[r]) : 0.f;
         if (parg) *reinterpret_cast<f32x4*>(a.ws.n_dz1 + grow * HC + it * 16 + 4 * g) = dh[it];
       }
+      PSL_STAMP(20);
       // dX1^T[x][row] = W1^T dz1^T (linear1.weight [128][52]): input tiles (feat 0..15, feat 16..31, rel 0..15, rel 16..19)
       f32x4 dx[4];
       constexpr int b1 = bfirst(BL_N1);
@@ -467,6 +476,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
           if (need_rel) { dx[2] = mfma16(wf4[2][r], dh[q][r], dx[2]); dx[3] = mfma16(wf4[3][r], dh[q][r], dx[3]); }
         }
       }
+      PSL_STAMP(21);
       // feature part -> scattered into the colour feature rows straight from the accumulators
       if (featg && dst >= 0) {
 #pragma unroll
@@ -510,7 +520,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       }
     }
   }
+  PSL_STAMP(22);
   lds_barrier();
+  PSL_STAMP(23);
 
   // ---------------------------------------------------------------- position gradient of the colour branch (tracker)
   if constexpr (PTSG) {
@@ -585,6 +597,9 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
     attr_set = true;
   }
   const float* WB = ctx->wb;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  if (dbg_on && a.dbg) PSL_HIP(hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), s));
   if (color) {
     if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
     else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
@@ -593,6 +608,18 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
     else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
   }
   PSL_LAUNCH_CHECK();
+  if (dbg_on && a.dbg && color) {
+    unsigned long long h[64];
+    PSL_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[psl bwd2 colour P=%d ptsg=%d] phase0 %llu |", a.P, (int)ptsg, h[1] - h[0]);
+    unsigned long long prev = h[1];
+    for (int L = 0; L < 5; ++L) {
+      fprintf(stderr, " L%d: pre %llu bar %llu mfma %llu |", 4 - L, h[2 + 3 * L] - prev, h[3 + 3 * L] - h[2 + 3 * L], h[4 + 3 * L] - h[3 + 3 * L]);
+      prev = h[4 + 3 * L];
+    }
+    fprintf(stderr, " dcc-bar %llu reduce %llu | F: dH %llu act %llu dX %llu scatter+rel %llu bar %llu | total %llu\n",
+            h[17] - prev, h[18] - h[17], h[19] - h[18], h[20] - h[19], h[21] - h[20], h[22] - h[21], h[23] - h[22], h[23] - h[0]);
+  }
   return PSL_OK;
 }
 

@@ -232,9 +232,10 @@ __device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, floa
 // fetched 64 rows at a time, one row per lane, then walked with coalesced 16 B/lane candidate loads.
 __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
                                          const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
-                                         float r2, u64 (&best)[K]) {
-  const int lane = threadIdx.x & 63;
+                                         float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   float rho = m.cell;
+  unsigned long long cand = 0;
   for (;;) {
     const bool last = rho >= r;
     const float re = last ? r : rho;
@@ -246,40 +247,50 @@ __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __rest
     box_of(m, qx, qy, qz, re, bx);
     const int ny_b = bx.hi[1] - bx.lo[1] + 1;
     const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
-    for (int rb = 0; rb < nrows; rb += 64) {
-      int beg = 0, end = 0;
-      const int row = rb + lane;
+    // The rows of the cube ((cz, cy) pairs: x-runs of cells = contiguous ranges of `spos`) hold ~10..40 points each:
+    // they are walked FOUR AT A TIME, 16 lanes per row, and the [begin, end) pairs of the next four are requested
+    // before the current four are scanned -- a quarter of the serial memory round trips of a 64-lanes-per-row walk,
+    // and no idle lanes on short rows.
+    auto row_range = [&](int row, int& beg, int& end) {
+      beg = 0; end = 0;
       if (row < nrows) {
         const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
         const int rowbase = (cz * m.ny + cy) * m.nx;
         beg = cell_start[rowbase + bx.lo[0]];
         end = cell_start[rowbase + bx.hi[0] + 1];
       }
-      const int nr = min(64, nrows - rb);
-      for (int ri = 0; ri < nr; ++ri) {
-        const int b0 = __builtin_amdgcn_readlane(beg, ri), e0 = __builtin_amdgcn_readlane(end, ri);
-        for (int j0 = b0; j0 < e0; j0 += 64) {
-          const int j = j0 + lane;
-          const bool valid = j < e0;
-          float4 c = valid ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-          const unsigned idx = __float_as_uint(c.w);
-          float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
-          u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
-          u64 mask = __ballot(valid && key < best[K - 1]);
-          while (mask) {
-            int l = __builtin_ctzll(mask);
-            unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
-            unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
-            topk_insert(best, ((u64)khi << 32) | klo);
-            mask &= mask - 1;
-            if (mask) mask &= __ballot(valid && key < best[K - 1]);
-          }
+    };
+    int beg, end, nbeg, nend;
+    row_range(grp, beg, end);
+    for (int rb = 0; rb < nrows; rb += 4) {
+      row_range(rb + 4 + grp, nbeg, nend);
+      int j = beg + l16;
+      float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      while (__ballot(j < end)) {
+        const bool valid = j < end;
+        const int jn = j + 16;
+        const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row, in flight
+        cand += (unsigned long long)__popcll(__ballot(valid));
+        const unsigned idx = __float_as_uint(c.w);
+        const float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
+        const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
+        u64 mask = __ballot(valid && key < best[K - 1]);
+        while (mask) {
+          const int l = __builtin_ctzll(mask);
+          const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
+          const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
+          topk_insert(best, ((u64)khi << 32) | klo);
+          mask &= mask - 1;
+          if (mask) mask &= __ballot(valid && key < best[K - 1]);
         }
+        j = jn; c = cn;
       }
+      beg = nbeg; end = nend;
     }
     if (last || best[K - 1] != sentinel) break;
     rho *= 2.0f;
   }
+  if (n_cand) *n_cand = cand;
 }
 
 __device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lane, unsigned& ib_out, unsigned& db_out,
@@ -305,7 +316,8 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
                                                   const float* __restrict__ depth, const float* __restrict__ z_vals,
                                                   const float* __restrict__ r_query,
                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
-                                                  int* __restrict__ I_out, int* __restrict__ cnt_out) {
+                                                  int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                                  unsigned long long* __restrict__ cand_counter) {
   const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (p >= n_rays * S) return;
   const int ray = p / S, si = p - ray * S;
@@ -318,11 +330,12 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
                rays_d[ray * 3 + 2], zq, qx, qy, qz);
   u64 best[K];
-  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best);
+  unsigned long long n_cand = 0;
+  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand);
   unsigned ib, db; int cnt;
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-  if (lane == 0) cnt_out[p] = cnt;
+  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -555,13 +568,16 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
 }
 
-int g_knn_version = -1;      // PSL_KNN=1 / psl_debug_option("knn", 1): the one-wavefront-per-sample kernel of round 1
+int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 1 = one wavefront per sample (default), 2 = one per ray
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] == '1') ? 1 : 2; }
+  // default: one wavefront per SAMPLE.  The per-ray kernel (PSL_KNN=2) is exact too but measured slower: the five
+  // samples of a ray span +-2..4 % of the depth (up to 12 cm) while the search starts at a 4 cm cube, so the union box
+  // is 3-6x one sample's cube and every candidate is tested against samples it cannot belong to
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] == '2') ? 2 : 1; }
   if (g_knn_version >= 2) {
     hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
@@ -572,7 +588,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   int blocks = (n_rays * S + 3) / 4;
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out);
+                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

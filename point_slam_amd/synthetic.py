@@ -106,11 +106,13 @@ def dynamic_radii(color: torch.Tensor, cfg: dict):
     return r_add.float(), (ratio * r_add).float()
 
 
-def in_hole(p: torch.Tensor, cell: float = 0.25) -> torch.Tensor:
-    """3-D checker of `cell`-sized cubes: one cube in four is left without seed points, so that the frames of a run
-    still find uncovered surface and the map GROWS (as it does in a real sequence) instead of being saturated."""
+def in_hole(p: torch.Tensor, cell: float = 0.5) -> torch.Tensor:
+    """3-D checkerboard of `cell`-sized cubes: every other cube is left without seed points, so that the frames of a run
+    still find uncovered surface and the map GROWS (as it does in a real sequence) instead of being saturated.  (Only
+    the inside of an empty cube is "new": a surface point closer than its add-radius, 2..8 cm, to a seeded cube is
+    rejected by the dedupe test.)"""
     c = torch.floor((p + 0.5 * cell) / cell).long()     # half-cell offset: the room's walls lie on multiples of the cell
-    return ((c[..., 0] + 2 * c[..., 1] + 3 * c[..., 2]) % 4) == 0
+    return ((c[..., 0] + c[..., 1] + c[..., 2]) % 2) == 0
 
 
 def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed: int = 1219, device="cpu",
@@ -121,7 +123,7 @@ def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed
     g = torch.Generator(device="cpu").manual_seed(seed)
     per_view = (n_points // n_add + n_views - 1) // n_views
     if holes:
-        per_view = per_view * 4 // 3 + 16
+        per_view = per_view * 2 + 16
     out = []
     t = torch.linspace(0.0, 1.0, n_add)
     for v in range(n_views):

@@ -174,7 +174,8 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
     z = O.z_samples(gd.cpu(), 0.98, 1.02, 5)
     q = O.sample_points(ro.cpu(), rd.cpu(), z)
     r = rq.cpu().repeat_interleave(5)
-    Do, Io = O.knn_exact(w["pts"], q, 8)
+    cloud = s.npc.cloud_pos()           # the module's cloud as it is NOW (an earlier test may have added points)
+    Do, Io = O.knn_exact(cloud, q, 8)
     inr = Do <= (r * r)[:, None]
     Io_m = torch.where(inr, Io, torch.full_like(Io, -1))
     bad = int((I != Io_m).any(1).sum())
@@ -185,6 +186,7 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
                          v1=got[1][0][p_].tolist(), D=[float(x) for x in Do[p_]]))
     report(test="fullsize_ray_knn", rays=R, mismatched_samples=bad, mismatched_v1=bad1, mean_cnt=float(cnt.float().mean()),
            diag=diag)
+    _lib.check(L.psl_debug_option(b"knn", 1))
     assert bad1 == 0
     assert bad == 0
     assert torch.equal(cnt, O.neighbor_count(Do, r))
