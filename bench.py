@@ -76,6 +76,9 @@ def build_world(args, rank, world, dev):
         r_add, r_q = syn.dynamic_radii(color, cfg)
         fr = Frame(i, depth, color, r_add, r_q, c2w)
         if i < 0:
+            # earlier keyframes: their views were MAPPED when they were taken, i.e. points were added where they saw
+            # uncovered surface (untimed set-up; otherwise half of their samples would query empty space for ever)
+            slam.add_points(fr, c2w)
             slam.keyframes.append(fr)
         else:
             frames.append(fr)

@@ -160,6 +160,11 @@ struct psl_ctx {
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
   // small device scratch
+  // psl_map_iters: rows of the compact gradient / Adam state that have received a gradient since the frame started.
+  // A row that never did has g = m = v = 0, so its Adam update is exactly zero and the row is skipped (the reference
+  // steps every frustum-selected row densely, Mapper.py:394-402; the result is bit-identical)
+  unsigned char* touched = nullptr; size_t touched_cap = 0;
+  unsigned char *touched_geo = nullptr, *touched_col = nullptr;   // non-null only inside psl_map_iters
   unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read
   int* d_counter;
   int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
@@ -228,7 +233,8 @@ struct ProfScope {  // brackets a kernel class with HIP events on the launch str
 int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
-struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2; };
+struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2;
+                     const unsigned char* touched; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
                     const int* wf_index; float* wf; const int* wb_index; float* wb; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,

@@ -37,6 +37,7 @@ struct Bwd2Out {
   float* g_geo; float* g_col; const int* row_map;
   float* g_brel;     // [30] accumulated with atomics (pre-zeroed)
   float* g_affine;   // [12] accumulated with atomics (pre-zeroed)
+  unsigned char *t_geo, *t_col;   // per compact row: "has received a gradient" (psl_map_iters' lazy Adam), or null
 };
 
 constexpr int LD_E2 = 44;   // colour d(embedding) tile [16][40] (PTSG)
@@ -137,6 +138,7 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
           for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_geo[(size_t)row * C + jt * 16 + 4 * g + r], w[k] * dcg[jt][r]);
+          if (o.t_geo && g == 0) o.t_geo[row] = 1;
         }
       }
       if constexpr (PTSG) {
@@ -392,6 +394,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     dc[1] = *reinterpret_cast<const f32x4*>(sDcc + FRAG + (g * 16 + s) * 4);
     int dst = -1;
     if (i >= 0 && has && wgt != 0.f) dst = o.row_map ? o.row_map[i] : i;
+    if (featg && dst >= 0 && o.t_col && g == 0) o.t_col[dst] = 1;
     if (!relpos) {
       // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
       if (featg && dst >= 0) {
@@ -431,35 +434,52 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
         if (g == 0) sGW[row] = v;
       }
-      // dH1^T[hid][row] = W2^T d_nf^T (linear2.weight [32][128]): 8 hidden tiles, 2 k-groups
-      f32x4 dh[8];
+      // dH1^T[hid][row] = W2^T d_nf^T (linear2.weight [32][128]): 8 hidden tiles x 2 k-groups, walked as four steps of
+      // four tiles; the fragments of step + 1 and -- from the start -- the saved hidden activations h1 of this wave's
+      // rows (HBM: written by the forward kernel) are in flight while the MFMAs of a step issue.
+      f32x4 dh[8], h1v[8];
       constexpr int b2 = bfirst(BL_N2);
+      constexpr int b1 = bfirst(BL_N1);
+      f32x4 wn[4];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + j * 2 + 0, lane);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int it = 0; it < 8; ++it) {
+        dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        h1v[it] = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow * HC + it * 16 + 4 * g);
+      }
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {       // st = 2 * half + q
         sched_fence_b();
-        f32x4 wf8[8];
+        const int half = st >> 1, q = st & 1;
+        f32x4 wc4[4];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) wf8[it] = ldfragb(WB, b2 + it * 2 + q, lane);
+        for (int j = 0; j < 4; ++j) wc4[j] = wn[j];
+        if (st < 3) {
+          const int h2 = (st + 1) >> 1, q2 = (st + 1) & 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + (4 * h2 + j) * 2 + q2, lane);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b1 + j * 8 + 0, lane);       // first step of the next product
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int it = 0; it < 8; ++it) dh[it] = mfma16(wf8[it][r], dnf[q][r], dh[it]);
+          for (int j = 0; j < 4; ++j) dh[4 * half + j] = mfma16(wc4[j][r], dnf[q][r], dh[4 * half + j]);
       }
       PSL_STAMP(19);
       // dz1 = dH1 * softplus'(h1)
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const f32x4 h1 = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow * HC + it * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[it][r] = live ? dh[it][r] * softplus100_grad_from_out(h1[r]) : 0.f;
+        for (int r = 0; r < 4; ++r) dh[it][r] = live ? dh[it][r] * softplus100_grad_from_out(h1v[it][r]) : 0.f;
         if (parg) *reinterpret_cast<f32x4*>(a.ws.n_dz1 + grow * HC + it * 16 + 4 * g) = dh[it];
       }
       PSL_STAMP(20);
-      // dX1^T[x][row] = W1^T dz1^T (linear1.weight [128][52]): input tiles (feat 0..15, feat 16..31, rel 0..15, rel 16..19)
+      // dX1^T[x][row] = W1^T dz1^T (linear1.weight [128][52]): input tiles (feat 0..15, feat 16..31, rel 0..15, rel 16..19),
+      // eight k-groups; the four fragments of group q + 1 are in flight during group q
       f32x4 dx[4];
-      constexpr int b1 = bfirst(BL_N1);
 #pragma unroll
       for (int it = 0; it < 4; ++it) dx[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       const bool need_rel = parg || PTSG;
@@ -468,7 +488,11 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         sched_fence_b();
         f32x4 wf4[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) wf4[it] = ldfragb(WB, b1 + it * 8 + q, lane);
+        for (int it = 0; it < 4; ++it) wf4[it] = wn[it];
+        if (q < 7) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) wn[it] = ldfragb(WB, b1 + it * 8 + q + 1, lane);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           dx[0] = mfma16(wf4[0][r], dh[q][r], dx[0]);
@@ -484,7 +508,10 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
           for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], dx[jt][r]);
       }
-      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y]; one (row, frequency) pair per lane
+      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y].  Step 1: dL/dy for the 160 (row, frequency)
+      // pairs of this wave, in place in its LDS tile.  Step 2: the two small contractions over them --
+      // dB_rel[a][f] = sum_rows dy[row][f] rel[row][a] (30 lanes) and dp[s][a] -= sum_{rows of s, f} dy[row][f] B[a][f]
+      // (6 lanes) -- so that a wave ends in 30 (+6) LDS atomics instead of 480 (+480).
       if (need_rel) {
         float* xw = sXe + wave * 16 * LD_X2;
 #pragma unroll
@@ -498,23 +525,32 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
           const int r2 = e / ERF, f = e - r2 * ERF;
           const int row2 = 16 * wave + r2, s2 = row2 >> 3;
           const bool lv = (p0 + s2) < a.P && sI[row2] >= 0;
-          if (!lv) continue;
-          const float rx = sRel[row2 * 3], ry = sRel[row2 * 3 + 1], rz = sRel[row2 * 3 + 2];
           float sn, cs;
           if (a.ws.n_x) {     // the forward pass saved [sin | cos] in the first 20 columns of F_theta's input
             const float* xr = a.ws.n_x + ((size_t)p0 * K + row2) * NX;
             sn = xr[f]; cs = xr[ERF + f];
           } else {
-            fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
+            fast_sincosf(fourier_phase(sRel[row2 * 3], sRel[row2 * 3 + 1], sRel[row2 * 3 + 2], Brel, ERF, f), sn, cs);
           }
           const float dy2 = TWO_PI * (xw[r2 * LD_X2 + f] * cs - xw[r2 * LD_X2 + ERF + f] * sn);
-          if (parg) {
-            atomic_add_f32(&sDB[f], dy2 * rx); atomic_add_f32(&sDB[ERF + f], dy2 * ry);
-            atomic_add_f32(&sDB[2 * ERF + f], dy2 * rz);
-          }
-          if constexpr (PTSG) {   // rel = x_k - p  =>  dp -= d_rel
-            atomic_add_f32(&sDP[s2 * 4], -dy2 * Brel[f]); atomic_add_f32(&sDP[s2 * 4 + 1], -dy2 * Brel[ERF + f]);
-            atomic_add_f32(&sDP[s2 * 4 + 2], -dy2 * Brel[2 * ERF + f]);
+          xw[r2 * LD_X2 + f] = lv ? dy2 : 0.f;        // each pair is read and rewritten by its own lane only
+        }
+        wave_lds_sync();
+        if (parg && lane < 3 * ERF) {
+          const int ax = lane / ERF, f = lane - ax * ERF;
+          float v = 0.f;
+#pragma unroll
+          for (int r2 = 0; r2 < 16; ++r2) v += xw[r2 * LD_X2 + f] * sRel[(16 * wave + r2) * 3 + ax];
+          atomic_add_f32(&sDB[ax * ERF + f], v);
+        }
+        if constexpr (PTSG) {   // rel = x_k - p  =>  dp -= d_rel
+          if (lane >= 32 && lane < 38) {
+            const int sl = (lane - 32) / 3, ax = (lane - 32) - 3 * sl;
+            float v = 0.f;
+            for (int r2 = 8 * sl; r2 < 8 * sl + 8; ++r2)
+#pragma unroll
+              for (int f = 0; f < ERF; ++f) v += xw[r2 * LD_X2 + f] * Brel[ax * ERF + f];
+            atomic_add_f32(&sDP[(2 * wave + sl) * 4 + ax], -v);
           }
         }
       }
@@ -586,6 +622,7 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
   o.g_geo = g.g_geo_feats; o.g_col = g.g_col_feats; o.row_map = g.feat_row_map;
   o.g_brel = small;
   o.g_affine = small + 32;
+  o.t_geo = ctx->touched_geo; o.t_col = ctx->touched_col;
   const int tiles = (a.P + TILE - 1) / TILE;
   const bool color = a.flags & PSL_STAGE_COLOR;
   const bool ptsg = a.flags & PSL_PTS_GRAD;

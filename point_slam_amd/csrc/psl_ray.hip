@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     const long long i = (long long)blk * blockDim.x + threadIdx.x;
     if (i >= (long long)sg.n_rows * (C / 4)) return;
     const int row = (int)(i >> 3), q = (int)(i & 7);
+    if (sg.touched && !sg.touched[row]) return;       // g = m = v = 0: the update is exactly zero
     const int dst = sg.rows ? sg.rows[row] : row;
     float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
     float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];

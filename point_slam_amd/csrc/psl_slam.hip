@@ -662,8 +662,18 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       psl_map_ws_floats(n, m->n_frames)) {
     set_error("psl_map_iters: internal workspace layout exceeds psl_map_ws_floats"); return PSL_ERR_STATE;
   }
-  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false; } } pre_guard{ctx};
+  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
+                                               c->touched_geo = c->touched_col = nullptr; } } pre_guard{ctx};
   ctx->fused_ray = true;
+  if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {   // lazy Adam: rows without any gradient so far are skipped
+    const size_t need = 2 * (size_t)m->n_sel;
+    if (ctx->touched_cap < need) {
+      if (ctx->touched) (void)hipFree(ctx->touched);
+      PSL_HIP(hipMalloc(&ctx->touched, need + need / 4)); ctx->touched_cap = need + need / 4;
+    }
+    PSL_HIP(hipMemsetAsync(ctx->touched, 0, need, s));
+    ctx->touched_geo = ctx->touched; ctx->touched_col = ctx->touched + m->n_sel;
+  }
   if (ctx->loss_acc_cap < m->n_iters) {
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
     PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters)); psl::poison(ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
@@ -747,12 +757,12 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       AdamRowsSeg sg{}, sc{};
       AdamParSeg sp{};
       sg.feats = (float*)m->geo_feats; sg.rows = m->sel_rows; sg.g = (float4*)m->g_geo; sg.m = (float4*)m->adam_geo;
-      sg.v = (float4*)(m->adam_geo + (size_t)m->n_sel * C); sg.n_rows = m->n_sel;
+      sg.v = (float4*)(m->adam_geo + (size_t)m->n_sel * C); sg.n_rows = m->n_sel; sg.touched = ctx->touched_geo;
       int st = 1;
       if (color_stage) {
         st = m->step0_col + (it - m->n_geo_iters);
         sc.feats = (float*)m->col_feats; sc.rows = m->sel_rows; sc.g = (float4*)m->g_col; sc.m = (float4*)m->adam_col;
-        sc.v = (float4*)(m->adam_col + (size_t)m->n_sel * C); sc.n_rows = m->n_sel;
+        sc.v = (float4*)(m->adam_col + (size_t)m->n_sel * C); sc.n_rows = m->n_sel; sc.touched = ctx->touched_col;
         if (m->train_decoder) {
           sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
           sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
