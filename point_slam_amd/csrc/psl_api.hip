@@ -165,6 +165,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->cell_of, sizeof(int) * np)); psl::poison(c->cell_of, sizeof(int) * np);
   PSL_HIP(hipMalloc(&c->cell_start, sizeof(int) * (kMaxCells + 1))); psl::poison(c->cell_start, sizeof(int) * (kMaxCells + 1));
   PSL_HIP(hipMalloc(&c->cell_fill, sizeof(int) * kMaxCells)); psl::poison(c->cell_fill, sizeof(int) * kMaxCells);
+  PSL_HIP(hipMalloc(&c->coarse, sizeof(int) * kMaxCoarse)); psl::poison(c->coarse, sizeof(int) * kMaxCoarse);
   PSL_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * 4096)); psl::poison(c->scan_tmp, sizeof(int) * 4096);
   PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8)); psl::poison(c->bounds, sizeof(int) * 8);
   PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta))); psl::poison(c->meta, sizeof(GridMeta));
@@ -191,7 +192,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
-  (void)hipFree(c->cell_fill); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
+  (void)hipFree(c->cell_fill); (void)hipFree(c->coarse); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
   (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
   (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);

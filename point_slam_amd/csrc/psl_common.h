@@ -114,7 +114,9 @@ struct GridMeta {      // lives in device memory; written by k_grid_meta
   int nx, ny, nz;
   int ncells;
   int npts;
+  int cnx, cny, cnz;   // coarse occupancy grid: blocks of 4 x 4 x 4 cells (block edge >= the largest query radius)
 };
+constexpr int kMaxCoarse = kMaxCells / 4 + 1024;   // worst case: a grid that is one cell thick in two dimensions
 
 // --------------------------------------------------------------------- context
 // decode classes are kept apart by launch type: colour-stage mapper batch, geometry-stage mapper batch (13x fewer
@@ -144,6 +146,7 @@ struct psl_ctx {
   int* cell_of;          // [max_points]
   int* cell_start;       // [kMaxCells + 1] exclusive prefix sums
   int* cell_fill;        // [kMaxCells]
+  int* coarse = nullptr; // [kMaxCoarse] points per 4x4x4 block of cells: lets a query in empty space stop at once
   int* scan_tmp;         // block sums for the scan
   int* bounds;           // 6 ints: ordered-int min/max
   // forward-layout weights (rebuilt per render call from the master blob)

@@ -71,6 +71,7 @@ __global__ void k_grid_meta(const int* b, int n, float min_cell, GridMeta* m) {
   m->ox = lo[0]; m->oy = lo[1]; m->oz = lo[2];
   m->cell = cell; m->inv_cell = 1.0f / cell;
   m->nx = nx; m->ny = ny; m->nz = nz; m->ncells = nx * ny * nz; m->npts = n;
+  m->cnx = (nx + 3) / 4; m->cny = (ny + 3) / 4; m->cnz = (nz + 3) / 4;
 }
 
 __device__ __forceinline__ int cell_coord(float x, float o, float inv, int n) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ int cell_coord(float x, float o, float inv, int n) {
 }
 
 __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pos, const GridMeta* __restrict__ m,
-                                                    int* cell_of, int* cell_fill) {
+                                                    int* cell_of, int* cell_fill, int* coarse) {
   int n = m->npts;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 p = pos[i];
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ p
     int c = (cz * m->ny + cy) * m->nx + cx;
     cell_of[i] = c;
     atomicAdd(&cell_fill[c], 1);
+    atomicAdd(&coarse[((cz >> 2) * m->cny + (cy >> 2)) * m->cnx + (cx >> 2)], 1);
   }
 }
 
@@ -181,10 +183,11 @@ int grid_build(psl_ctx* ctx, hipStream_t s) {
   // (one-cell) ring of the expanding search already holds the 8 nearest neighbours
   hipLaunchKernelGGL(k_grid_meta, dim3(1), dim3(1), 0, s, ctx->bounds, n, 0.25f * ctx->cfg.max_query_radius, ctx->meta);
   PSL_HIP(hipMemsetAsync(ctx->cell_fill, 0, sizeof(int) * kMaxCells, s));
+  PSL_HIP(hipMemsetAsync(ctx->coarse, 0, sizeof(int) * kMaxCoarse, s));
   const int nblk = kMaxCells / SCAN_B;
   if (n > 0) {
     int nb = min((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, ctx->pos, ctx->meta, ctx->cell_of, ctx->cell_fill);
+    hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, s, ctx->pos, ctx->meta, ctx->cell_of, ctx->cell_fill, ctx->coarse);
   }
   hipLaunchKernelGGL(k_scan_block_sums, dim3(nblk), dim3(256), 0, s, ctx->cell_fill, ctx->meta, ctx->scan_tmp);
   hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, ctx->scan_tmp, nblk);
@@ -222,6 +225,25 @@ __device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, floa
   bx.lo[2] = cell_coord(z - rr, m.oz, m.inv_cell, m.nz); bx.hi[2] = cell_coord(z + rr, m.oz, m.inv_cell, m.nz);
 }
 
+// Coarse occupancy test, one wavefront: true when NO point lies in the 4x4x4-cell blocks that overlap the box
+// [lo - r, hi + r] -- then no point lies within r of anything inside [lo, hi] and the search is over before it began
+// (queries in still-unmapped space otherwise walk the whole r-cube, 9^3 cells, to learn the same).
+__device__ __forceinline__ bool wave_box_empty(const GridMeta& m, const int* __restrict__ coarse, float lox, float loy,
+                                               float loz, float hix, float hiy, float hiz, float r) {
+  const int lane = threadIdx.x & 63;
+  const float rr = r * 1.0001f + 1e-6f;
+  const int x0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx) >> 2, x1 = cell_coord(hix + rr, m.ox, m.inv_cell, m.nx) >> 2;
+  const int y0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny) >> 2, y1 = cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny) >> 2;
+  const int z0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz) >> 2, z1 = cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz) >> 2;
+  const int nxb = x1 - x0 + 1, nyb = y1 - y0 + 1, nb = nxb * nyb * (z1 - z0 + 1);
+  int any = 0;
+  for (int e = lane; e < nb; e += 64) {
+    const int ex = e % nxb, ey = (e / nxb) % nyb, ez = e / (nxb * nyb);
+    any |= coarse[((z0 + ez) * m.cny + (y0 + ey)) * m.cnx + (x0 + ex)];
+  }
+  return __ballot(any != 0) == 0ull;
+}
+
 // One wavefront answers one query with an EXPANDING search: scan the cells overlapping the cube [q-rho, q+rho]
 // (rho starts at one cell), keep the 8 smallest (d2, index) keys with d2 <= rho^2; if 8 were found, every
 // unscanned point is farther than rho (some coordinate differs by more than rho) and the result is final;
@@ -232,10 +254,18 @@ __device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, floa
 // fetched 64 rows at a time, one row per lane, then walked with coalesced 16 B/lane candidate loads.
 __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
                                          const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
-                                         float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr) {
+                                         float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr,
+                                         const int* __restrict__ coarse = nullptr) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   float rho = m.cell;
   unsigned long long cand = 0;
+  if (coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
+    const u64 sentinel = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = sentinel;
+    if (n_cand) *n_cand = 0;
+    return;
+  }
   for (;;) {
     const bool last = rho >= r;
     const float re = last ? r : rho;
@@ -317,7 +347,7 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
                                                   const float* __restrict__ r_query,
                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                   int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                  unsigned long long* __restrict__ cand_counter) {
+                                                  unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
   const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (p >= n_rays * S) return;
   const int ray = p / S, si = p - ray * S;
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
                rays_d[ray * 3 + 2], zq, qx, qy, qz);
   u64 best[K];
   unsigned long long n_cand = 0;
-  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand);
+  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand, coarse);
   unsigned ib, db; int cnt;
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
@@ -359,7 +389,7 @@ __global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ 
                                                    const float* __restrict__ r_query,
                                                    float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                    int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                   unsigned long long* __restrict__ cand_counter) {
+                                                   unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
   const int ray = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (ray >= n_rays) return;
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
@@ -375,6 +405,11 @@ __global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ 
                  rays_d[ray * 3 + 2], zq, qx[s], qy[s], qz[s]);
     lox = fminf(lox, qx[s]); loy = fminf(loy, qy[s]); loz = fminf(loz, qz[s]);
     hix = fmaxf(hix, qx[s]); hiy = fmaxf(hiy, qy[s]); hiz = fmaxf(hiz, qz[s]);
+  }
+  if (wave_box_empty(m, coarse, lox, loy, loz, hix, hiy, hiz, r)) {     // the whole ray segment lies in unmapped space
+    if (lane < S * K) I_out[(size_t)ray * S * K + lane] = -1;
+    if (lane < S) cnt_out[ray * S + lane] = 0;
+    return;
   }
   // this lane's slot of the five lists: list = lane >> 3 (lanes >= 40 idle), entry = lane & 7
   const int my_list = lane >> 3;
@@ -549,7 +584,7 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
                                                      const int* __restrict__ cell_start, const float* __restrict__ q,
                                                      const float* __restrict__ r_per_query, float r_fixed, float r2_fixed,
                                                      int nq, float* __restrict__ D_out, long long* __restrict__ I_out,
-                                                     int* __restrict__ cnt_out) {
+                                                     int* __restrict__ cnt_out, const int* __restrict__ coarse) {
   const int qi = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (qi >= nq) return;
   const int lane = threadIdx.x & 63;
@@ -557,7 +592,7 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   float r, r2;
   if (r_per_query) { r = r_per_query[qi]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
   u64 best[K];
-  wave_knn(m, spos, cell_start, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], r, r2, best);
+  wave_knn(m, spos, cell_start, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], r, r2, best, nullptr, coarse);
   unsigned ib, db; int cnt;
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) {
@@ -568,27 +603,27 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
 }
 
-int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 1 = one wavefront per sample (default), 2 = one per ray
+int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch size (default), 1 = one wavefront per sample, 2 = per ray
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  // default: one wavefront per SAMPLE.  The per-ray kernel (PSL_KNN=2) is exact too but measured slower: the five
-  // samples of a ray span +-2..4 % of the depth (up to 12 cm) while the search starts at a 4 cm cube, so the union box
-  // is 3-6x one sample's cube and every candidate is tested against samples it cannot belong to
-  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] == '2') ? 2 : 1; }
-  if (g_knn_version >= 2) {
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
+  // 0 = by launch size: small batches (the tracker's 200..5000 rays) are latency-bound and want five wavefronts per ray;
+  // the mapper's block prefetch (10^4..10^5 rays per launch) is throughput-bound and wants the shared candidate scan
+  const int ver = g_knn_version ? g_knn_version : (n_rays >= 8192 ? 2 : 1);
+  if (ver >= 2) {
     hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand);
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }
   int blocks = (n_rays * S + 3) / 4;
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand);
+                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
@@ -598,7 +633,7 @@ int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_
   if (nq <= 0) return PSL_OK;
   int blocks = (nq + 3) / 4;
   hipLaunchKernelGGL(k_knn_queries, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, q,
-                     r_per_query, r_scalar, r2_of(r_scalar), nq, D_out, (long long*)I_out, cnt_out);
+                     r_per_query, r_scalar, r2_of(r_scalar), nq, D_out, (long long*)I_out, cnt_out, ctx->coarse);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

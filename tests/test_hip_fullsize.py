@@ -186,7 +186,7 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
                          v1=got[1][0][p_].tolist(), D=[float(x) for x in Do[p_]]))
     report(test="fullsize_ray_knn", rays=R, mismatched_samples=bad, mismatched_v1=bad1, mean_cnt=float(cnt.float().mean()),
            diag=diag)
-    _lib.check(L.psl_debug_option(b"knn", 1))
+    _lib.check(L.psl_debug_option(b"knn", 0))       # back to the default (kernel chosen by launch size)
     assert bad1 == 0
     assert bad == 0
     assert torch.equal(cnt, O.neighbor_count(Do, r))

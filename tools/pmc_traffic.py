@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""HBM traffic per launch of every kernel class from the two PMC passes of tools/pmc_run.sh (FETCH_SIZE and WRITE_SIZE,
+separate rocprofv3 --pmc runs on tools/pmc_probe.py: the same launches bench.py times, 1 M points).
+
+Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: both counters are reported in KiB;
+on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) streaming reads at 64 B, so it is DOUBLED for
+the kernels whose reads are such streams (the weight-fragment and activation streams of the register-chained decode
+kernels, the dW GEMM, Adam); WRITE_SIZE is taken as reported (uncalibrated there).
+
+usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc_<tag>/write.csv out.json
+"""
+import json
+import sys
+
+CLASS_OF = [   # (substring of the kernel name, grid predicate, class)
+    # probe: mapper batch 4 995 samples = 626 workgroups x 512, tracker batch 1 000 samples = 126 x 512 (the grid is
+    # reported in work-items by rocpd; in workgroups by some versions)
+    ("k_decode_fwd2ILb1", lambda g: g >= 150000 or 300 <= g < 2000, "decode_fwd"),
+    ("k_decode_fwd2ILb1", lambda g: True, "decode_fwd_track"),
+    ("k_decode_fwd2ILb0", lambda g: True, "decode_fwd_geo"),
+    ("k_decode_bwd2ILb0ELb1", lambda g: True, "decode_bwd"),
+    ("k_decode_bwd2ILb1ELb1", lambda g: True, "decode_bwd_track"),
+    ("k_decode_bwd2ILb0ELb0", lambda g: True, "decode_bwd_geo"),
+    ("k_dwE", lambda g: True, "dw_gemm"),
+    ("k_map_adam", lambda g: True, "adam"),
+    ("k_knn_rays", lambda g: True, "knn"),
+]
+DOUBLE_FETCH = {"decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
+                "dw_gemm", "adam"}
+
+
+def read(path, counter):
+    out = {}
+    for line in open(path):
+        if line.startswith("#") or line.startswith("kernel,"):
+            continue
+        parts = line.strip().split(",")
+        if len(parts) != 5 or parts[1] != counter:
+            continue
+        name, _, grid = parts[0].rpartition("@")
+        try:
+            g = int(float(grid))
+        except ValueError:
+            g = 0
+        for sub, pred, cls in CLASS_OF:
+            if sub in name and pred(g):
+                n, mean = int(parts[2]), float(parts[3])
+                a = out.setdefault(cls, [0, 0.0])
+                a[0] += n
+                a[1] += mean * n
+                break
+    return {k: v[1] / v[0] for k, v in out.items() if v[0]}
+
+
+def main():
+    fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    for cls in sorted(set(fetch) | set(write)):
+        f_kib, w_kib = fetch.get(cls, 0.0), write.get(cls, 0.0)
+        f_b = f_kib * 1024 * (2 if cls in DOUBLE_FETCH else 1)
+        w_b = w_kib * 1024
+        res[cls] = dict(bytes_per_launch=round(f_b + w_b), read_bytes=round(f_b), write_bytes=round(w_b),
+                        fetch_size_kib_raw=round(f_kib, 1), write_size_kib_raw=round(w_kib, 1),
+                        fetch_doubled=cls in DOUBLE_FETCH,
+                        source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_probe.py")
+    json.dump(res, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,11 +15,14 @@ def main():
         scols = [r[1] for r in cur.execute("pragma table_info(rocpd_info_kernel_symbol)")]
         name_col = "kernel_name" if "kernel_name" in scols else scols[-1]
         pname = "name" if "name" in pcols else ("symbol" if "symbol" in pcols else pcols[-1])
-        q = f"""select s.{name_col}, p.{pname}, count(*), avg(e.value), sum(e.value)
+        # launches of one kernel at different sizes (tracker batch / mapper batch) are different classes: keep the grid
+        gcol = next((c for c in ("grid_size_x", "grid_x", "grid_size") if c in kcols), None)
+        gsel = f"d.{gcol}" if gcol else "0"
+        q = f"""select s.{name_col} || '@' || {gsel}, p.{pname}, count(*), avg(e.value), sum(e.value)
                 from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
                 join rocpd_kernel_dispatch d on e.event_id = d.event_id
                 join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-                group by s.{name_col}, p.{pname} order by s.{name_col}"""
+                group by s.{name_col}, {gsel}, p.{pname} order by s.{name_col}"""
         try:
             rows = cur.execute(q).fetchall()
         except Exception as ex:
@@ -30,7 +33,8 @@ def main():
         for n, c, k, m, sm in rows:
             if "psl" not in n:
                 continue
-            print(f"{n.split('(')[0][-48:]},{c},{k},{m:.1f},{sm:.0f}")
+            base, _, grid = n.rpartition("@")
+            print(f"{base.split('(')[0][-48:]}@{grid},{c},{k},{m:.1f},{sm:.0f}")
 
 
 if __name__ == "__main__":

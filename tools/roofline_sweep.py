@@ -7,7 +7,7 @@ import bench as B
 from point_slam_amd import _lib
 
 args = types.SimpleNamespace(gpus=1, steps=1, warmup=0, points=1_000_000, engine="native", mix="base", width=640,
-                             height=480, exchange_every=2, no_cpu_baseline=True, no_kernel_timing=True)
+                             height=480, exchange_every=2, no_cpu_baseline=True, no_kernel_timing=True, saturated_map=True)
 dev = torch.device("cuda:0")
 cfg, cam, slam, frames, cams0, every = B.build_world(args, 0, 1, dev)
 cfg["mapping"]["geo_iter_ratio"] = 0.0
