@@ -12,18 +12,18 @@ usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc
 import json
 import sys
 
-CLASS_OF = [   # (substring of the kernel name, grid predicate, class)
-    # probe: mapper batch 4 995 samples = 626 workgroups x 512, tracker batch 1 000 samples = 126 x 512 (the grid is
-    # reported in work-items by rocpd; in workgroups by some versions)
-    ("k_decode_fwd2ILb1", lambda g: g >= 150000 or 300 <= g < 2000, "decode_fwd"),
-    ("k_decode_fwd2ILb1", lambda g: True, "decode_fwd_track"),
-    ("k_decode_fwd2ILb0", lambda g: True, "decode_fwd_geo"),
-    ("k_decode_bwd2ILb0ELb1", lambda g: True, "decode_bwd"),
-    ("k_decode_bwd2ILb1ELb1", lambda g: True, "decode_bwd_track"),
-    ("k_decode_bwd2ILb0ELb0", lambda g: True, "decode_bwd_geo"),
+CLASS_OF = [   # (substring of the (possibly left-truncated) mangled kernel name, grid predicate, class)
+    # probe: mapper batch 4 995 samples = 626 workgroups x 512 work-items, tracker batch 1 000 samples = 126 x 512
+    ("decode_fwd2ILb1", lambda g: g >= 150000, "decode_fwd"),
+    ("decode_fwd2ILb1", lambda g: True, "decode_fwd_track"),
+    ("decode_fwd2ILb0", lambda g: True, "decode_fwd_geo"),
+    ("2ILb0ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd"),
+    ("2ILb1ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_track"),
+    ("2ILb0ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo"),
+    ("2ILb1ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo_track"),
     ("k_dwE", lambda g: True, "dw_gemm"),
-    ("k_map_adam", lambda g: True, "adam"),
-    ("k_knn_rays", lambda g: True, "knn"),
+    ("AdamRowsSeg", lambda g: True, "adam"),
+    ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn"),
 ]
 DOUBLE_FETCH = {"decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
                 "dw_gemm", "adam"}

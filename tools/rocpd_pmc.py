@@ -34,7 +34,7 @@ def main():
             if "psl" not in n:
                 continue
             base, _, grid = n.rpartition("@")
-            print(f"{base.split('(')[0][-48:]}@{grid},{c},{k},{m:.1f},{sm:.0f}")
+            print(f"{base.split('(')[0][-110:]}@{grid},{c},{k},{m:.1f},{sm:.0f}")
 
 
 if __name__ == "__main__":
