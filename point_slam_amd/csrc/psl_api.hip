@@ -180,6 +180,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
+  PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long)));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
@@ -194,7 +195,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->coarse); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
   (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
-  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
+  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
@@ -305,7 +306,10 @@ extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
     for (size_t i = 0; i < n; ++i) PSL_HIP(hipEventCreate(&ctx->ev[i]));
   }
   ctx->prof_on = on;
-  if (on) { memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work)); }
+  if (on) {
+    memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work));
+    PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long)));
+  }
   return PSL_OK;
 }
 
@@ -328,6 +332,11 @@ extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, do
     ms_out[i] = have > 0 ? tot * ((double)cnt / have) : 0.0;
     count_out[i] = cnt;
     work_out[i] = ctx->prof_work[i];
+  }
+  if (n > (int)PROF_ADAM) {   // feature rows the lazy Adam stepped: 5 streams x 4 B x 32 channels each
+    unsigned long long rows = 0;
+    PSL_HIP(hipMemcpy(&rows, ctx->adam_rows, sizeof(rows), hipMemcpyDeviceToHost));
+    work_out[PROF_ADAM] += 20.0 * C * (double)rows;
   }
   return n;
 }

@@ -612,7 +612,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
   // 0 = by launch size: small batches (the tracker's 200..5000 rays) are latency-bound and want five wavefronts per ray;
   // the mapper's block prefetch (10^4..10^5 rays per launch) is throughput-bound and wants the shared candidate scan
-  const int ver = g_knn_version ? g_knn_version : (n_rays >= 8192 ? 2 : 1);
+  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : 1);
   if (ver >= 2) {
     hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -341,8 +341,18 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
 // feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the
 // forward-layout copy of each weight it steps (wt_index: master element -> element of the [Kpad][N] copy, -1 for
 // biases / B matrices), which replaces the separate re-pack launch before the next forward.
+//
+// Feature rows, lazy and exact (lz.tab != null).  torch.optim.Adam steps every selected row in every iteration, also the
+// ones without a gradient (m decays, p keeps moving): ~200 000 rows x 2 groups x 7 accesses of 128 B per iteration,
+// 50 us of pure HBM time, although an iteration reads and writes only the ~25 000 rows next to its samples.  A row's
+// update depends on nothing but its own (p, g, m, v) and the step's constants, so the steps a row missed can be replayed
+// later IN REGISTERS, in order, with the same arithmetic -- bit-identical to the dense sweep.  A row is brought up to
+// date when (a) the backward of this iteration scattered a gradient into it (`touched`), or (b) the next iteration's
+// neighbour lists name it (`need` == it + 1, stamped by k_map_ray_fused from the prefetched lists), or (c) `dense`:
+// the next lists are not known yet (end of a k-NN prefetch block) or the call ends.  upto[row] = number of this
+// call's iterations already applied; -1 = never had a gradient, m = v = 0 and every missed step is exactly +0.
 __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_geo, int nb_col,
-                                                  float b1, float b2, float eps) {
+                                                  float b1, float b2, float eps, AdamLazy lz) {
   int blk = blockIdx.x;
   if (blk < nb_geo + nb_col) {
     const AdamRowsSeg& sg = (blk < nb_geo) ? geo : col;
@@ -350,16 +360,50 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     const long long i = (long long)blk * blockDim.x + threadIdx.x;
     if (i >= (long long)sg.n_rows * (C / 4)) return;
     const int row = (int)(i >> 3), q = (int)(i & 7);
-    if (sg.touched && !sg.touched[row]) return;       // g = m = v = 0: the update is exactly zero
-    const int dst = sg.rows ? sg.rows[row] : row;
+    if (!lz.tab) {                                      // dense single step (round-1 kernels, psl_adam_step_rows semantics)
+      const int dst = sg.rows ? sg.rows[row] : row;
+      float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
+      float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];
+      adam_update(pp.x, gg.x, mm.x, vv.x, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+      adam_update(pp.y, gg.y, mm.y, vv.y, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+      adam_update(pp.z, gg.z, mm.z, vv.z, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+      adam_update(pp.w, gg.w, mm.w, vv.w, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+      *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
+      sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    const bool has_g = sg.touched[row] != 0;
+    int u = sg.upto[row];
+    if (!has_g && (u < 0 || (!lz.dense && lz.need[row] != lz.it + 1))) return;
+    if (u < 0) u = lz.it;                               // first gradient of this row: the missed steps were +0
+    if (u > lz.it) return;
+    const int dst = sg.rows[row];
     float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
-    float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];
-    adam_update(pp.x, gg.x, mm.x, vv.x, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-    adam_update(pp.y, gg.y, mm.y, vv.y, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-    adam_update(pp.z, gg.z, mm.z, vv.z, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-    adam_update(pp.w, gg.w, mm.w, vv.w, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    float4 pp = *pp4, mm = sg.m[i], vv = sg.v[i];
+    const float* tab = reinterpret_cast<const float*>(lz.tab) + sg.tab_off;
+    for (int t = u; t < lz.it; ++t) {                   // replay of the steps without a gradient
+      const float a = tab[4 * t], b = tab[4 * t + 1];
+      adam_update(pp.x, 0.f, mm.x, vv.x, a, b, b1, b2, eps);
+      adam_update(pp.y, 0.f, mm.y, vv.y, a, b, b1, b2, eps);
+      adam_update(pp.z, 0.f, mm.z, vv.z, a, b, b1, b2, eps);
+      adam_update(pp.w, 0.f, mm.w, vv.w, a, b, b1, b2, eps);
+    }
+    {
+      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_g) { gg = sg.g[i]; sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      const float a = tab[4 * lz.it], b = tab[4 * lz.it + 1];
+      adam_update(pp.x, gg.x, mm.x, vv.x, a, b, b1, b2, eps);
+      adam_update(pp.y, gg.y, mm.y, vv.y, a, b, b1, b2, eps);
+      adam_update(pp.z, gg.z, mm.z, vv.z, a, b, b1, b2, eps);
+      adam_update(pp.w, gg.w, mm.w, vv.w, a, b, b1, b2, eps);
+    }
     *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
-    sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the 8 lanes of a row sit in one wavefront and have all read touched/upto above (same instruction)
+    if (q == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; }
+    if (lz.rows_done) {                                 // one atomic per wavefront, not per row
+      const unsigned long long act = __ballot(q == 0);
+      if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(lz.rows_done, (unsigned long long)__popcll(act));
+    }
   } else {
     const int i = (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x;
     if (i >= par.n) return;
@@ -374,6 +418,18 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
   }
 }
 
+// stamps the rows the NEXT iteration's neighbour lists name (AdamLazy::need)
+__global__ __launch_bounds__(256) void k_mark_need(const int4* __restrict__ next_I, int n4, const int* __restrict__ row_map,
+                                                   int* __restrict__ need, int stamp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int4 v = next_I[i];
+  const int e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (e[j] >= 0) { const int r = row_map[e[j]]; if (r >= 0) need[r] = stamp; }
+}
+
 }  // namespace psl
 
 using namespace psl;
@@ -385,7 +441,7 @@ extern "C" int psl_composite_fwd(const float* raw, const float* z, int n_rays, f
                               nullptr, weights, nullptr, (hipStream_t)stream);
 }
 
-static void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2) {
+void psl::adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2) {
   double bc1 = 1.0 - pow((double)b1, (double)step);
   double bc2 = 1.0 - pow((double)b2, (double)step);
   lr_bc1 = (float)((double)lr / bc1);
@@ -394,7 +450,7 @@ static void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, f
 
 namespace psl {
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par) {
+                    float lr_par, hipStream_t s, int step_par, AdamLazy lazy) {
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
@@ -402,8 +458,16 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   const int nb_col = (int)(((long long)col.n_rows * (C / 4) + 255) / 256);
   const int nb_par = (par.n + 255) / 256;
   if (nb_geo + nb_col + nb_par == 0) return PSL_OK;
+  geo.tab_off = 0; col.tab_off = 2;
   hipLaunchKernelGGL(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
-                     0.999f, 1e-8f);
+                     0.999f, 1e-8f, lazy);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+int launch_mark_need(const int* next_I, long long n_entries, const int* row_map, int* need, int stamp, hipStream_t s) {
+  const int n4 = (int)(n_entries / 4);
+  if (n4 <= 0) return PSL_OK;
+  hipLaunchKernelGGL(k_mark_need, dim3((n4 + 255) / 256), dim3(256), 0, s, (const int4*)next_I, n4, row_map, need, stamp);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

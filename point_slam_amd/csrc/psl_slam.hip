@@ -663,16 +663,36 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     set_error("psl_map_iters: internal workspace layout exceeds psl_map_ws_floats"); return PSL_ERR_STATE;
   }
   struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
-                                               c->touched_geo = c->touched_col = nullptr; } } pre_guard{ctx};
+                                               c->touched_geo = c->touched_col = nullptr;
+                                               c->adam_upto = c->adam_need = nullptr; } } pre_guard{ctx};
   ctx->fused_ray = true;
-  if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {   // lazy Adam: rows without any gradient so far are skipped
-    const size_t need = 2 * (size_t)m->n_sel;
+  std::vector<float4> tab_host;
+  if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {
+    // lazy exact Adam of the feature rows (k_map_adam): upto_geo | upto_col | need | touched_geo | touched_col
+    const size_t ns = (size_t)m->n_sel, need = 3 * ns * sizeof(int) + 2 * ns;
     if (ctx->touched_cap < need) {
       if (ctx->touched) (void)hipFree(ctx->touched);
+      ctx->touched = nullptr; ctx->touched_cap = 0;
       PSL_HIP(hipMalloc(&ctx->touched, need + need / 4)); ctx->touched_cap = need + need / 4;
     }
-    PSL_HIP(hipMemsetAsync(ctx->touched, 0, need, s));
-    ctx->touched_geo = ctx->touched; ctx->touched_col = ctx->touched + m->n_sel;
+    PSL_HIP(hipMemsetAsync(ctx->touched, 0xFF, 2 * ns * sizeof(int), s));
+    PSL_HIP(hipMemsetAsync(ctx->touched + 2 * ns * sizeof(int), 0, ns * sizeof(int) + 2 * ns, s));
+    ctx->adam_upto = (int*)ctx->touched; ctx->adam_need = ctx->adam_upto + 2 * ns;
+    ctx->touched_geo = ctx->touched + 3 * ns * sizeof(int); ctx->touched_col = ctx->touched_geo + ns;
+    if (ctx->adam_tab_cap < (size_t)m->n_iters) {
+      if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
+      ctx->adam_tab = nullptr; ctx->adam_tab_cap = 0;
+      PSL_HIP(hipMalloc(&ctx->adam_tab, sizeof(float4) * ((size_t)m->n_iters + 64))); ctx->adam_tab_cap = (size_t)m->n_iters + 64;
+    }
+    tab_host.resize(m->n_iters);
+    for (int it = 0; it < m->n_iters; ++it) {   // the constants launch_map_adam would compute for iteration `it`
+      const bool cs = it > m->n_geo_iters;
+      float4 t = make_float4(0.f, 1.f, 0.f, 1.f);
+      adam_consts(m->step0_geo + it + 1, cs ? m->lr_geo_color_stage : m->lr_geo_geo_stage, 0.9f, 0.999f, t.x, t.y);
+      if (cs) adam_consts(m->step0_col + (it - m->n_geo_iters), m->lr_col, 0.9f, 0.999f, t.z, t.w);
+      tab_host[it] = t;
+    }
+    PSL_HIP(hipMemcpyAsync(ctx->adam_tab, tab_host.data(), sizeof(float4) * m->n_iters, hipMemcpyHostToDevice, s));
   }
   if (ctx->loss_acc_cap < m->n_iters) {
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
@@ -746,31 +766,42 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
+    // lazy Adam: rows the next iteration reads must be up to date; its lists exist unless a prefetch block ends here
+    const bool lazy = ctx->adam_upto != nullptr;
+    const bool dense = !lazy || it + 1 == m->n_iters || (it + 1) % kblock == 0;
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
     // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
     const float lr_geo = color_stage ? m->lr_geo_color_stage : m->lr_geo_geo_stage;
     // dense Adam: 5 streams (p r/w, g r/w(zero), m r/w, v r/w ~ 7 accesses of 4 B; counted as 5 x 4 B per element as in
     // SURVEY.md §8d) over every selected row
-    ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((double)m->n_sel * C * (color_stage ? 2 : 1) +
+    // (lazy path: the rows actually stepped are counted on the device and added by psl_profile_read)
+    ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
                                              ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
+    if (lazy && !dense) {
+      rc = launch_mark_need(ctx->pre_I + (size_t)n * S * K, (long long)n * S * K, m->row_map, ctx->adam_need, it + 1, s);
+      if (rc) return rc;
+    }
     {
       AdamRowsSeg sg{}, sc{};
       AdamParSeg sp{};
       sg.feats = (float*)m->geo_feats; sg.rows = m->sel_rows; sg.g = (float4*)m->g_geo; sg.m = (float4*)m->adam_geo;
       sg.v = (float4*)(m->adam_geo + (size_t)m->n_sel * C); sg.n_rows = m->n_sel; sg.touched = ctx->touched_geo;
+      sg.upto = ctx->adam_upto;
       int st = 1;
       if (color_stage) {
         st = m->step0_col + (it - m->n_geo_iters);
         sc.feats = (float*)m->col_feats; sc.rows = m->sel_rows; sc.g = (float4*)m->g_col; sc.m = (float4*)m->adam_col;
         sc.v = (float4*)(m->adam_col + (size_t)m->n_sel * C); sc.n_rows = m->n_sel; sc.touched = ctx->touched_col;
+        sc.upto = ctx->adam_upto ? ctx->adam_upto + m->n_sel : nullptr;
         if (m->train_decoder) {
           sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
           sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
           sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
         }
       }
+      AdamLazy lz{lazy ? ctx->adam_tab : nullptr, ctx->adam_need, it, dense ? 1 : 0, ctx->adam_rows};
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
-                           st + m->step0_params);
+                           st + m->step0_params, lz);
       if (rc) return rc;
       if (ex && color_stage) {   // mlp_exposure is part of color_decoder.parameters() (decoders_lr); latent lr 0.001
         hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, m->n_frames, ex_g, ex_aff, ex_act,
