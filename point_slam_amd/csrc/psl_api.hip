@@ -180,7 +180,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
-  PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long)));
+  PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
@@ -308,7 +308,7 @@ extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
   ctx->prof_on = on;
   if (on) {
     memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work));
-    PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long)));
+    PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
   }
   return PSL_OK;
 }
@@ -334,8 +334,9 @@ extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, do
     work_out[i] = ctx->prof_work[i];
   }
   if (n > (int)PROF_ADAM) {   // feature rows the lazy Adam stepped: 5 streams x 4 B x 32 channels each
-    unsigned long long rows = 0;
-    PSL_HIP(hipMemcpy(&rows, ctx->adam_rows, sizeof(rows), hipMemcpyDeviceToHost));
+    unsigned long long rows = 0, slots[kAdamRowSlots];
+    PSL_HIP(hipMemcpy(slots, ctx->adam_rows, sizeof(slots), hipMemcpyDeviceToHost));
+    for (int k = 0; k < kAdamRowSlots; k += 8) rows += slots[k];
     work_out[PROF_ADAM] += 20.0 * C * (double)rows;
   }
   return n;

@@ -244,11 +244,13 @@ struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_row
                      int* upto;                // [n_rows] iterations of this call already applied to the row (-1: m = v = 0)
                      int tab_off; };           // 0: (x,y) of the step table belong to this group, 2: (z,w)
 // Lazy, exact Adam of the mapper's feature rows (see k_map_adam): per-iteration constants of the whole call
-struct AdamLazy { const float4* tab; const int* need; int it; int dense; unsigned long long* rows_done; };
+constexpr int kAdamTabLds = 72;   // >= the k-NN prefetch block (64 iterations) + 1
+constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache lines
+struct AdamLazy { const float4* tab; const int* need; int it; int dense; unsigned long long* rows_done; int base; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
                     const int* wf_index; float* wf; const int* wb_index; float* wb; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, 0, 1, nullptr});
+                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, 0, 1, nullptr, 0});
 int launch_mark_need(const int* next_I, long long n_entries, const int* row_map, int* need, int stamp, hipStream_t s);
 void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2);
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,

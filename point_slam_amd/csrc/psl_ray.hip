@@ -358,8 +358,9 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     const AdamRowsSeg& sg = (blk < nb_geo) ? geo : col;
     if (blk >= nb_geo) blk -= nb_geo;
     const long long i = (long long)blk * blockDim.x + threadIdx.x;
-    if (i >= (long long)sg.n_rows * (C / 4)) return;
-    const int row = (int)(i >> 3), q = (int)(i & 7);
+    const bool inside = i < (long long)sg.n_rows * (C / 4);
+    if (!lz.tab && !inside) return;
+    const int row = inside ? (int)(i >> 3) : 0, q = (int)(i & 7);
     if (!lz.tab) {                                      // dense single step (round-1 kernels, psl_adam_step_rows semantics)
       const int dst = sg.rows ? sg.rows[row] : row;
       float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
@@ -372,37 +373,53 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
       sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       return;
     }
-    const bool has_g = sg.touched[row] != 0;
+    const bool has_g = inside && sg.touched[row] != 0;
     int u = sg.upto[row];
-    if (!has_g && (u < 0 || (!lz.dense && lz.need[row] != lz.it + 1))) return;
+    const bool work = has_g || (inside && u >= 0 && u <= lz.it && (lz.dense || lz.need[row] == lz.it + 1));
+    if (!__syncthreads_or(work ? 1 : 0)) return;
+    // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
+    // made each step a full memory round trip)
+    __shared__ float2 stab[kAdamTabLds];
+    const int nt = lz.it - lz.base + 1;
+    for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
+      const float4 v = lz.tab[lz.base + t];
+      stab[t] = sg.tab_off ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+    }
+    __syncthreads();
+    if (!work) return;
     if (u < 0) u = lz.it;                               // first gradient of this row: the missed steps were +0
-    if (u > lz.it) return;
     const int dst = sg.rows[row];
     float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
     float4 pp = *pp4, mm = sg.m[i], vv = sg.v[i];
-    const float* tab = reinterpret_cast<const float*>(lz.tab) + sg.tab_off;
+    auto consts = [&](int t) -> float2 {
+      const int k = t - lz.base;
+      if (k >= 0 && k < kAdamTabLds) return stab[k];
+      const float4 v = lz.tab[t];
+      return sg.tab_off ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+    };
     for (int t = u; t < lz.it; ++t) {                   // replay of the steps without a gradient
-      const float a = tab[4 * t], b = tab[4 * t + 1];
-      adam_update(pp.x, 0.f, mm.x, vv.x, a, b, b1, b2, eps);
-      adam_update(pp.y, 0.f, mm.y, vv.y, a, b, b1, b2, eps);
-      adam_update(pp.z, 0.f, mm.z, vv.z, a, b, b1, b2, eps);
-      adam_update(pp.w, 0.f, mm.w, vv.w, a, b, b1, b2, eps);
+      const float2 ab = consts(t);
+      adam_update(pp.x, 0.f, mm.x, vv.x, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.y, 0.f, mm.y, vv.y, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.z, 0.f, mm.z, vv.z, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.w, 0.f, mm.w, vv.w, ab.x, ab.y, b1, b2, eps);
     }
     {
       float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
       if (has_g) { gg = sg.g[i]; sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-      const float a = tab[4 * lz.it], b = tab[4 * lz.it + 1];
-      adam_update(pp.x, gg.x, mm.x, vv.x, a, b, b1, b2, eps);
-      adam_update(pp.y, gg.y, mm.y, vv.y, a, b, b1, b2, eps);
-      adam_update(pp.z, gg.z, mm.z, vv.z, a, b, b1, b2, eps);
-      adam_update(pp.w, gg.w, mm.w, vv.w, a, b, b1, b2, eps);
+      const float2 ab = consts(lz.it);
+      adam_update(pp.x, gg.x, mm.x, vv.x, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.y, gg.y, mm.y, vv.y, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.z, gg.z, mm.z, vv.z, ab.x, ab.y, b1, b2, eps);
+      adam_update(pp.w, gg.w, mm.w, vv.w, ab.x, ab.y, b1, b2, eps);
     }
     *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
     // the 8 lanes of a row sit in one wavefront and have all read touched/upto above (same instruction)
     if (q == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; }
-    if (lz.rows_done) {                                 // one atomic per wavefront, not per row
+    if (lz.rows_done) {                                 // one atomic per wavefront, spread over 256 cache lines
       const unsigned long long act = __ballot(q == 0);
-      if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) atomicAdd(lz.rows_done, (unsigned long long)__popcll(act));
+      if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
+        atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), (unsigned long long)__popcll(act));
     }
   } else {
     const int i = (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x;

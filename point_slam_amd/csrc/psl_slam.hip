@@ -45,14 +45,11 @@ struct RayBufs {             // per-iteration ray batch (n slots, inactive slots
 
 // get_samples + get_rays_from_uv (src/common.py:40-89,162-183) for pre-drawn flat pixel indices.
 // cam_tensor != null: pose from (quat, T) (tracker); else from frames[f].c2w (mapper).
-__global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int H1, int W0, int W1,
-                                                   const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
-                                                   const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
-                                                   RayBufs b, int n_batches = 1) {
-  // n_batches > 1: the rays of several mapper iterations at once (block prefetch)
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ray_setup_one(int i, const psl_cam_intr& cam, int H0, int H1, int W0, int W1,
+                                              const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
+                                              const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
+                                              const RayBufs& b) {
   int n = n_frames * pix_per_frame;
-  if (i >= n * n_batches) return;
   int f = (i % n) / pix_per_frame;
   const FrameDev& fr = frames[f];
   float R[3][3], T[3];
@@ -84,6 +81,16 @@ __global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int
   b.gd[i] = act ? dep : 1.0f;                // inactive slots get a harmless finite depth
 }
 
+__global__ __launch_bounds__(256) void k_ray_setup(psl_cam_intr cam, int H0, int H1, int W0, int W1,
+                                                   const FrameDev* __restrict__ frames, int n_frames, int pix_per_frame,
+                                                   const int* __restrict__ pix_idx, const float* __restrict__ cam_tensor,
+                                                   RayBufs b, int n_batches = 1) {
+  // n_batches > 1: the rays of several mapper iterations at once (block prefetch)
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_frames * pix_per_frame * n_batches) return;
+  ray_setup_one(i, cam, H0, H1, W0, W1, frames, n_frames, pix_per_frame, pix_idx, cam_tensor, b);
+}
+
 __global__ void k_track_init(FrameDev* fdev, FrameDev fh, float* best) {
   if (threadIdx.x == 0) *fdev = fh;
   if (threadIdx.x < 8) best[threadIdx.x] = (threadIdx.x == 7) ? 1e20f : 0.f;
@@ -93,8 +100,7 @@ __global__ void k_track_init(FrameDev* fdev, FrameDev fh, float* best) {
 // (Tracker.py:142-144, Mapper.py:507-509).  One workgroup.  n <= 4096: every thread ranks its own element
 // against all others held in LDS (n^2/1024 compares per thread, no sort, two barriers); larger batches use a
 // 4-pass byte-wise radix select over the float bit patterns (positive floats order like their bits).
-__global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
-  gd += (size_t)blockIdx.x * n; active += (size_t)blockIdx.x * n;   // one workgroup per ray batch
+__device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd, int* active, int n) {
   __shared__ unsigned keys[4096];
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_min, s_med;
@@ -164,6 +170,11 @@ __global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__
   const float thr = fminf(10.0f * med, 1.2f * mx);
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     if (active[i] && !(gd[i] <= thr)) active[i] = 0;
+}
+
+__global__ __launch_bounds__(1024) void k_depth_inlier(const float* __restrict__ gd, int* active, int n) {
+  // one workgroup per ray batch
+  depth_inlier_block(gd + (size_t)blockIdx.x * n, active + (size_t)blockIdx.x * n, n);
 }
 
 __device__ __forceinline__ float signf0(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
@@ -258,6 +269,36 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
   p = p + ((-(float)((double)lr / bc1)) * m) / denom;
 }
 
+// one thread: quaternion chain of dL/dR, then Adam on the 7 pose parameters
+__device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&gT)[3], float* cam_tensor, float* adam_mv,
+                                          int step, float lr_T, float lr_q) {
+  float qr = cam_tensor[0], qi = cam_tensor[1], qj = cam_tensor[2], qk = cam_tensor[3];
+  float nn = qr * qr + qi * qi + qj * qj + qk * qk;
+  float s = 2.0f / nn;
+  // R = I + s*M(q)
+  float M[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr},
+                   {qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr},
+                   {qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)}};
+  float GM = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) GM += G[a][k] * M[a][k];
+  float dMr = G[0][1] * (-qk) + G[0][2] * qj + G[1][0] * qk + G[1][2] * (-qi) + G[2][0] * (-qj) + G[2][1] * qi;
+  float dMi = G[0][1] * qj + G[0][2] * qk + G[1][0] * qj + G[1][1] * (-2.f * qi) + G[1][2] * (-qr) + G[2][0] * qk +
+              G[2][1] * qr + G[2][2] * (-2.f * qi);
+  float dMj = G[0][0] * (-2.f * qj) + G[0][1] * qi + G[0][2] * qr + G[1][0] * qi + G[1][2] * qk + G[2][0] * (-qr) +
+              G[2][1] * qk + G[2][2] * (-2.f * qj);
+  float dMk = G[0][0] * (-2.f * qk) + G[0][1] * (-qr) + G[0][2] * qi + G[1][0] * qr + G[1][1] * (-2.f * qk) +
+              G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
+  float ds = -s * s;   // d s / d q_x = -s^2 q_x
+  float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, step);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, step);
+}
+
 // d(loss)/d(pose) from the per-ray gradients, analytic quaternion chain, Adam on (T: lr, quat: 0.2 lr)
 // (Tracker.py:305-311,323,183; get_camera_from_tensor common.py:251-267).
 __global__ __launch_bounds__(256) void k_pose_step(RayBufs b, int n, float* cam_tensor, float* adam_mv /*[14]*/, int step,
@@ -294,31 +335,182 @@ __global__ __launch_bounds__(256) void k_pose_step(RayBufs b, int n, float* cam_
     for (int k = 0; k < 3; ++k) G[a][k] = lds[0][a * 3 + k] + lds[1][a * 3 + k] + lds[2][a * 3 + k] + lds[3][a * 3 + k];
     gT[a] = lds[0][9 + a] + lds[1][9 + a] + lds[2][9 + a] + lds[3][9 + a];
   }
-  float qr = cam_tensor[0], qi = cam_tensor[1], qj = cam_tensor[2], qk = cam_tensor[3];
-  float nn = qr * qr + qi * qi + qj * qj + qk * qk;
-  float s = 2.0f / nn;
-  // R = I + s*M(q)
-  float M[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr},
-                   {qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr},
-                   {qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)}};
-  float GM = 0.f;
+  pose_adam(G, gT, cam_tensor, adam_mv, step, lr_T, lr_q);
+}
+
+// ------------------------------------------------------------------ tracker, batches of <= 1024 rays: two fused launches
+// A tracker iteration on a Replica-sized batch (200 rays) spent 7 of its 10 launches in single-workgroup kernels of
+// ~5 us each (ray set-up, depth-outlier mask, compositing, loss, compositing backward, ray gradient, pose step).  With
+// one ray per thread of ONE 1024-thread workgroup they collapse into two kernels around the decode:
+//   k_track_pre : [ray gradient + pose step of the previous iteration]  ->  ray set-up + depth-outlier mask of this one
+//   k_track_mid : compositing -> tracker loss (mask, best pose) -> compositing backward
+// so an iteration is k_track_pre, k-NN, decode forward, k_track_mid, decode backward.  Same arithmetic, same order per
+// ray as the separate kernels; the block reductions see one element per thread.
+__global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, const float4* __restrict__ dp,
+                                                    const float4* __restrict__ dp2, float near_s, float far_s, RayBufs b,
+                                                    int n, float* cam_tensor, float* adam_mv, int step, float lr_T,
+                                                    float lr_q, psl_cam_intr cam, int H0, int H1, int W0, int W1,
+                                                    const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx) {
+  __shared__ float red[16][12];
+  const int r = threadIdx.x;
+  if (do_step) {
+    float acc[12];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+    if (r < n) {
+      // g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (k_ray_grad)
+      float go[3] = {0.f, 0.f, 0.f}, gd3[3] = {0.f, 0.f, 0.f};
+      const float gt = b.gd[r];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) GM += G[a][k] * M[a][k];
-  float dMr = G[0][1] * (-qk) + G[0][2] * qj + G[1][0] * qk + G[1][2] * (-qi) + G[2][0] * (-qj) + G[2][1] * qi;
-  float dMi = G[0][1] * qj + G[0][2] * qk + G[1][0] * qj + G[1][1] * (-2.f * qi) + G[1][2] * (-qr) + G[2][0] * qk +
-              G[2][1] * qr + G[2][2] * (-2.f * qi);
-  float dMj = G[0][0] * (-2.f * qj) + G[0][1] * qi + G[0][2] * qr + G[1][0] * qi + G[1][2] * qk + G[2][0] * (-qr) +
-              G[2][1] * qk + G[2][2] * (-2.f * qj);
-  float dMk = G[0][0] * (-2.f * qk) + G[0][1] * (-qr) + G[0][2] * qi + G[1][0] * qr + G[1][1] * (-2.f * qk) +
-              G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
-  float ds = -s * s;   // d s / d q_x = -s^2 q_x
-  float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
+      for (int s = 0; s < S; ++s) {
+        float4 g = dp[r * S + s];
+        if (dp2) { const float4 g2 = dp2[r * S + s]; g.x += g2.x; g.y += g2.y; g.z += g2.z; }
+        const float z = sample_z(gt, s, near_s, far_s);
+        go[0] += g.x; go[1] += g.y; go[2] += g.z;
+        gd3[0] += z * g.x; gd3[1] += z * g.y; gd3[2] += z * g.z;
+      }
+      const float d0 = b.dirs[r * 3], d1 = b.dirs[r * 3 + 1], d2 = b.dirs[r * 3 + 2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, step);
+      for (int a = 0; a < 3; ++a) {
+        acc[a * 3 + 0] += d0 * gd3[a]; acc[a * 3 + 1] += d1 * gd3[a]; acc[a * 3 + 2] += d2 * gd3[a];   // dL/dR[a][k]
+        acc[9 + a] += go[a];                                                                          // dL/dT[a]
+      }
+    }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, step);
+    for (int j = 0; j < 12; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) red[w][j] = acc[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float G[3][3], gT[3];
+      const int nw = (n + 63) >> 6;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][a * 3 + k]; G[a][k] = t; }
+        float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][9 + a]; gT[a] = t;
+      }
+      pose_adam(G, gT, cam_tensor, adam_mv, step, lr_T, lr_q);
+      __threadfence_block();
+    }
+    __syncthreads();          // the new pose is visible to every thread of the workgroup
+  }
+  if (!do_setup) return;
+  if (r < n) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx, cam_tensor, b);
+  __syncthreads();
+  depth_inlier_block(b.gd, b.active, n);
+}
+
+__global__ __launch_bounds__(1024) void k_track_mid(const float4* __restrict__ raw, const int* __restrict__ cnt, RayBufs b, int n,
+                                                    float near_s, float far_s, int min_nn, float coef, float w_color,
+                                                    int handle_dynamic, int use_color, const float* __restrict__ cam_tensor,
+                                                    float* best /*[8]*/, float* loss_out /*[4]*/, float4* __restrict__ d_raw,
+                                                    float* __restrict__ zero64) {
+  __shared__ double lds[16];
+  __shared__ float s_thr;
+  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;   // accumulators of the decode backward that follows
+  const int r = threadIdx.x;
+  const bool in = r < n;
+  float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
+  float W = 1.f, d = 0.f, v = 0.f, m0 = 0.f, m1 = 0.f, m2 = 0.f, gt = 1.f;
+  bool act = false;
+  if (in) {                                       // k_composite_fwd
+    gt = b.gd[r];
+    act = b.active[r] != 0;
+    float T = 1.0f, wsum = 0.f;
+    int nhas = 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float4 q = raw[r * S + s];
+      z[s] = sample_z(gt, s, near_s, far_s);
+      al[s] = sigmoidf(coef * q.w);
+      Tt[s] = T;
+      w[s] = al[s] * T;
+      T = T * (1.0f - al[s] + 1e-10f);
+      wsum += w[s];
+      c0[s] = q.x; c1[s] = q.y; c2[s] = q.z;
+      nhas += (cnt[r * S + s] >= min_nn) ? 1 : 0;
+    }
+    W = wsum + 1e-10f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { a0 += w[s] * c0[s]; a1 += w[s] * c1[s]; a2 += w[s] * c2[s]; ad += w[s] * z[s]; }
+    d = ad / W;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { const float tmp = z[s] - d; v += w[s] * tmp * tmp; }
+    m0 = a0 / W; m1 = a1 / W; m2 = a2 / W;
+    b.depth[r] = d; b.var[r] = v;
+    b.rgb[r * 3] = m0; b.rgb[r * 3 + 1] = m1; b.rgb[r * 3 + 2] = m2;
+    b.valid[r] = nhas >= (S / 2 + 1) ? 1 : 0;
+  }
+  // k_tracker_loss (Tracker.py:159-180)
+  double se = 0.0, sc = 0.0;
+  if (in && act) {
+    float e = fabsf(gt - d);
+    if (handle_dynamic) e = e / sqrtf(v + 1e-10f);
+    se = (double)e; sc = 1.0;
+  }
+  const double tot = block_sum_d(se, lds);
+  const double nact = block_sum_d(sc, lds);
+  if (threadIdx.x == 0) s_thr = (nact > 0.0) ? 10.0f * (float)(tot / nact) : 0.f;
+  __syncthreads();
+  const float thr = s_thr;
+  double lg = 0.0, lc = 0.0;
+  float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (in && act) {
+    const float inv = 1.0f / sqrtf(v + 1e-10f);
+    const float diff = fabsf(gt - d);
+    const float tmp = handle_dynamic ? diff / sqrtf(v + 1e-10f) : diff;
+    const bool m = (tmp < thr) && (gt > 0.f) && (d == d) && (v == v);
+    if (m) {
+      const float e = diff / sqrtf(v + 1e-10f);
+      const float ec = fminf(fmaxf(e, 0.f), 1e3f);
+      lg = (double)ec;
+      if (e <= 1e3f) gdp = signf0(d - gt) * inv;
+      const float q0 = b.gc[r * 3], q1 = b.gc[r * 3 + 1], q2 = b.gc[r * 3 + 2];
+      lc = (double)fabsf(q0 - m0) + (double)fabsf(q1 - m1) + (double)fabsf(q2 - m2);
+      if (use_color) { g0 = w_color * signf0(m0 - q0); g1 = w_color * signf0(m1 - q1); g2 = w_color * signf0(m2 - q2); }
+    }
+  }
+  const double Lg = block_sum_d(lg, lds);
+  const double Lc = block_sum_d(lc, lds);
+  if (threadIdx.x == 0) {
+    const double L = use_color ? Lg + (double)w_color * Lc : Lg;
+    loss_out[0] = (float)L; loss_out[1] = (float)Lg; loss_out[2] = (float)Lc; loss_out[3] = (float)nact;
+    if ((float)L < best[7]) {
+      best[7] = (float)L;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) best[j] = cam_tensor[j];
+    }
+  }
+  if (!in) return;
+  // k_composite_bwd with g_var = 0
+  const float gv = 0.f;
+  float dvd = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) dvd += w[s] * (z[s] - d);
+  const float gdt = gdp + gv * (-2.0f * dvd);
+  float gw[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float dz = z[s] - d;
+    gw[s] = gv * dz * dz + (gdt * dz + g0 * (c0[s] - m0) + g1 * (c1[s] - m1) + g2 * (c2[s] - m2)) / W;
+  }
+  float suffix = 0.f;  // sum_{t>s} gw_t w_t
+#pragma unroll
+  for (int s = S - 1; s >= 0; --s) {
+    const float ga = gw[s] * Tt[s] - suffix / (1.0f - al[s] + 1e-10f);
+    const float gocc = ga * coef * al[s] * (1.0f - al[s]);
+    const float ws = w[s] / W;
+    d_raw[r * S + s] = make_float4(g0 * ws, g1 * ws, g2 * ws, gocc);
+    suffix += gw[s] * w[s];
+  }
 }
 
 // ------------------------------------------------------------------ per-frame exposure compensation
@@ -582,28 +774,55 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     PSL_LAUNCH_CHECK();
     ra.flags |= PSL_HAS_AFFINE; ra.exposure_affine = ex_aff; rg.g_exposure_affine = ex_g;
   }
+  // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
+  const bool fused = n <= 1024 && ctx->decode_bwd_version >= 2 && ctx->decode_version >= 2;
+  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; } } fused_guard{ctx};
+  const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
+  if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
+  auto track_pre = [&](int it, int do_step, int do_setup) {
+    ProfScope ps(ctx, PROF_MISC, s);
+    hipLaunchKernelGGL(k_track_pre, dim3(1), dim3(1024), 0, s, do_step, do_setup, (const float4*)rw.dp, (const float4*)rw.dp2,
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, b, n, t->cam_tensor, t->adam_state, t->step0 + it,
+                       t->lr_T, t->lr_quat, t->cam, eh, t->cam.H - eh, ew, t->cam.W - ew, fdev,
+                       t->pix_idx + (size_t)std::min(it, t->n_iters - 1) * n);
+  };
   for (int it = 0; it < t->n_iters; ++it) {
-    { ProfScope ps(ctx, PROF_MISC, s);
+    if (fused) {
+      track_pre(it, it > 0 ? 1 : 0, 1);       // pose step of iteration it-1 (Adam step number step0 + it), rays of iteration it
+      PSL_LAUNCH_CHECK();
+    } else {
+      ProfScope ps(ctx, PROF_MISC, s);
       hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, eh, t->cam.H - eh,
                          ew, t->cam.W - ew, fdev, 1, n, t->pix_idx + (size_t)it * n, t->cam_tensor, b);
       hipLaunchKernelGGL(k_depth_inlier, dim3(1), dim3(1024), 0, s, b.gd, b.active, n);
-      PSL_LAUNCH_CHECK(); }
+      PSL_LAUNCH_CHECK();
+    }
     ra.fallback_geo = t->fallback + (size_t)it * 64;
     ra.fallback_col = t->fallback + (size_t)it * 64 + 32;
     int rc = render_fwd_impl(ctx, &ra, s, it == 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
-                       t->cam_tensor, t->best_out, t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch);
+    float* lo = t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch;
+    if (fused) {
+      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
+      hipLaunchKernelGGL(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
+                         ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, t->sigmoid_coef, t->w_color, t->handle_dynamic,
+                         t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
+    } else {
+      hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
+                         t->cam_tensor, t->best_out, lo);
+    }
     PSL_LAUNCH_CHECK();
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
-                       t->lr_T, t->lr_quat);
+    if (!fused)
+      hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
+                         t->lr_T, t->lr_quat);
     if (ex)
       hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, 1, ex_g, ex_aff, ex_act, ex->adam,
                          ex->adam + (EX_N + EXD), ex->step0 + it + 1, ex->lr_mlp, ex->lr_feat);
     PSL_LAUNCH_CHECK();
   }
+  if (fused && t->n_iters > 0) { track_pre(t->n_iters, 1, 0); PSL_LAUNCH_CHECK(); }   // the last pose step
   return PSL_OK;
 }
 
@@ -799,7 +1018,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
           sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
         }
       }
-      AdamLazy lz{lazy ? ctx->adam_tab : nullptr, ctx->adam_need, it, dense ? 1 : 0, ctx->adam_rows};
+      AdamLazy lz{lazy ? ctx->adam_tab : nullptr, ctx->adam_need, it, dense ? 1 : 0, ctx->adam_rows, it - it % kblock};
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
                            st + m->step0_params, lz);
       if (rc) return rc;
