@@ -302,6 +302,19 @@ __device__ __forceinline__ void adam_update(float& p, float g, float& m, float& 
   p = p + ((-lr_bc1) * m) / denom;
 }
 
+// A replayed step of the lazy Adam: the gradient is zero.  m and v are the expressions of adam_update with g = 0, bit for
+// bit.  The parameter increment -lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps) uses the hardware reciprocal and square root
+// (1 ulp each) instead of the correctly rounded quotient and root: the replay loop is a serial chain per row, and the
+// IEEE sequences made one step cost ~1 us on a lone wavefront.  The increment is ~1e-3 of the step size itself
+// ~1e-3 |p|; two ulp of it are ~1e-13 |p|, far below the rounding of the sum p + increment.
+__device__ __forceinline__ void adam_replay(float& p, float& m, float& v, float lr_bc1, float inv_sqrt_bc2, float b1,
+                                            float b2, float eps) {
+  m = m + (1.0f - b1) * (0.f - m);
+  v = v * b2;
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_sqrt_bc2, eps);
+  p = fmaf((-lr_bc1) * m, __builtin_amdgcn_rcpf(denom), p);
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float lr_bc1, float sqrt_bc2,
                                               float b1, float b2, float eps, int zero_grad) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
 // ones without a gradient (m decays, p keeps moving): ~200 000 rows x 2 groups x 7 accesses of 128 B per iteration,
 // 50 us of pure HBM time, although an iteration reads and writes only the ~25 000 rows next to its samples.  A row's
 // update depends on nothing but its own (p, g, m, v) and the step's constants, so the steps a row missed can be replayed
-// later IN REGISTERS, in order, with the same arithmetic -- bit-identical to the dense sweep.  A row is brought up to
+// later IN REGISTERS, in order (m and v bit-identical to the dense sweep, p to ~1e-13 relative: adam_replay).  A row is brought up to
 // date when (a) the backward of this iteration scattered a gradient into it (`touched`), or (b) the next iteration's
 // neighbour lists name it (`need` == it + 1, stamped by k_map_ray_fused from the prefetched lists), or (c) `dense`:
 // the next lists are not known yet (end of a k-NN prefetch block) or the call ends.  upto[row] = number of this
@@ -399,10 +412,11 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     };
     for (int t = u; t < lz.it; ++t) {                   // replay of the steps without a gradient
       const float2 ab = consts(t);
-      adam_update(pp.x, 0.f, mm.x, vv.x, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.y, 0.f, mm.y, vv.y, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.z, 0.f, mm.z, vv.z, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.w, 0.f, mm.w, vv.w, ab.x, ab.y, b1, b2, eps);
+      const float isb = __builtin_amdgcn_rcpf(ab.y);
+      adam_replay(pp.x, mm.x, vv.x, ab.x, isb, b1, b2, eps);
+      adam_replay(pp.y, mm.y, vv.y, ab.x, isb, b1, b2, eps);
+      adam_replay(pp.z, mm.z, vv.z, ab.x, isb, b1, b2, eps);
+      adam_replay(pp.w, mm.w, vv.w, ab.x, isb, b1, b2, eps);
     }
     {
       float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);

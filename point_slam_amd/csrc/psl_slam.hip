@@ -260,13 +260,23 @@ __global__ void k_map_loss_finalize(const double* __restrict__ acc, int n_iters,
   loss_out[4 * it + 3] = (float)cnt;
 }
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, int step) {
+// bias corrections of Adam step `step`, in double like torch's Python scalars
+struct AdamBias { double bc1; float sqrt_bc2; };
+__device__ __forceinline__ AdamBias adam_bias(int step) {
+  AdamBias c;
+  c.bc1 = 1.0 - pow((double)0.9f, (double)step);
+  c.sqrt_bc2 = (float)sqrt(1.0 - pow((double)0.999f, (double)step));
+  return c;
+}
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, const AdamBias& c) {
   const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   m = m + (1.0f - b1) * (g - m);
   v = v * b2 + ((1.0f - b2) * g) * g;
-  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
-  float denom = sqrtf(v) / (float)sqrt(bc2) + eps;
-  p = p + ((-(float)((double)lr / bc1)) * m) / denom;
+  float denom = sqrtf(v) / c.sqrt_bc2 + eps;
+  p = p + ((-(float)((double)lr / c.bc1)) * m) / denom;
+}
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, int step) {
+  adam1(p, g, m, v, lr, adam_bias(step));
 }
 
 // one thread: quaternion chain of dL/dR, then Adam on the 7 pose parameters
@@ -293,10 +303,11 @@ __device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&
               G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
   float ds = -s * s;   // d s / d q_x = -s^2 q_x
   float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
+  const AdamBias bias = adam_bias(step);   // once, not per parameter: two double pow() on a single thread
 #pragma unroll
-  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, step);
+  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, bias);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, step);
+  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, bias);
 }
 
 // d(loss)/d(pose) from the per-ray gradients, analytic quaternion chain, Adam on (T: lr, quat: 0.2 lr)
