@@ -334,7 +334,9 @@ int psl_profile_enable(psl_ctx* ctx, int on);
  * 16 B x candidates / kernel time against the L2 bandwidth (its traffic is index-dependent).
  * Synchronises the device and resets the counter. */
 int64_t psl_knn_candidates(psl_ctx* ctx);
-/* run-time A/B switches for tests and profiling ("knn": 1 = one wavefront per sample, 2 = one per ray) */
+/* run-time A/B switches for tests and profiling: "knn" 0 = by launch size, 1 = one wavefront per sample, 2 = one per
+ * ray; "lazy_adam" 0 = dense Adam sweep over every selected feature row, 1 (default) = lazy replay (psl_map_iters);
+ * "track_fused" 0 = separate per-ray kernels in psl_track_iters, 1 (default) = fused for batches <= 1024 rays */
 int psl_debug_option(const char* name, int value);
 int psl_profile_classes(void);
 const char* psl_profile_name(int i);

@@ -169,6 +169,7 @@ struct psl_ctx {
   unsigned char* touched = nullptr; size_t touched_cap = 0;
   unsigned char *touched_geo = nullptr, *touched_col = nullptr;   // non-null only inside psl_map_iters
   int *adam_upto = nullptr, *adam_need = nullptr;                 // views into `touched` (lazy Adam bookkeeping)
+  int *adam_list = nullptr, *adam_count = nullptr; long long adam_list_cap = 0;   // work list [cap] and its per-iteration lengths
   float4* adam_tab = nullptr; size_t adam_tab_cap = 0;            // per-iteration (lr/bc1, sqrt(bc2)) of the two row groups
   unsigned long long* adam_rows = nullptr;                        // feature rows stepped by the lazy Adam since the last profile read
   unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read
@@ -241,17 +242,18 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
              int n_rays, int* I_out, int* cnt_out, hipStream_t s);
 struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2;
                      unsigned char* touched;   // [n_rows] set by the backward scatter when a row received a gradient
-                     int* upto;                // [n_rows] iterations of this call already applied to the row (-1: m = v = 0)
-                     int tab_off; };           // 0: (x,y) of the step table belong to this group, 2: (z,w)
+                     int* upto; };             // [n_rows] iterations of this call already applied to the row (-1: m = v = 0)
 // Lazy, exact Adam of the mapper's feature rows (see k_map_adam): per-iteration constants of the whole call
 constexpr int kAdamTabLds = 72;   // >= the k-NN prefetch block (64 iterations) + 1
 constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache lines
-struct AdamLazy { const float4* tab; const int* need; int it; int dense; unsigned long long* rows_done; int base; };
+struct AdamLazy { const float4* tab; const int* list; const int* count; long long list_cap; int it;
+                  unsigned long long* rows_done; int base; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
                     const int* wf_index; float* wf; const int* wb_index; float* wb; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, 0, 1, nullptr, 0});
-int launch_mark_need(const int* next_I, long long n_entries, const int* row_map, int* need, int stamp, hipStream_t s);
+                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, nullptr, 0, 0, nullptr, 0});
+int launch_adam_worklist(const int* I_a, const int* I_b, long long n_entries, const int* row_map, int* stamp_arr, int stamp,
+                         int* list, int* count, hipStream_t s);
 void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2);
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,

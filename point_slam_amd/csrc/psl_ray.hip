@@ -354,111 +354,144 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
 // feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the
 // forward-layout copy of each weight it steps (wt_index: master element -> element of the [Kpad][N] copy, -1 for
 // biases / B matrices), which replaces the separate re-pack launch before the next forward.
-//
-// Feature rows, lazy and exact (lz.tab != null).  torch.optim.Adam steps every selected row in every iteration, also the
-// ones without a gradient (m decays, p keeps moving): ~200 000 rows x 2 groups x 7 accesses of 128 B per iteration,
-// 50 us of pure HBM time, although an iteration reads and writes only the ~25 000 rows next to its samples.  A row's
-// update depends on nothing but its own (p, g, m, v) and the step's constants, so the steps a row missed can be replayed
-// later IN REGISTERS, in order (m and v bit-identical to the dense sweep, p to ~1e-13 relative: adam_replay).  A row is brought up to
-// date when (a) the backward of this iteration scattered a gradient into it (`touched`), or (b) the next iteration's
-// neighbour lists name it (`need` == it + 1, stamped by k_map_ray_fused from the prefetched lists), or (c) `dense`:
-// the next lists are not known yet (end of a k-NN prefetch block) or the call ends.  upto[row] = number of this
-// call's iterations already applied; -1 = never had a gradient, m = v = 0 and every missed step is exactly +0.
+__device__ __forceinline__ void adam_par_segment(const AdamParSeg& par, int i, float b1, float b2, float eps) {
+  if (i >= par.n) return;
+  float pp = par.p[i], mm = par.m[i], vv = par.v[i];
+  adam_update(pp, par.g[i], mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
+  par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
+  const int w = par.wt_index[i];
+  if (w >= 0) par.wt[w] = pp;
+  const int wf = par.wf_index[i], wb = par.wb_index[i];
+  if (wf >= 0) par.wf[wf] = pp;
+  if (wb >= 0) par.wb[wb] = pp;
+}
+
+// dense sweep: every selected row that ever had a gradient, one step (A/B baseline of the lazy kernel below)
 __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_geo, int nb_col,
-                                                  float b1, float b2, float eps, AdamLazy lz) {
+                                                  float b1, float b2, float eps) {
   int blk = blockIdx.x;
   if (blk < nb_geo + nb_col) {
     const AdamRowsSeg& sg = (blk < nb_geo) ? geo : col;
     if (blk >= nb_geo) blk -= nb_geo;
     const long long i = (long long)blk * blockDim.x + threadIdx.x;
-    const bool inside = i < (long long)sg.n_rows * (C / 4);
-    if (!lz.tab && !inside) return;
-    const int row = inside ? (int)(i >> 3) : 0, q = (int)(i & 7);
-    if (!lz.tab) {                                      // dense single step (round-1 kernels, psl_adam_step_rows semantics)
-      const int dst = sg.rows ? sg.rows[row] : row;
-      float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
-      float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];
-      adam_update(pp.x, gg.x, mm.x, vv.x, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-      adam_update(pp.y, gg.y, mm.y, vv.y, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-      adam_update(pp.z, gg.z, mm.z, vv.z, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-      adam_update(pp.w, gg.w, mm.w, vv.w, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
-      *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
-      sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      return;
-    }
-    const bool has_g = inside && sg.touched[row] != 0;
-    int u = sg.upto[row];
-    const bool work = has_g || (inside && u >= 0 && u <= lz.it && (lz.dense || lz.need[row] == lz.it + 1));
-    if (!__syncthreads_or(work ? 1 : 0)) return;
-    // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
-    // made each step a full memory round trip)
-    __shared__ float2 stab[kAdamTabLds];
-    const int nt = lz.it - lz.base + 1;
-    for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
-      const float4 v = lz.tab[lz.base + t];
-      stab[t] = sg.tab_off ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-    }
-    __syncthreads();
-    if (!work) return;
-    if (u < 0) u = lz.it;                               // first gradient of this row: the missed steps were +0
-    const int dst = sg.rows[row];
+    if (i >= (long long)sg.n_rows * (C / 4)) return;
+    const int row = (int)(i >> 3), q = (int)(i & 7);
+    if (sg.touched && !sg.touched[row]) return;         // never had a gradient: g = m = v = 0, the update is exactly zero
+    const int dst = sg.rows ? sg.rows[row] : row;
     float4* pp4 = reinterpret_cast<float4*>(sg.feats + (size_t)dst * C) + q;
-    float4 pp = *pp4, mm = sg.m[i], vv = sg.v[i];
-    auto consts = [&](int t) -> float2 {
-      const int k = t - lz.base;
-      if (k >= 0 && k < kAdamTabLds) return stab[k];
-      const float4 v = lz.tab[t];
-      return sg.tab_off ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-    };
-    for (int t = u; t < lz.it; ++t) {                   // replay of the steps without a gradient
-      const float2 ab = consts(t);
-      const float isb = __builtin_amdgcn_rcpf(ab.y);
-      adam_replay(pp.x, mm.x, vv.x, ab.x, isb, b1, b2, eps);
-      adam_replay(pp.y, mm.y, vv.y, ab.x, isb, b1, b2, eps);
-      adam_replay(pp.z, mm.z, vv.z, ab.x, isb, b1, b2, eps);
-      adam_replay(pp.w, mm.w, vv.w, ab.x, isb, b1, b2, eps);
-    }
-    {
-      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_g) { gg = sg.g[i]; sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-      const float2 ab = consts(lz.it);
-      adam_update(pp.x, gg.x, mm.x, vv.x, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.y, gg.y, mm.y, vv.y, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.z, gg.z, mm.z, vv.z, ab.x, ab.y, b1, b2, eps);
-      adam_update(pp.w, gg.w, mm.w, vv.w, ab.x, ab.y, b1, b2, eps);
-    }
+    float4 pp = *pp4, gg = sg.g[i], mm = sg.m[i], vv = sg.v[i];
+    adam_update(pp.x, gg.x, mm.x, vv.x, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.y, gg.y, mm.y, vv.y, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.z, gg.z, mm.z, vv.z, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
+    adam_update(pp.w, gg.w, mm.w, vv.w, sg.lr_bc1, sg.sqrt_bc2, b1, b2, eps);
     *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
-    // the 8 lanes of a row sit in one wavefront and have all read touched/upto above (same instruction)
-    if (q == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; }
-    if (lz.rows_done) {                                 // one atomic per wavefront, spread over 256 cache lines
-      const unsigned long long act = __ballot(q == 0);
-      if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
-        atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), (unsigned long long)__popcll(act));
-    }
+    sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    const int i = (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x;
-    if (i >= par.n) return;
-    float pp = par.p[i], mm = par.m[i], vv = par.v[i];
-    adam_update(pp, par.g[i], mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
-    par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
-    const int w = par.wt_index[i];
-    if (w >= 0) par.wt[w] = pp;
-    const int wf = par.wf_index[i], wb = par.wb_index[i];
-    if (wf >= 0) par.wf[wf] = pp;
-    if (wb >= 0) par.wb[wb] = pp;
+    adam_par_segment(par, (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x, b1, b2, eps);
   }
 }
 
-// stamps the rows the NEXT iteration's neighbour lists name (AdamLazy::need)
-__global__ __launch_bounds__(256) void k_mark_need(const int4* __restrict__ next_I, int n4, const int* __restrict__ row_map,
-                                                   int* __restrict__ need, int stamp) {
+// Feature rows, lazily.  torch.optim.Adam steps every selected row in every iteration, also the ones without a gradient
+// (m decays, p keeps moving): ~10^5 rows x 2 groups x 7 accesses of 128 B per iteration, 30-50 us of pure HBM time,
+// although an iteration reads and writes only the ~2x10^4 rows next to its samples.  A row's update depends on nothing
+// but its own (p, g, m, v) and the step's constants, so the steps a row missed are replayed later IN REGISTERS, in order
+// (m and v bit-identical to the dense sweep, p to ~1e-13 relative: adam_replay).  A row is brought up to date when
+//  (a) this iteration's neighbour lists name it (it may have received a gradient: `touched`), or
+//  (b) the next iteration's lists name it (the forward will read it) -- both sets come from the prefetched lists as a
+//      de-duplicated work list (k_adam_worklist), or
+//  (c) dense pass (list == null): the next lists are not known yet (end of a k-NN prefetch block) or the call ends.
+// upto[row] = number of this call's iterations already applied; -1 = never had a gradient (m = v = 0, every missed
+// step is exactly +0).  32 lanes per row, one channel each: the replay is a serial chain per channel and the slowest
+// row of a launch sets its duration.
+__global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_rows, int n_groups,
+                                                       float b1, float b2, float eps, AdamLazy lz) {
+  int blk = blockIdx.x;
+  if (blk >= nb_rows * n_groups) { adam_par_segment(par, (blk - nb_rows * n_groups) * blockDim.x + threadIdx.x, b1, b2, eps); return; }
+  const bool is_col = blk >= nb_rows;
+  if (is_col) blk -= nb_rows;
+  const AdamRowsSeg& sg = is_col ? col : geo;
+  const int n_work = lz.list ? *lz.count : sg.n_rows;
+  if ((long long)blk * 8 >= n_work) return;             // the whole workgroup lies beyond the work list
+  const int e = threadIdx.x & 31;
+  const long long ridx = (long long)blk * 8 + (threadIdx.x >> 5);
+  int row = -1;
+  if (ridx < n_work) row = lz.list ? lz.list[ridx] : (int)ridx;
+  bool has_g = false, work = false;
+  int u = -1;
+  if (row >= 0) {
+    has_g = sg.touched[row] != 0;
+    u = sg.upto[row];
+    work = has_g || (u >= 0 && u <= lz.it);
+  }
+  if (!__syncthreads_or(work ? 1 : 0)) return;
+  // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
+  // made each step a full memory round trip)
+  __shared__ float2 stab[kAdamTabLds];
+  const int nt = lz.it - lz.base + 1;
+  for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
+    const float4 v = lz.tab[lz.base + t];
+    stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+  }
+  __syncthreads();
+  if (!work) return;
+  if (u < 0) u = lz.it;                                 // first gradient of this row: the missed steps were +0
+  auto consts = [&](int t) -> float2 {
+    const int k = t - lz.base;
+    if (k >= 0 && k < kAdamTabLds) return stab[k];
+    const float4 v = lz.tab[t];
+    return is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+  };
+  float* pptr = sg.feats + (size_t)sg.rows[row] * C + e;
+  const size_t k = (size_t)row * C + e;
+  float* gp = reinterpret_cast<float*>(sg.g) + k;
+  float* mp = reinterpret_cast<float*>(sg.m) + k;
+  float* vp = reinterpret_cast<float*>(sg.v) + k;
+  float pp = *pptr, mm = *mp, vv = *vp;
+  float gg = 0.f;
+  if (has_g) { gg = *gp; *gp = 0.f; }
+  for (int t = u; t < lz.it; ++t) {                     // replay of the steps without a gradient
+    const float2 ab = consts(t);
+    adam_replay(pp, mm, vv, ab.x, __builtin_amdgcn_rcpf(ab.y), b1, b2, eps);
+  }
+  const float2 ab = consts(lz.it);
+  adam_update(pp, gg, mm, vv, ab.x, ab.y, b1, b2, eps);
+  *pptr = pp; *mp = mm; *vp = vv;
+  // the 32 lanes of a row sit in one wavefront and have all read touched/upto above
+  if (e == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; }
+  if (lz.rows_done) {                                   // one atomic per wavefront, spread over 256 cache lines
+    const unsigned long long act = __ballot(e == 0);
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
+      atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), (unsigned long long)__popcll(act));
+  }
+}
+
+// Work list of a lazy Adam step: the distinct selected rows named by the neighbour lists of this iteration (I_a) and of
+// the next one (I_b, may be null).  `stamp_arr[row] == stamp` marks rows already listed (stamps grow with the
+// iteration, the array is cleared once per call); appends are aggregated per wavefront.
+__global__ __launch_bounds__(256) void k_adam_worklist(const int4* __restrict__ I_a, const int4* __restrict__ I_b, int n4,
+                                                       const int* __restrict__ row_map, int* __restrict__ stamp_arr,
+                                                       int stamp, int* __restrict__ list, int* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const int4 v = next_I[i];
-  const int e[4] = {v.x, v.y, v.z, v.w};
+  const int lane = threadIdx.x & 63;
+  int4 v = make_int4(-1, -1, -1, -1);
+  if (i < n4) v = I_a[i];
+  else if (I_b && i < 2 * n4) v = I_b[i - n4];
+  const int ent[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    if (e[j] >= 0) { const int r = row_map[e[j]]; if (r >= 0) need[r] = stamp; }
+  for (int c = 0; c < 4; ++c) {
+    int r = -1;
+    if (ent[c] >= 0) r = row_map[ent[c]];
+    bool fresh = false;
+    if (r >= 0) fresh = atomicExch(&stamp_arr[r], stamp) != stamp;
+    const unsigned long long mask = __ballot(fresh);
+    if (mask) {
+      const int leader = __builtin_ctzll(mask);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(count, __popcll(mask));
+      base = __shfl(base, leader);
+      if (fresh) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = r;
+    }
+  }
 }
 
 }  // namespace psl
@@ -485,20 +518,32 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
+  const int nb_par = (par.n + 255) / 256;
+  if (lazy.tab) {
+    // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
+    const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, geo.n_rows) : geo.n_rows;
+    const int nb_rows = (int)((rows + 7) / 8), n_groups = col.n_rows > 0 ? 2 : 1;
+    if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
+    hipLaunchKernelGGL(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
+                       0.9f, 0.999f, 1e-8f, lazy);
+    PSL_LAUNCH_CHECK();
+    return PSL_OK;
+  }
   const int nb_geo = (int)(((long long)geo.n_rows * (C / 4) + 255) / 256);
   const int nb_col = (int)(((long long)col.n_rows * (C / 4) + 255) / 256);
-  const int nb_par = (par.n + 255) / 256;
   if (nb_geo + nb_col + nb_par == 0) return PSL_OK;
-  geo.tab_off = 0; col.tab_off = 2;
   hipLaunchKernelGGL(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
-                     0.999f, 1e-8f, lazy);
+                     0.999f, 1e-8f);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
-int launch_mark_need(const int* next_I, long long n_entries, const int* row_map, int* need, int stamp, hipStream_t s) {
+int launch_adam_worklist(const int* I_a, const int* I_b, long long n_entries, const int* row_map, int* stamp_arr, int stamp,
+                         int* list, int* count, hipStream_t s) {
   const int n4 = (int)(n_entries / 4);
   if (n4 <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_mark_need, dim3((n4 + 255) / 256), dim3(256), 0, s, (const int4*)next_I, n4, row_map, need, stamp);
+  const int tot = I_b ? 2 * n4 : n4;
+  hipLaunchKernelGGL(k_adam_worklist, dim3((tot + 255) / 256), dim3(256), 0, s, (const int4*)I_a, (const int4*)I_b, n4, row_map,
+                     stamp_arr, stamp, list, count);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

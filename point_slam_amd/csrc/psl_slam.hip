@@ -721,6 +721,13 @@ __global__ __launch_bounds__(256) void k_flag_compact(const int* __restrict__ fl
 
 using namespace psl;
 
+// A/B switches (psl_debug_option "lazy_adam" / "track_fused", or the environment at load time)
+namespace psl {
+static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
+int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
+}  // namespace psl
+
 // ---------------------------------------------------------------------------------------------- C ABI
 static RayBufs carve_rays(float*& p, int n) {
   RayBufs b;
@@ -786,7 +793,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     ra.flags |= PSL_HAS_AFFINE; ra.exposure_affine = ex_aff; rg.g_exposure_affine = ex_g;
   }
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
-  const bool fused = n <= 1024 && ctx->decode_bwd_version >= 2 && ctx->decode_version >= 2;
+  const bool fused = n <= 1024 && ctx->decode_bwd_version >= 2 && ctx->decode_version >= 2 && g_track_fused != 0;
   struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
@@ -894,21 +901,25 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   }
   struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
                                                c->touched_geo = c->touched_col = nullptr;
-                                               c->adam_upto = c->adam_need = nullptr; } } pre_guard{ctx};
+                                               c->adam_upto = c->adam_need = c->adam_list = c->adam_count = nullptr; } } pre_guard{ctx};
   ctx->fused_ray = true;
   std::vector<float4> tab_host;
   if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {
-    // lazy exact Adam of the feature rows (k_map_adam): upto_geo | upto_col | need | touched_geo | touched_col
-    const size_t ns = (size_t)m->n_sel, need = 3 * ns * sizeof(int) + 2 * ns;
+    // lazy Adam of the feature rows (k_map_adam_lazy): upto_geo | upto_col | stamp | count[n_iters] | list | touched_geo |
+    // touched_col
+    const size_t ns = (size_t)m->n_sel, lcap = std::min<size_t>(2 * (size_t)n * S * K, ns);
+    const size_t n_int = 3 * ns + (size_t)m->n_iters + lcap, need = n_int * sizeof(int) + 2 * ns;
     if (ctx->touched_cap < need) {
       if (ctx->touched) (void)hipFree(ctx->touched);
       ctx->touched = nullptr; ctx->touched_cap = 0;
       PSL_HIP(hipMalloc(&ctx->touched, need + need / 4)); ctx->touched_cap = need + need / 4;
     }
     PSL_HIP(hipMemsetAsync(ctx->touched, 0xFF, 2 * ns * sizeof(int), s));
-    PSL_HIP(hipMemsetAsync(ctx->touched + 2 * ns * sizeof(int), 0, ns * sizeof(int) + 2 * ns, s));
+    PSL_HIP(hipMemsetAsync(ctx->touched + 2 * ns * sizeof(int), 0, (ns + (size_t)m->n_iters) * sizeof(int), s));
     ctx->adam_upto = (int*)ctx->touched; ctx->adam_need = ctx->adam_upto + 2 * ns;
-    ctx->touched_geo = ctx->touched + 3 * ns * sizeof(int); ctx->touched_col = ctx->touched_geo + ns;
+    ctx->adam_count = ctx->adam_need + ns; ctx->adam_list = ctx->adam_count + m->n_iters; ctx->adam_list_cap = (long long)lcap;
+    ctx->touched_geo = ctx->touched + n_int * sizeof(int); ctx->touched_col = ctx->touched_geo + ns;
+    PSL_HIP(hipMemsetAsync(ctx->touched_geo, 0, 2 * ns, s));
     if (ctx->adam_tab_cap < (size_t)m->n_iters) {
       if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
       ctx->adam_tab = nullptr; ctx->adam_tab_cap = 0;
@@ -997,7 +1008,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
     // lazy Adam: rows the next iteration reads must be up to date; its lists exist unless a prefetch block ends here
-    const bool lazy = ctx->adam_upto != nullptr;
+    const bool lazy = ctx->adam_upto != nullptr && g_lazy_adam != 0;
     const bool dense = !lazy || it + 1 == m->n_iters || (it + 1) % kblock == 0;
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
     // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
@@ -1007,8 +1018,9 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // (lazy path: the rows actually stepped are counted on the device and added by psl_profile_read)
     ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
                                              ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
-    if (lazy && !dense) {
-      rc = launch_mark_need(ctx->pre_I + (size_t)n * S * K, (long long)n * S * K, m->row_map, ctx->adam_need, it + 1, s);
+    if (lazy && !dense) {   // distinct rows of this iteration's and the next iteration's neighbour lists
+      rc = launch_adam_worklist(ctx->pre_I, ctx->pre_I + (size_t)n * S * K, (long long)n * S * K, m->row_map, ctx->adam_need,
+                                it + 1, ctx->adam_list, ctx->adam_count + it, s);
       if (rc) return rc;
     }
     {
@@ -1029,7 +1041,8 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
           sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
         }
       }
-      AdamLazy lz{lazy ? ctx->adam_tab : nullptr, ctx->adam_need, it, dense ? 1 : 0, ctx->adam_rows, it - it % kblock};
+      AdamLazy lz{lazy ? ctx->adam_tab : nullptr, (lazy && !dense) ? ctx->adam_list : nullptr,
+                  lazy ? ctx->adam_count + it : nullptr, ctx->adam_list_cap, it, ctx->adam_rows, it - it % kblock};
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
                            st + m->step0_params, lz);
       if (rc) return rc;

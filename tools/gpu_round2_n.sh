@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 2, run N: A/B on one box -- lazy Adam and tracker fusion on/off
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+show() { python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1], d['value'], d['ms_per_step'], d.get('split'))
+PY
+}
+for rep in 1 2; do
+PSL_LAZY_ADAM=1 PSL_TRACK_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1f1_$rep.json 2>/dev/null; show gpurun_out/n_l1f1_$rep.json
+PSL_LAZY_ADAM=0 PSL_TRACK_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0f1_$rep.json 2>/dev/null; show gpurun_out/n_l0f1_$rep.json
+PSL_LAZY_ADAM=1 PSL_TRACK_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1f0_$rep.json 2>/dev/null; show gpurun_out/n_l1f0_$rep.json
+PSL_LAZY_ADAM=0 PSL_TRACK_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0f0_$rep.json 2>/dev/null; show gpurun_out/n_l0f0_$rep.json
+done
