@@ -252,13 +252,14 @@ struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const i
                     const int* wf_index; float* wf; const int* wb_index; float* wb; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
                     float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, nullptr, 0, 0, nullptr, 0});
-int launch_adam_worklist(const int* I_a, const int* I_b, long long n_entries, const int* row_map, int* stamp_arr, int stamp,
-                         int* list, int* count, hipStream_t s);
 void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2);
+// work list of the lazy Adam, built by extra workgroups of k_map_ray_fused (see adam_worklist_role)
+struct AdamWorklist { const int* I_a; const int* I_b; int n4; const int* row_map; int* stamp_arr; int stamp; int* list; int* count; };
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
                          float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
-                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s);
+                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s,
+                         const AdamWorklist* wl = nullptr);
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);
 int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);

@@ -123,6 +123,37 @@ __global__ __launch_bounds__(256) void k_ray_grad(const float4* __restrict__ dp,
   if (g_d) { g_d[r * 3] = d0; g_d[r * 3 + 1] = d1; g_d[r * 3 + 2] = d2; }
 }
 
+// Work list of a lazy Adam step (k_map_adam_lazy): the distinct selected rows named by the neighbour lists of this
+// iteration (I_a) and of the next one (I_b, may be null).  `stamp_arr[row] == stamp` marks rows already listed (stamps
+// grow with the iteration, the array is cleared once per call); appends are aggregated per wavefront.  Runs as extra
+// workgroups of k_map_ray_fused: no launch of its own, and the four entries of a thread are in flight together.
+__device__ __forceinline__ void adam_worklist_role(const AdamWorklist& wl, int i) {
+  const int lane = threadIdx.x & 63;
+  int4 v = make_int4(-1, -1, -1, -1);
+  if (i < wl.n4) v = reinterpret_cast<const int4*>(wl.I_a)[i];
+  else if (wl.I_b && i < 2 * wl.n4) v = reinterpret_cast<const int4*>(wl.I_b)[i - wl.n4];
+  const int ent[4] = {v.x, v.y, v.z, v.w};
+  int r[4];
+  bool fresh[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r[c] = (ent[c] >= 0) ? wl.row_map[ent[c]] : -1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) fresh[c] = (r[c] >= 0) ? (atomicExch(&wl.stamp_arr[r[c]], wl.stamp) != wl.stamp) : false;
+  unsigned long long mask[4];
+  int tot = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { mask[c] = __ballot(fresh[c]); tot += __popcll(mask[c]); }
+  if (tot == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(wl.count, tot);
+  base = __shfl(base, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (fresh[c]) wl.list[base + __popcll(mask[c] & ((1ull << lane) - 1ull))] = r[c];
+    base += __popcll(mask[c]);
+  }
+}
+
 // Mapper iteration, everything between the two decode kernels in ONE launch: compositing (common.py:298-336), the
 // mapper loss with its mask (Mapper.py:524-553: L1 sums, so every ray's cotangent is local) and the compositing
 // backward.  Replaces k_composite_fwd + k_mapper_loss + k_composite_bwd (three ~6 us launches per iteration).
@@ -135,7 +166,9 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
                                                        float* __restrict__ rgb, unsigned char* __restrict__ valid,
                                                        float4* __restrict__ d_raw, double* __restrict__ loss_acc,
                                                        float* __restrict__ zero64, const float* __restrict__ frame_affine,
-                                                       int pix_per_frame, float* __restrict__ g_frame_affine) {
+                                                       int pix_per_frame, float* __restrict__ g_frame_affine, AdamWorklist wl,
+                                                       int nb_ray) {
+  if ((int)blockIdx.x >= nb_ray) { adam_worklist_role(wl, ((int)blockIdx.x - nb_ray) * (int)blockDim.x + (int)threadIdx.x); return; }
   // frame_affine != null (ScanNet, colour stage): the decoder returned raw colour logits; the affine of the ray's window
   // frame (slot r / pix_per_frame) and the sigmoid are applied to the COMPOSITED logits here (Mapper.py:530-548), and
   // d(loss)/d(affine) is accumulated per frame into g_frame_affine [F][12].
@@ -251,11 +284,16 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
 int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_depth, const float* gt_color, const int* active,
                          float near_s, float far_s, int min_nn, int n_rays, float coef, float w_color, int color_stage,
                          float* depth, float* var, float* rgb, unsigned char* valid, float4* d_raw, double* loss_acc,
-                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s) {
+                         float* zero64, const float* frame_affine, int pix_per_frame, float* g_frame_affine, hipStream_t s,
+                         const AdamWorklist* wl) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_map_ray_fused, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
+  AdamWorklist w{};
+  if (wl) w = *wl;
+  const int nb_ray = (n_rays + 255) / 256;
+  const int nb_wl = (w.I_a && w.n4 > 0) ? ((w.I_b ? 2 : 1) * w.n4 + 255) / 256 : 0;
+  hipLaunchKernelGGL(k_map_ray_fused, dim3(nb_ray + nb_wl), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
                      near_s, far_s, min_nn, n_rays, coef, w_color, color_stage, depth, var, rgb, valid, d_raw, loss_acc,
-                     zero64, frame_affine, pix_per_frame, g_frame_affine);
+                     zero64, frame_affine, pix_per_frame, g_frame_affine, w, nb_ray);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
@@ -465,35 +503,6 @@ __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRows
   }
 }
 
-// Work list of a lazy Adam step: the distinct selected rows named by the neighbour lists of this iteration (I_a) and of
-// the next one (I_b, may be null).  `stamp_arr[row] == stamp` marks rows already listed (stamps grow with the
-// iteration, the array is cleared once per call); appends are aggregated per wavefront.
-__global__ __launch_bounds__(256) void k_adam_worklist(const int4* __restrict__ I_a, const int4* __restrict__ I_b, int n4,
-                                                       const int* __restrict__ row_map, int* __restrict__ stamp_arr,
-                                                       int stamp, int* __restrict__ list, int* __restrict__ count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  int4 v = make_int4(-1, -1, -1, -1);
-  if (i < n4) v = I_a[i];
-  else if (I_b && i < 2 * n4) v = I_b[i - n4];
-  const int ent[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    int r = -1;
-    if (ent[c] >= 0) r = row_map[ent[c]];
-    bool fresh = false;
-    if (r >= 0) fresh = atomicExch(&stamp_arr[r], stamp) != stamp;
-    const unsigned long long mask = __ballot(fresh);
-    if (mask) {
-      const int leader = __builtin_ctzll(mask);
-      int base = 0;
-      if (lane == leader) base = atomicAdd(count, __popcll(mask));
-      base = __shfl(base, leader);
-      if (fresh) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = r;
-    }
-  }
-}
-
 }  // namespace psl
 
 using namespace psl;
@@ -534,16 +543,6 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   if (nb_geo + nb_col + nb_par == 0) return PSL_OK;
   hipLaunchKernelGGL(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
                      0.999f, 1e-8f);
-  PSL_LAUNCH_CHECK();
-  return PSL_OK;
-}
-int launch_adam_worklist(const int* I_a, const int* I_b, long long n_entries, const int* row_map, int* stamp_arr, int stamp,
-                         int* list, int* count, hipStream_t s) {
-  const int n4 = (int)(n_entries / 4);
-  if (n4 <= 0) return PSL_OK;
-  const int tot = I_b ? 2 * n4 : n4;
-  hipLaunchKernelGGL(k_adam_worklist, dim3((tot + 255) / 256), dim3(256), 0, s, (const int4*)I_a, (const int4*)I_b, n4, row_map,
-                     stamp_arr, stamp, list, count);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }

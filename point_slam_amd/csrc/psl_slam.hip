@@ -995,21 +995,25 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     const bool repack = it == 0;   // afterwards the fused Adam kernel keeps the forward-layout copy in step
     int rc = render_fwd_impl(ctx, &ra, s, repack);
     if (rc) return rc;
-    { // compositing + mapper loss + compositing backward in one launch
+    // lazy Adam: rows the next iteration reads must be up to date; its lists exist unless a prefetch block ends here
+    const bool lazy = ctx->adam_upto != nullptr && g_lazy_adam != 0;
+    const bool dense = !lazy || it + 1 == m->n_iters || (it + 1) % kblock == 0;
+    AdamWorklist wl{};
+    if (lazy && !dense)   // distinct rows of this iteration's and the next iteration's neighbour lists
+      wl = AdamWorklist{ctx->pre_I, ctx->pre_I + (size_t)n * S * K, n * S * K / 4, m->row_map, ctx->adam_need, it + 1,
+                        ctx->adam_list, ctx->adam_count + it};
+    { // compositing + mapper loss + compositing backward in one launch (+ the work list of this iteration's Adam)
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
       const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
       rc = launch_map_ray_fused((const float4*)rw.raw, ctx->pre_cnt, b.gd, b.gc, b.active, ctx->cfg.near_end_surface,
                                 ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, n, m->sigmoid_coef, m->w_color,
                                 color_stage ? 1 : 0, b.depth, b.var, b.rgb, b.valid, (float4*)rw.d_raw,
                                 ctx->loss_acc + 4 * (size_t)it, ctx->d_small, (ex && color_stage) ? ex_aff : nullptr,
-                                m->pix_per_frame, ex_g, s);
+                                m->pix_per_frame, ex_g, s, &wl);
       if (rc) return rc;
     }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
-    // lazy Adam: rows the next iteration reads must be up to date; its lists exist unless a prefetch block ends here
-    const bool lazy = ctx->adam_upto != nullptr && g_lazy_adam != 0;
-    const bool dense = !lazy || it + 1 == m->n_iters || (it + 1) % kblock == 0;
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
     // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
     const float lr_geo = color_stage ? m->lr_geo_color_stage : m->lr_geo_geo_stage;
@@ -1018,11 +1022,6 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // (lazy path: the rows actually stepped are counted on the device and added by psl_profile_read)
     ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
                                              ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
-    if (lazy && !dense) {   // distinct rows of this iteration's and the next iteration's neighbour lists
-      rc = launch_adam_worklist(ctx->pre_I, ctx->pre_I + (size_t)n * S * K, (long long)n * S * K, m->row_map, ctx->adam_need,
-                                it + 1, ctx->adam_list, ctx->adam_count + it, s);
-      if (rc) return rc;
-    }
     {
       AdamRowsSeg sg{}, sc{};
       AdamParSeg sp{};
