@@ -67,6 +67,9 @@ constexpr int poff(int i) {  // master offset (floats) of entry i
 }
 constexpr int kMasterFloats = poff(kNumParams);
 constexpr int kColorFloats = poff(kNumColorParams);
+// per-chunk partial dW slabs of the colour decoder (psl_dw.hip): master layout with every tensor start rounded up to 4
+struct DwReduceArgs { int chunks_of_entry[kNumColorParams]; int slab_off[kNumColorParams]; };
+constexpr int kDwSlabStride = kColorFloats + 4 * kNumColorParams;
 
 // indices into kParams
 constexpr int PI_C_FCC = 0;    // + 2*i (weight), +2*i+1 (bias)
@@ -170,6 +173,8 @@ struct psl_ctx {
   unsigned char *touched_geo = nullptr, *touched_col = nullptr;   // non-null only inside psl_map_iters
   int *adam_upto = nullptr, *adam_need = nullptr;                 // views into `touched` (lazy Adam bookkeeping)
   int *adam_list = nullptr, *adam_count = nullptr; long long adam_list_cap = 0;   // work list [cap] and its per-iteration lengths
+  bool dw_defer_reduce = false;   // psl_map_iters: launch_dw leaves the chunk reduction to the Adam launch (dw_ra)
+  psl::DwReduceArgs dw_ra{};
   float4* adam_tab = nullptr; size_t adam_tab_cap = 0;            // per-iteration (lr/bc1, sqrt(bc2)) of the two row groups
   unsigned long long* adam_rows = nullptr;                        // feature rows stepped by the lazy Adam since the last profile read
   unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read
@@ -249,7 +254,10 @@ constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache l
 struct AdamLazy { const float4* tab; const int* list; const int* count; long long list_cap; int it;
                   unsigned long long* rows_done; int base; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
-                    const int* wf_index; float* wf; const int* wb_index; float* wb; };
+                    const int* wf_index; float* wf; const int* wb_index; float* wb;
+                    // slabs != null: g is not read; the gradient of element e is the ordered sum of its chunk partials
+                    // (what k_dw_reduce would have written), taken inside the Adam launch
+                    const float* slabs; const float* g_brel; DwReduceArgs ra; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
                     float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, nullptr, 0, 0, nullptr, 0});
 void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2);

@@ -23,10 +23,9 @@ struct DwJob {
 constexpr int MAX_JOBS = 16;
 constexpr int MAX_CHUNKS = 256;
 struct DwArgs { DwJob job[MAX_JOBS]; int n_jobs; int n_items; float* slabs; };
-struct DwReduceArgs { int chunks_of_entry[kNumColorParams]; int slab_off[kNumColorParams]; };
 // slab layout = master layout with every tensor start rounded up to 4 floats, so that a lane's 4 consecutive k
 // (one float4) is 16-byte aligned in every layer (all row lengths are multiples of 4)
-constexpr int SLAB_STRIDE = kColorFloats + 4 * kNumColorParams;
+constexpr int SLAB_STRIDE = kDwSlabStride;
 static int slab_off_of(int pi) { int o = 0; for (int j = 0; j < pi; ++j) o += (kParams[j].rows * kParams[j].cols + 3) / 4 * 4; return o; }
 
 // One wavefront = one (16*AQ) x (16*BQ) output tile of one layer for one chunk of rows (AQ, BQ in {4, 2}: 64 or 32
@@ -274,6 +273,8 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   d.n_jobs = nj; d.n_items = base; d.slabs = ctx->dw_slabs;
   hipLaunchKernelGGL(k_dw, dim3((unsigned)((base + 3) / 4)), dim3(256), 0, s, d);
   PSL_LAUNCH_CHECK();
+  ctx->dw_ra = ra;
+  if (ctx->dw_defer_reduce) return PSL_OK;   // psl_map_iters: the Adam launch sums the chunk partials itself
   hipLaunchKernelGGL(k_dw_reduce, dim3((kMasterFloats + 31) / 32), dim3(256), 0, s, ctx->dw_slabs, ra, g_brel,
                      g_params);
   PSL_LAUNCH_CHECK();

@@ -252,11 +252,63 @@ __device__ __forceinline__ bool wave_box_empty(const GridMeta& m, const int* __r
 // r-sized neighbourhood holds several thousand candidates.
 // The (cz,cy) rows of the cube are x-runs of cells = contiguous ranges of `spos`; their [begin,end) pairs are
 // fetched 64 rows at a time, one row per lane, then walked with coalesced 16 B/lane candidate loads.
+// one pass of the expanding search for one wavefront: scans rows wsub*4 .. of every nsub*4 rows of the cube
+// [q - re, q + re] (nsub wavefronts share a query), inserting keys below best[K-1] into `best`
+__device__ __forceinline__ void knn_scan_rows(const GridMeta& m, const float4* __restrict__ spos,
+                                              const int* __restrict__ cell_start, float qx, float qy, float qz, float re,
+                                              u64 (&best)[K], int wsub, int nsub, unsigned long long& cand) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+  CellBox bx;
+  box_of(m, qx, qy, qz, re, bx);
+  const int ny_b = bx.hi[1] - bx.lo[1] + 1;
+  const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
+  // The rows of the cube ((cz, cy) pairs: x-runs of cells = contiguous ranges of `spos`) hold ~10..40 points each:
+  // they are walked FOUR AT A TIME, 16 lanes per row, and the [begin, end) pairs of the next four are requested
+  // before the current four are scanned -- a quarter of the serial memory round trips of a 64-lanes-per-row walk,
+  // and no idle lanes on short rows.
+  auto row_range = [&](int row, int& beg, int& end) {
+    beg = 0; end = 0;
+    if (row < nrows) {
+      const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+      const int rowbase = (cz * m.ny + cy) * m.nx;
+      beg = cell_start[rowbase + bx.lo[0]];
+      end = cell_start[rowbase + bx.hi[0] + 1];
+    }
+  };
+  const int step = 4 * nsub;
+  int beg, end, nbeg, nend;
+  row_range(4 * wsub + grp, beg, end);
+  for (int rb = 4 * wsub; rb < nrows; rb += step) {
+    row_range(rb + step + grp, nbeg, nend);
+    int j = beg + l16;
+    float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    while (__ballot(j < end)) {
+      const bool valid = j < end;
+      const int jn = j + 16;
+      const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row, in flight
+      cand += (unsigned long long)__popcll(__ballot(valid));
+      const unsigned idx = __float_as_uint(c.w);
+      const float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
+      const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
+      u64 mask = __ballot(valid && key < best[K - 1]);
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
+        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
+        topk_insert(best, ((u64)khi << 32) | klo);
+        mask &= mask - 1;
+        if (mask) mask &= __ballot(valid && key < best[K - 1]);
+      }
+      j = jn; c = cn;
+    }
+    beg = nbeg; end = nend;
+  }
+}
+
 __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
                                          const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
                                          float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr,
                                          const int* __restrict__ coarse = nullptr) {
-  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   float rho = m.cell;
   unsigned long long cand = 0;
   if (coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
@@ -273,50 +325,7 @@ __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __rest
     const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = sentinel;
-    CellBox bx;
-    box_of(m, qx, qy, qz, re, bx);
-    const int ny_b = bx.hi[1] - bx.lo[1] + 1;
-    const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
-    // The rows of the cube ((cz, cy) pairs: x-runs of cells = contiguous ranges of `spos`) hold ~10..40 points each:
-    // they are walked FOUR AT A TIME, 16 lanes per row, and the [begin, end) pairs of the next four are requested
-    // before the current four are scanned -- a quarter of the serial memory round trips of a 64-lanes-per-row walk,
-    // and no idle lanes on short rows.
-    auto row_range = [&](int row, int& beg, int& end) {
-      beg = 0; end = 0;
-      if (row < nrows) {
-        const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
-        const int rowbase = (cz * m.ny + cy) * m.nx;
-        beg = cell_start[rowbase + bx.lo[0]];
-        end = cell_start[rowbase + bx.hi[0] + 1];
-      }
-    };
-    int beg, end, nbeg, nend;
-    row_range(grp, beg, end);
-    for (int rb = 0; rb < nrows; rb += 4) {
-      row_range(rb + 4 + grp, nbeg, nend);
-      int j = beg + l16;
-      float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      while (__ballot(j < end)) {
-        const bool valid = j < end;
-        const int jn = j + 16;
-        const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row, in flight
-        cand += (unsigned long long)__popcll(__ballot(valid));
-        const unsigned idx = __float_as_uint(c.w);
-        const float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
-        const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
-        u64 mask = __ballot(valid && key < best[K - 1]);
-        while (mask) {
-          const int l = __builtin_ctzll(mask);
-          const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
-          const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
-          topk_insert(best, ((u64)khi << 32) | klo);
-          mask &= mask - 1;
-          if (mask) mask &= __ballot(valid && key < best[K - 1]);
-        }
-        j = jn; c = cn;
-      }
-      beg = nbeg; end = nend;
-    }
+    knn_scan_rows(m, spos, cell_start, qx, qy, qz, re, best, 0, 1, cand);
     if (last || best[K - 1] != sentinel) break;
     rho *= 2.0f;
   }
@@ -366,6 +375,69 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
+}
+
+// ray mode for SMALL launches (the tracker: 200 rays = 1000 queries, one wavefront each would leave every SIMD with a
+// single wavefront that waits out ~30 dependent memory round trips): FOUR wavefronts per sample share the rows of every
+// pass, merge their four top-8 lists through LDS and decide together whether the search radius must grow.  Same keys,
+// same order, same answer as k_knn_rays.
+__global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                     const int* __restrict__ cell_start,
+                                                     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                                     const float* __restrict__ r_query,
+                                                     float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
+                                                     int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                                     unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
+  __shared__ u64 sbest[4][K];
+  const int p = blockIdx.x;
+  if (p >= n_rays * S) return;
+  const int ray = p / S, si = p - ray * S;
+  const int lane = threadIdx.x & 63, wsub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const GridMeta m = *meta;
+  const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
+  float r, r2;
+  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  float qx, qy, qz;
+  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+               rays_d[ray * 3 + 2], zq, qx, qy, qz);
+  if (wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {      // same answer in all four wavefronts
+    if (wsub == 0) { if (lane < K) I_out[p * K + lane] = -1; if (lane == 0) cnt_out[p] = 0; }
+    return;
+  }
+  u64 best[K];
+  unsigned long long n_cand = 0;
+  float rho = m.cell;
+  for (;;) {
+    const bool last = rho >= r;
+    const float re = last ? r : rho;
+    const float t2 = last ? r2 : __fmul_rn(rho, rho);
+    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[j] = sentinel;
+    knn_scan_rows(m, spos, cell_start, qx, qy, qz, re, best, wsub, 4, n_cand);
+#pragma unroll
+    for (int j = 0; j < K; ++j) if (lane == j) sbest[wsub][j] = best[j];
+    __syncthreads();
+    // every wavefront merges the other three lists into its own: the four rows sets are disjoint, so are the keys
+    for (int o = 1; o < 4; ++o) {
+      const int w2 = (wsub + o) & 3;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const u64 kk = sbest[w2][j];
+        if (kk < best[K - 1]) topk_insert(best, kk);
+      }
+    }
+    __syncthreads();
+    if (last || best[K - 1] != sentinel) break;
+    rho *= 2.0f;
+  }
+  if (lane == 0 && cand_counter) atomicAdd(cand_counter, n_cand);
+  if (wsub != 0) return;
+  unsigned ib, db; int cnt;
+  knn_emit(best, r2, lane, ib, db, cnt);
+  if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
+  if (lane == 0) cnt_out[p] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -609,10 +681,18 @@ static inline float r2_of(float r) { return (float)((double)r * (double)r); }   
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }
-  // 0 = by launch size: small batches (the tracker's 200..5000 rays) are latency-bound and want five wavefronts per ray;
-  // the mapper's block prefetch (10^4..10^5 rays per launch) is throughput-bound and wants the shared candidate scan
-  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : 1);
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
+  // 0 = by launch size: small batches (the tracker's 200 rays) are latency-bound and get FOUR wavefronts per sample (3);
+  // from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the launch is
+  // throughput-bound and wants the shared candidate scan of one wavefront per ray (2).  1 = one wavefront per sample.
+  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : 3);
+  if (ver == 3) {
+    hipLaunchKernelGGL(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
+    PSL_LAUNCH_CHECK();
+    return PSL_OK;
+  }
   if (ver >= 2) {
     hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -392,16 +392,49 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
 // feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the
 // forward-layout copy of each weight it steps (wt_index: master element -> element of the [Kpad][N] copy, -1 for
 // biases / B matrices), which replaces the separate re-pack launch before the next forward.
-__device__ __forceinline__ void adam_par_segment(const AdamParSeg& par, int i, float b1, float b2, float eps) {
-  if (i >= par.n) return;
+__device__ __forceinline__ void adam_par_apply(const AdamParSeg& par, int i, float g, float b1, float b2, float eps) {
   float pp = par.p[i], mm = par.m[i], vv = par.v[i];
-  adam_update(pp, par.g[i], mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
+  adam_update(pp, g, mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
   par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
   const int w = par.wt_index[i];
   if (w >= 0) par.wt[w] = pp;
   const int wf = par.wf_index[i], wb = par.wb_index[i];
   if (wf >= 0) par.wf[wf] = pp;
   if (wb >= 0) par.wb[wb] = pp;
+}
+// workgroup `blk` of the parameter segment.  par.slabs == null: 256 parameters, gradient read from par.g.  Otherwise
+// 32 parameters x 8 chunk lanes: the chunk partials of the dW kernel are summed here in k_dw_reduce's fixed order
+// (lane c takes chunks c, c+8, ...; the 8 sums are added in order) -- one launch and one pass over g_params less.
+__device__ __forceinline__ void adam_par_segment(const AdamParSeg& par, int blk, float b1, float b2, float eps) {
+  if (!par.slabs) {
+    const int i = blk * 256 + (int)threadIdx.x;
+    if (i < par.n) adam_par_apply(par, i, par.g[i], b1, b2, eps);
+    return;
+  }
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int e = blk * 32 + el;
+  float v = 0.f;
+  if (e < par.n) {
+    constexpr int b0 = poff(PI_C_BREL);
+    if (e >= b0 && e < b0 + 3 * ERF) { if (cl == 0) v = par.g_brel[e - b0]; }
+    else {
+      int ent = 0;
+#pragma unroll
+      for (int j = 1; j < kNumColorParams; ++j) if (e >= poff(j)) ent = j;
+      const int n_chunks = par.ra.chunks_of_entry[ent];
+      const int se = par.ra.slab_off[ent] + (e - poff(ent));
+      for (int c = cl; c < n_chunks; c += 8) v += par.slabs[(size_t)c * kDwSlabStride + se];
+    }
+  }
+  part[cl][el] = v;
+  __syncthreads();
+  if (cl == 0 && e < par.n) {
+    float t = part[0][el];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) t += part[c][el];
+    adam_par_apply(par, e, t, b1, b2, eps);
+  }
 }
 
 // dense sweep: every selected row that ever had a gradient, one step (A/B baseline of the lazy kernel below)
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
     *pp4 = pp; sg.m[i] = mm; sg.v[i] = vv;
     sg.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
-    adam_par_segment(par, (blk - nb_geo - nb_col) * blockDim.x + threadIdx.x, b1, b2, eps);
+    adam_par_segment(par, blk - nb_geo - nb_col, b1, b2, eps);
   }
 }
 
@@ -444,7 +477,7 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
 __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_rows, int n_groups,
                                                        float b1, float b2, float eps, AdamLazy lz) {
   int blk = blockIdx.x;
-  if (blk >= nb_rows * n_groups) { adam_par_segment(par, (blk - nb_rows * n_groups) * blockDim.x + threadIdx.x, b1, b2, eps); return; }
+  if (blk >= nb_rows * n_groups) { adam_par_segment(par, blk - nb_rows * n_groups, b1, b2, eps); return; }
   const bool is_col = blk >= nb_rows;
   if (is_col) blk -= nb_rows;
   const AdamRowsSeg& sg = is_col ? col : geo;
@@ -527,7 +560,7 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
-  const int nb_par = (par.n + 255) / 256;
+  const int nb_par = par.n <= 0 ? 0 : (par.slabs ? (par.n + 31) / 32 : (par.n + 255) / 256);
   if (lazy.tab) {
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
     const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, geo.n_rows) : geo.n_rows;

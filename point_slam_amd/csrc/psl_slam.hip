@@ -726,6 +726,7 @@ namespace psl {
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
 int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
+int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -901,8 +902,10 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   }
   struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
                                                c->touched_geo = c->touched_col = nullptr;
-                                               c->adam_upto = c->adam_need = c->adam_list = c->adam_count = nullptr; } } pre_guard{ctx};
+                                               c->adam_upto = c->adam_need = c->adam_list = c->adam_count = nullptr;
+                                               c->dw_defer_reduce = false; } } pre_guard{ctx};
   ctx->fused_ray = true;
+  ctx->dw_defer_reduce = g_dw_fused != 0;   // the chunk partials of the dW kernel are summed inside the Adam launch
   std::vector<float4> tab_host;
   if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {
     // lazy Adam of the feature rows (k_map_adam_lazy): upto_geo | upto_col | stamp | count[n_iters] | list | touched_geo |
@@ -1038,6 +1041,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
           sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
           sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
           sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
+          if (ctx->dw_defer_reduce) { sp.slabs = ctx->dw_slabs; sp.g_brel = ctx->d_small; sp.ra = ctx->dw_ra; }
         }
       }
       AdamLazy lz{lazy ? ctx->adam_tab : nullptr, (lazy && !dense) ? ctx->adam_list : nullptr,

@@ -127,21 +127,27 @@ def test_ray_knn_sparse_cloud_matches_oracle(dev):
                              params=theta.data_ptr(), col_embed_B=Bcol.data_ptr(), fallback_geo=fb[0].data_ptr(),
                              fallback_col=fb[1].data_ptr(), exposure_affine=None, ws=ws.data_ptr(), depth=depth.data_ptr(),
                              var=var.data_ptr(), rgb=rgb.data_ptr(), valid_ray=valid.data_ptr())
-    _lib.check(L.psl_render_fwd(npc.handle, C.byref(a), _lib.stream_ptr()))
-    torch.cuda.synchronize()
     P = 5 * R
     Ppad = (P + 15) // 16 * 16
-    I = ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long()
-    cnt = ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu()
     q = O.sample_points(ro, rd, O.z_samples(gd, 0.98, 1.02, 5))
     rq = cfg["pointcloud"]["radius_query"]
     Do, Io = O.knn_exact(cloud, q, 8)
     Io_m = torch.where(Do <= rq * rq, Io, torch.full_like(Io, -1))
     cnt_o = O.neighbor_count(Do, rq)
-    report(test="ray_knn_sparse", empty_frac=float((cnt_o == 0).float().mean()), full_frac=float((cnt_o == 8).float().mean()),
-           mismatched=int((I != Io_m).any(1).sum()))
     assert 0.02 < float((cnt_o == 0).float().mean()) and float((cnt_o == 8).float().mean()) < 0.9
-    assert torch.equal(I, Io_m) and torch.equal(cnt, cnt_o)
+    try:
+        for ver in (0, 1, 2, 3):    # by launch size / one wavefront per sample / one per ray / four per sample
+            _lib.check(L.psl_debug_option(b"knn", ver))
+            ws.zero_()
+            _lib.check(L.psl_render_fwd(npc.handle, C.byref(a), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            I = ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long()
+            cnt = ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu()
+            report(test="ray_knn_sparse", kernel=ver, empty_frac=float((cnt_o == 0).float().mean()),
+                   full_frac=float((cnt_o == 8).float().mean()), mismatched=int((I != Io_m).any(1).sum()))
+            assert torch.equal(I, Io_m) and torch.equal(cnt, cnt_o), f"k-NN kernel {ver}"
+    finally:
+        _lib.check(L.psl_debug_option(b"knn", 0))
 
 
 # ------------------------------------------------------------------------------ compositing
