@@ -23,6 +23,12 @@ void poison(void* p, size_t bytes) {
   if (v == 1 && p) { (void)hipMemset(p, 0x7F, bytes); (void)hipDeviceSynchronize(); }
 }
 
+void dbg_range(const char* name, const void* p, size_t bytes) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PSL_DEBUG_ADDRS"); v = (e && e[0] == '1') ? 1 : 0; }
+  if (v == 1) fprintf(stderr, "[psl addr] %-14s %p .. %p (%zu B)\n", name, p, (const void*)((const char*)p + bytes), bytes);
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -184,6 +190,14 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
+  dbg_range("pos", c->pos, sizeof(float4) * np); dbg_range("spos", c->spos, sizeof(float4) * np);
+  dbg_range("cell_of", c->cell_of, sizeof(int) * np); dbg_range("cell_start", c->cell_start, sizeof(int) * (kMaxCells + 1));
+  dbg_range("cell_fill", c->cell_fill, sizeof(int) * kMaxCells); dbg_range("coarse", c->coarse, sizeof(int) * kMaxCoarse);
+  dbg_range("scan_tmp", c->scan_tmp, sizeof(int) * 4096); dbg_range("wt", c->wt, sizeof(float) * kWtFloats);
+  dbg_range("wt_index", c->wt_index, sizeof(int) * kColorFloats); dbg_range("wf", c->wf, sizeof(float) * kFFloats);
+  dbg_range("wb", c->wb, sizeof(float) * kBFloats); dbg_range("wf_index", c->wf_index, sizeof(int) * kColorFloats);
+  dbg_range("wb_index", c->wb_index, sizeof(int) * kColorFloats); dbg_range("d_small", c->d_small, 256);
+  dbg_range("d_expo", c->d_expo, sizeof(float) * 64 * (12 + 128 + 12)); dbg_range("adam_rows", c->adam_rows, 8 * kAdamRowSlots);
   *out = c;
   return PSL_OK;
 }

@@ -224,6 +224,9 @@ bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every lau
     }                                                                                  \
   } while (0)
 
+// PSL_DEBUG_ADDRS=1: log (name, [begin, end)) of device buffers to stderr, to match a GPU memory-fault address
+void dbg_range(const char* name, const void* p, size_t bytes);
+
 struct ProfScope {  // brackets a kernel class with HIP events on the launch stream when profiling is on
   psl_ctx* c; int slot; hipStream_t s; int k;
   ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0) : c(c_), slot(slot_), s(s_), k(0) {

@@ -205,6 +205,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
     if (ctx->dw_slabs) PSL_HIP(hipFree(ctx->dw_slabs));
     PSL_HIP(hipMalloc(&ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS)); psl::poison(ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS);
     ctx->dw_slab_cap = MAX_CHUNKS;
+    dbg_range("dw_slabs", ctx->dw_slabs, sizeof(float) * (size_t)SLAB_STRIDE * MAX_CHUNKS);
   }
   static int chunk_rows = -1;    // > 0: fixed rows per chunk (debug); default: balanced sizing, see finish()
   if (chunk_rows < 0) { const char* e = getenv("PSL_DW_CHUNK"); chunk_rows = e ? atoi(e) : 0; if (chunk_rows < 16) chunk_rows = 0; }

@@ -59,12 +59,16 @@ __global__ void k_grid_meta(const int* b, int n, float min_cell, GridMeta* m) {
   float lo[3], hi[3];
   for (int a = 0; a < 3; ++a) { lo[a] = ord2f(b[a]); hi[a] = ord2f(b[3 + a]); }
   if (n == 0) { for (int a = 0; a < 3; ++a) { lo[a] = 0.f; hi[a] = 0.f; } }
+  // a non-finite extent (an inf position in the cloud) would never fit the cell budget below: collapse that axis, the
+  // offending points are clamped into its only cell by cell_coord
+  for (int a = 0; a < 3; ++a) if (!(fabsf(hi[a] - lo[a]) < 3.0e38f)) { lo[a] = 0.f; hi[a] = 0.f; }
   float cell = min_cell * 1.001f;  // margin: a point within r <= min_cell never lands two cells away
   int nx, ny, nz;
   for (;;) {
-    nx = (int)floorf((hi[0] - lo[0]) / cell) + 1;
-    ny = (int)floorf((hi[1] - lo[1]) / cell) + 1;
-    nz = (int)floorf((hi[2] - lo[2]) / cell) + 1;
+    // (extents clamped as floats: a NaN / inf position in the cloud must not reach the float->int conversion)
+    nx = (int)fminf(fmaxf(floorf((hi[0] - lo[0]) / cell), 0.f), 1.0e9f) + 1;
+    ny = (int)fminf(fmaxf(floorf((hi[1] - lo[1]) / cell), 0.f), 1.0e9f) + 1;
+    nz = (int)fminf(fmaxf(floorf((hi[2] - lo[2]) / cell), 0.f), 1.0e9f) + 1;
     if ((long long)nx * ny * nz <= (long long)kMaxCells) break;
     cell *= 1.26f;
   }
@@ -75,8 +79,9 @@ __global__ void k_grid_meta(const int* b, int n, float min_cell, GridMeta* m) {
 }
 
 __device__ __forceinline__ int cell_coord(float x, float o, float inv, int n) {
-  int c = (int)floorf((x - o) * inv);
-  return min(max(c, 0), n - 1);
+  // clamped as a float BEFORE the conversion: (int) of NaN / inf / |x| > 2^31 is undefined behaviour
+  const float f = fminf(fmaxf(floorf((x - o) * inv), 0.f), (float)(n - 1));   // fmaxf(NaN, 0) = 0
+  return (int)f;
 }
 
 __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pos, const GridMeta* __restrict__ m,
@@ -232,9 +237,9 @@ __device__ __forceinline__ bool wave_box_empty(const GridMeta& m, const int* __r
                                                float loz, float hix, float hiy, float hiz, float r) {
   const int lane = threadIdx.x & 63;
   const float rr = r * 1.0001f + 1e-6f;
-  const int x0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx) >> 2, x1 = cell_coord(hix + rr, m.ox, m.inv_cell, m.nx) >> 2;
-  const int y0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny) >> 2, y1 = cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny) >> 2;
-  const int z0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz) >> 2, z1 = cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz) >> 2;
+  const int x0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx) >> 2, x1 = max(x0, cell_coord(hix + rr, m.ox, m.inv_cell, m.nx) >> 2);
+  const int y0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny) >> 2, y1 = max(y0, cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny) >> 2);
+  const int z0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz) >> 2, z1 = max(z0, cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz) >> 2);
   const int nxb = x1 - x0 + 1, nyb = y1 - y0 + 1, nb = nxb * nyb * (z1 - z0 + 1);
   int any = 0;
   for (int e = lane; e < nb; e += 64) {
@@ -500,10 +505,12 @@ __global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ 
 #pragma unroll
     for (int s = 0; s < S; ++s) thr[s] = ((done_mask >> s) & 1u) ? 0ull : sentinel;     // a final list admits nothing
     // union of the five cubes [q_s - re, q_s + re]: a superset of every sample's own cube
+    // (a NaN coordinate -- fminf/fmaxf skip it -- would leave lo = +3e38 > hi = -3e38, an inverted box with NEGATIVE
+    //  extents whose "rows" index cell_start far outside the grid: the upper corner is clamped to the lower one)
     const float rr = re * 1.0001f + 1e-6f;
-    const int bx0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx), bx1 = cell_coord(hix + rr, m.ox, m.inv_cell, m.nx);
-    const int by0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny), by1 = cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny);
-    const int bz0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz), bz1 = cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz);
+    const int bx0 = cell_coord(lox - rr, m.ox, m.inv_cell, m.nx), bx1 = max(bx0, cell_coord(hix + rr, m.ox, m.inv_cell, m.nx));
+    const int by0 = cell_coord(loy - rr, m.oy, m.inv_cell, m.ny), by1 = max(by0, cell_coord(hiy + rr, m.oy, m.inv_cell, m.ny));
+    const int bz0 = cell_coord(loz - rr, m.oz, m.inv_cell, m.nz), bz1 = max(bz0, cell_coord(hiz + rr, m.oz, m.inv_cell, m.nz));
     const int ny_b = by1 - by0 + 1;
     const int nrows = (bz1 - bz0 + 1) * ny_b;
     // [begin, end) of the first four rows

@@ -641,9 +641,13 @@ __global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict_
   for (int dv = 0; dv < 2; ++dv)
 #pragma unroll
     for (int du = 0; du < 2; ++du) {
-      int uu = (int)u0 + du, vv = (int)v0 + dv;
-      bool ok = uu >= 0 && uu < cam.W && vv >= 0 && vv < cam.H;
-      float val = ok ? depth[(size_t)vv * cam.W + uu] : 0.f;
+      // The bounds test is made on the FLOATS: a point in the camera plane (z ~ 0) projects to +-1e30 or NaN, for which
+      // (int)u0 is undefined behaviour -- the compiler folded the saturated INT_MAX + 1 into a 64-bit index and the
+      // "out of image" lookup became a wild load (one run in ~20 of bench.py, whenever a map point met z ~ 0).
+      const float uf = u0 + (float)du, vf = v0 + (float)dv;
+      const bool ok = uf >= 0.f && uf < (float)cam.W && vf >= 0.f && vf < (float)cam.H;   // false for NaN
+      float val = 0.f;
+      if (ok) val = depth[(size_t)(int)vf * cam.W + (int)uf];
       d += val * (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
     }
   if (d == 0.f) d = depth_max;
@@ -767,6 +771,14 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   if ((rws - t->ws) + psl_render_ws_floats(n, PSL_STAGE_COLOR | PSL_PTS_GRAD) > psl_track_ws_floats(n)) {
     set_error("psl_track_iters: internal workspace layout exceeds psl_track_ws_floats"); return PSL_ERR_STATE;
   }
+  dbg_range("trk.ws", t->ws, sizeof(float) * (size_t)psl_track_ws_floats(n));
+  dbg_range("trk.pix_idx", t->pix_idx, sizeof(int) * (size_t)t->n_iters * n);
+  dbg_range("trk.fallback", t->fallback, sizeof(float) * (size_t)t->n_iters * 64);
+  dbg_range("trk.cam", t->cam_tensor, 28); dbg_range("trk.adam", t->adam_state, 56); dbg_range("trk.best", t->best_out, 32);
+  dbg_range("trk.depth", t->frame.depth, sizeof(float) * (size_t)t->cam.H * t->cam.W);
+  dbg_range("trk.color", t->frame.color, sizeof(float) * 3 * (size_t)t->cam.H * t->cam.W);
+  if (t->frame.r_query) dbg_range("trk.r_query", t->frame.r_query, sizeof(float) * (size_t)t->cam.H * t->cam.W);
+  if (t->loss_out) dbg_range("trk.loss_out", t->loss_out, sizeof(float) * 4 * (size_t)t->n_iters);
   FrameDev fh;
   memset(&fh, 0, sizeof(fh));
   fh.depth = t->frame.depth; fh.color = t->frame.color; fh.r_query = t->frame.r_query;
@@ -916,6 +928,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       if (ctx->touched) (void)hipFree(ctx->touched);
       ctx->touched = nullptr; ctx->touched_cap = 0;
       PSL_HIP(hipMalloc(&ctx->touched, need + need / 4)); ctx->touched_cap = need + need / 4;
+      dbg_range("touched", ctx->touched, ctx->touched_cap);
     }
     PSL_HIP(hipMemsetAsync(ctx->touched, 0xFF, 2 * ns * sizeof(int), s));
     PSL_HIP(hipMemsetAsync(ctx->touched + 2 * ns * sizeof(int), 0, (ns + (size_t)m->n_iters) * sizeof(int), s));
@@ -927,6 +940,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       if (ctx->adam_tab) (void)hipFree(ctx->adam_tab);
       ctx->adam_tab = nullptr; ctx->adam_tab_cap = 0;
       PSL_HIP(hipMalloc(&ctx->adam_tab, sizeof(float4) * ((size_t)m->n_iters + 64))); ctx->adam_tab_cap = (size_t)m->n_iters + 64;
+      dbg_range("adam_tab", ctx->adam_tab, sizeof(float4) * ctx->adam_tab_cap);
     }
     tab_host.resize(m->n_iters);
     for (int it = 0; it < m->n_iters; ++it) {   // the constants launch_map_adam would compute for iteration `it`
@@ -942,8 +956,28 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
     PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters)); psl::poison(ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
     ctx->loss_acc_cap = m->n_iters;
+    dbg_range("loss_acc", ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
   }
   PSL_HIP(hipMemsetAsync(ctx->loss_acc, 0, sizeof(double) * 4 * (size_t)m->n_iters, s));
+  dbg_range("map.ws", m->ws, sizeof(float) * (size_t)psl_map_ws_floats(n, m->n_frames));
+  dbg_range("map.pix_idx", m->pix_idx, sizeof(int) * (size_t)m->n_iters * n);
+  dbg_range("map.fallback", m->fallback, sizeof(float) * (size_t)m->n_iters * 64);
+  dbg_range("map.sel_rows", m->sel_rows, sizeof(int) * (size_t)m->n_sel);
+  dbg_range("map.row_map", m->row_map, sizeof(int) * (size_t)ctx->n_points);
+  dbg_range("map.g_geo", m->g_geo, sizeof(float) * (size_t)m->n_sel * C);
+  dbg_range("map.g_col", m->g_col, sizeof(float) * (size_t)m->n_sel * C);
+  dbg_range("map.adam_geo", m->adam_geo, sizeof(float) * 2 * (size_t)m->n_sel * C);
+  dbg_range("map.adam_col", m->adam_col, sizeof(float) * 2 * (size_t)m->n_sel * C);
+  dbg_range("map.adam_par", m->adam_params, sizeof(float) * 2 * (size_t)kColorFloats);
+  dbg_range("map.geo_feats", m->geo_feats, sizeof(float) * (size_t)ctx->n_points * C);
+  dbg_range("map.col_feats", m->col_feats, sizeof(float) * (size_t)ctx->n_points * C);
+  dbg_range("map.params", m->params, sizeof(float) * (size_t)kMasterFloats);
+  if (m->loss_out) dbg_range("map.loss_out", m->loss_out, sizeof(float) * 4 * (size_t)m->n_iters);
+  for (int f = 0; f < m->n_frames; ++f) {
+    dbg_range("map.depth", m->frames[f].depth, sizeof(float) * (size_t)m->cam.H * m->cam.W);
+    dbg_range("map.color", m->frames[f].color, sizeof(float) * 3 * (size_t)m->cam.H * m->cam.W);
+    if (m->frames[f].r_query) dbg_range("map.r_query", m->frames[f].r_query, sizeof(float) * (size_t)m->cam.H * m->cam.W);
+  }
   {
     std::vector<FrameDev> fh(m->n_frames);
     for (int f = 0; f < m->n_frames; ++f) {

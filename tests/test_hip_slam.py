@@ -136,6 +136,43 @@ def test_frustum_select_matches_oracle():
     assert torch.equal(got, torch.sort(got).values)
 
 
+def test_frustum_select_points_in_the_camera_plane():
+    """Points whose camera-space z is ~0 project to +-inf / NaN pixel coordinates (Mapper.py:150-153 divides by
+    z + 1e-5).  The reference drops them (cv2.remap outside the image -> 0, mask false); a float->int conversion of such
+    a coordinate was undefined behaviour in k_frustum_flags and faulted one bench run in ~20.  Also non-finite
+    positions in the cloud: the grid build and the selection must survive them."""
+    from oracle import pointslam_oracle as O
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    fr = frames[1]
+    c2w = fr.c2w.cpu().double()
+    g = torch.Generator().manual_seed(3)
+    # camera-frame points with z + 1e-5 == 0 (exactly and to within a few ulp) and |x|,|y| of every size, to world
+    n_bad = 4096
+    xy = (torch.rand(n_bad, 2, generator=g, dtype=torch.float64) - 0.5) * torch.logspace(-6, 3, n_bad, dtype=torch.float64)[:, None]
+    zc = torch.full((n_bad, 1), -1e-5, dtype=torch.float64) + (torch.randint(-3, 4, (n_bad, 1), generator=g).double() * 1e-12)
+    pc = torch.cat([xy, zc], 1)
+    bad = (pc @ c2w[:3, :3].T + c2w[:3, 3]).float()
+    weird = torch.tensor([[float("inf"), 0.0, 0.0], [float("nan"), 1.0, 1.0], [0.0, -float("inf"), 2.0], [1e30, 1e30, -1e30]])
+    cloud = torch.cat([pts.cpu(), bad, weird], 0)
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(cloud.to(dev))
+    for _ in range(3):
+        sel, row_map = s.frustum_select(fr, fr.c2w)
+    torch.cuda.synchronize()
+    got = sel.cpu().long()
+    n0 = pts.shape[0]
+    ref = O.frustum_select(pts, fr.c2w.cpu(), fr.depth.cpu(), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
+                           cam["cy"], cfg["mapping"]["frustum_edge"])
+    a, b = set(got[got < n0].tolist()), set(ref.tolist())
+    report(test="frustum_degenerate", n_sel=int(got.shape[0]), extra_selected=int((got >= n0).sum()), sym_diff=len(a ^ b))
+    assert len(a ^ b) <= max(3, len(b) // 2000)
+    assert int((got >= n0 + n_bad).sum()) == 0          # non-finite positions are never inside the frustum
+    # the map stays usable: a render-sized k-NN query over it answers as before
+    D, I, cnt = s.npc.find_neighbors_faiss(pts[:512].to(dev), step="query")
+    assert int((cnt > 0).sum()) > 0 and bool(torch.isfinite(D[cnt > 0][:, 0]).all())
+
+
 def test_map_native_matches_dropin():
     dev = torch.device("cuda:0")
     cfg, cam, frames, pts = _scene(dev)

@@ -10,8 +10,8 @@ PY
 }
 rm -f gpurun_out/n_err.log
 for rep in 1 2; do
-PSL_LAZY_ADAM=1 PSL_TRACK_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1f1_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l1f1_$rep.json
-PSL_LAZY_ADAM=0 PSL_TRACK_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0f1_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l0f1_$rep.json
-PSL_LAZY_ADAM=1 PSL_TRACK_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1f0_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l1f0_$rep.json
-PSL_LAZY_ADAM=0 PSL_TRACK_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0f0_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l0f0_$rep.json
+PSL_LAZY_ADAM=1 PSL_DW_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1d1_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l1d1_$rep.json
+PSL_LAZY_ADAM=0 PSL_DW_FUSED=1 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0d1_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l0d1_$rep.json
+PSL_LAZY_ADAM=1 PSL_DW_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l1d0_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l1d0_$rep.json
+PSL_LAZY_ADAM=0 PSL_DW_FUSED=0 timeout 600 python bench.py --no-cpu-baseline > gpurun_out/n_l0d0_$rep.json 2>>gpurun_out/n_err.log; show gpurun_out/n_l0d0_$rep.json
 done
