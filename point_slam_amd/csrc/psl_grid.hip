@@ -689,10 +689,14 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
   if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
-  // 0 = by launch size: small batches (the tracker's 200 rays) are latency-bound and get FOUR wavefronts per sample (3);
-  // from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the launch is
-  // throughput-bound and wants the shared candidate scan of one wavefront per ray (2).  1 = one wavefront per sample.
-  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : 3);
+  // 0 = by launch size: from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the
+  // shared candidate scan of one wavefront per ray (2); below that one wavefront per sample (1).  3 = four wavefronts
+  // per sample sharing the rows of every pass: measured EQUAL to (1) on the tracker's 200-ray launches (68 us both,
+  // profiles/r02_knn_small_ab.txt) -- those launches are not bound by the serial row walk of a wavefront -- so it
+  // stays an option (PSL_KNN_SMALL=3), covered by the exactness tests.
+  static int small_ver = -1;
+  if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] == '3') ? 3 : 1; }
+  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : small_ver);
   if (ver == 3) {
     hipLaunchKernelGGL(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -1,16 +1,11 @@
 #!/bin/bash
-# round 2, run R: which k-NN kernel does the rare memory fault follow?
+# round 2, run R: does the bench still fault?  (async, as the driver runs it; 1 in ~20 runs faulted before the fix)
 cd "$GRAFT_REPO_ROOT" || exit 1
-N=${1:-30}
-count() { # dir, label, env...
-  dir=$1; label=$2; shift; shift
-  bad=0
-  for rep in $(seq 1 $N); do
-    (cd $dir && env "$@" timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing > /tmp/r.json 2> /tmp/r_err.log)
-    rc=$?
-    if [ $rc -ne 0 ]; then bad=$((bad+1)); grep -h "Memory access fault\|Error\|error" /tmp/r_err.log | head -2; fi
-  done
-  echo "$label: $bad / $N failed"
-}
-count . knn1_everywhere PSL_KNN=1
-count . knn2_everywhere PSL_KNN=2
+N=${1:-40}
+bad=0
+for rep in $(seq 1 $N); do
+  timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing > /tmp/r.json 2> /tmp/r_err.log
+  rc=$?
+  if [ $rc -ne 0 ]; then bad=$((bad+1)); grep -h "Memory access fault\|Error\|error" /tmp/r_err.log | head -2; fi
+done
+echo "bench runs failed: $bad / $N"
