@@ -211,6 +211,10 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
   (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2);
+    (void)hipEventDestroy(c->ev_knn_ready[0]); (void)hipEventDestroy(c->ev_knn_ready[1]); (void)hipEventDestroy(c->ev_knn_free);
+  }
   if (c->scan_flags) (void)hipFree(c->scan_flags);
   if (c->ev) { for (size_t i = 0; i < (size_t)PROF_N * PROF_RING * 2; ++i) (void)hipEventDestroy(c->ev[i]); delete[] c->ev; }
   delete c;
@@ -293,13 +297,15 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused; }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap; }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
   if (!strcmp(name, "knn")) { psl::g_knn_version = value; return PSL_OK; }
   if (!strcmp(name, "lazy_adam")) { psl::g_lazy_adam = value; return PSL_OK; }
   if (!strcmp(name, "track_fused")) { psl::g_track_fused = value; return PSL_OK; }
+  if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }
+  if (!strcmp(name, "knn_overlap")) { psl::g_knn_overlap = value; return PSL_OK; }
   set_error("psl_debug_option: unknown option %s", name);
   return PSL_ERR_ARG;
 }

@@ -173,6 +173,8 @@ struct psl_ctx {
   unsigned char *touched_geo = nullptr, *touched_col = nullptr;   // non-null only inside psl_map_iters
   int *adam_upto = nullptr, *adam_need = nullptr;                 // views into `touched` (lazy Adam bookkeeping)
   int *adam_list = nullptr, *adam_count = nullptr; long long adam_list_cap = 0;   // work list [cap] and its per-iteration lengths
+  hipStream_t stream2 = nullptr;                 // low-priority stream of the mapper's k-NN block prefetch
+  hipEvent_t ev_knn_ready[2] = {nullptr, nullptr}, ev_knn_free = nullptr;
   bool dw_defer_reduce = false;   // psl_map_iters: launch_dw leaves the chunk reduction to the Adam launch (dw_ra)
   psl::DwReduceArgs dw_ra{};
   float4* adam_tab = nullptr; size_t adam_tab_cap = 0;            // per-iteration (lr/bc1, sqrt(bc2)) of the two row groups

@@ -731,6 +731,7 @@ static int env_flag(const char* name, int dflt) { const char* e = getenv(name); 
 int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
 int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
+int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -867,7 +868,8 @@ static int64_t map_prefetch_floats(int n_rays) {
 
 extern "C" int64_t psl_map_ws_floats(int n_rays, int n_frames) {
   if (n_rays < 0 || n_frames < 0) return PSL_ERR_ARG;
-  return map_prefetch_floats(n_rays) + rays_floats(map_knn_block(n_rays) * n_rays) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
+  // two prefetch sets (rays + neighbour lists): block b+1 is looked up on a second stream while block b iterates
+  return 2 * (map_prefetch_floats(n_rays) + rays_floats(map_knn_block(n_rays) * n_rays) + 16) + psl_render_ws_floats(n_rays, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) + 64 +
          (int64_t)((sizeof(FrameDev) * (size_t)std::max(n_frames, 1) + 3) / 4) + 32 + psl_param_master_floats();
 }
 
@@ -888,12 +890,14 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   // the depth-outlier mask and the 8-NN lookups of `kblock` iterations are done by three launches per block
   // instead of three per iteration; iteration `it` then works on slice it % kblock of these buffers.
   const int kblock = map_knn_block(n);
-  RayBufs pb = carve_rays(p, kblock * n);
+  RayBufs pbs[2];
+  pbs[0] = carve_rays(p, kblock * n);
+  pbs[1] = carve_rays(p, kblock * n);
   bool any_rq = false;
   for (int f = 0; f < m->n_frames; ++f) any_rq |= m->frames[f].r_query != nullptr;
-  if (!any_rq) pb.rq = nullptr;
-  auto slice = [&](int j) {
-    RayBufs b = pb;
+  if (!any_rq) { pbs[0].rq = nullptr; pbs[1].rq = nullptr; }
+  auto slice = [&](int set, int j) {
+    RayBufs b = pbs[set];
     const size_t o = (size_t)j * n;
     b.rays_o += 3 * o; b.rays_d += 3 * o; b.dirs += 3 * o; b.gd += o; b.gc += 3 * o; if (b.rq) b.rq += o;
     b.active += o; b.depth += o; b.var += o; b.rgb += 3 * o; b.valid += o; b.g_depth += o; b.g_rgb += 3 * o;
@@ -903,16 +907,21 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   p += 64;
   FrameDev* fdev = (FrameDev*)p; p += (sizeof(FrameDev) * m->n_frames + 3) / 4 + 4;
   float* g_params = p; p += (psl_param_master_floats() + 3) / 4 * 4;
-  p = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);   // neighbour lists are read as 16-byte vectors
-  int* pre_I = (int*)p; p += (size_t)kblock * n * S * K;
-  int* pre_cnt = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
+  int *pre_Is[2], *pre_cnts[2];
+  for (int q = 0; q < 2; ++q) {
+    p = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);   // neighbour lists are read as 16-byte vectors
+    pre_Is[q] = (int*)p; p += (size_t)kblock * n * S * K;
+    pre_cnts[q] = (int*)p; p += ((size_t)kblock * n * S + 3) / 4 * 4;
+  }
   float* rws = (float*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   // the carve above must stay inside what psl_map_ws_floats() promises the caller
   if ((rws - m->ws) + psl_render_ws_floats(n, PSL_STAGE_COLOR | PSL_FEAT_GRAD | PSL_PARAM_GRAD) >
       psl_map_ws_floats(n, m->n_frames)) {
     set_error("psl_map_iters: internal workspace layout exceeds psl_map_ws_floats"); return PSL_ERR_STATE;
   }
-  struct PreGuard { psl_ctx* c; ~PreGuard() { c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
+  struct PreGuard { psl_ctx* c; bool ok = false;
+                    ~PreGuard() { if (!ok && c->stream2) (void)hipStreamSynchronize(c->stream2);   // error path: no prefetch left behind
+                                  c->pre_I = nullptr; c->pre_cnt = nullptr; c->fused_ray = false;
                                                c->touched_geo = c->touched_col = nullptr;
                                                c->adam_upto = c->adam_need = c->adam_list = c->adam_count = nullptr;
                                                c->dw_defer_reduce = false; } } pre_guard{ctx};
@@ -1004,24 +1013,49 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     hipLaunchKernelGGL(k_exposure_fwd, dim3(m->n_frames), dim3(128), 0, s, ex->mlp, ex->feats, ex_aff, ex_act);
     PSL_LAUNCH_CHECK();
   }
+  // k-NN prefetch of block b+1 on a second, low-priority stream while block b iterates (the lookups depend on nothing
+  // the iterations change): ~0.9 ms per 64 iterations leave the critical path.  PSL_KNN_OVERLAP=0 switches it off.
+  const bool overlap = g_knn_overlap != 0 && m->n_iters > kblock;
+  if (overlap && !ctx->stream2) {
+    int least = 0, greatest = 0;
+    PSL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    PSL_HIP(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, least));
+    PSL_HIP(hipEventCreateWithFlags(&ctx->ev_knn_ready[0], hipEventDisableTiming));
+    PSL_HIP(hipEventCreateWithFlags(&ctx->ev_knn_ready[1], hipEventDisableTiming));
+    PSL_HIP(hipEventCreateWithFlags(&ctx->ev_knn_free, hipEventDisableTiming));
+  }
+  auto prefetch = [&](int it0, int set, hipStream_t st) -> int {
+    const int nb = std::min(kblock, m->n_iters - it0);
+    { ProfScope ps(ctx, PROF_MISC, st);
+      hipLaunchKernelGGL(k_ray_setup, dim3((nb * n + 255) / 256), dim3(256), 0, st, m->cam, 0, m->cam.H, 0, m->cam.W,
+                         fdev, m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it0 * n, (const float*)nullptr, pbs[set],
+                         nb);
+      hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, st, pbs[set].gd, pbs[set].active, n);
+      PSL_LAUNCH_CHECK(); }
+    ProfScope ps(ctx, PROF_KNN, st, 108.0 * nb * n * S);
+    return knn_rays(ctx, pbs[set].rays_o, pbs[set].rays_d, pbs[set].gd, nullptr, pbs[set].rq, nb * n, pre_Is[set],
+                    pre_cnts[set], st);
+  };
   for (int it = 0; it < m->n_iters; ++it) {
     // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
     const bool color_stage = it > m->n_geo_iters;
     if (it % kblock == 0) {
-      const int nb = std::min(kblock, m->n_iters - it);
-      { ProfScope ps(ctx, PROF_MISC, s);
-        hipLaunchKernelGGL(k_ray_setup, dim3((nb * n + 255) / 256), dim3(256), 0, s, m->cam, 0, m->cam.H, 0, m->cam.W,
-                           fdev, m->n_frames, m->pix_per_frame, m->pix_idx + (size_t)it * n, (const float*)nullptr, pb,
-                           nb);
-        hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, s, pb.gd, pb.active, n);
-        PSL_LAUNCH_CHECK(); }
-      ProfScope ps(ctx, PROF_KNN, s, 108.0 * nb * n * S);
-      int rc = knn_rays(ctx, pb.rays_o, pb.rays_d, pb.gd, nullptr, pb.rq, nb * n, pre_I, pre_cnt, s);
-      if (rc) return rc;
+      const int set = (it / kblock) & 1;
+      if (it == 0 || !overlap) { int rc = prefetch(it, set, s); if (rc) return rc; }
+      else PSL_HIP(hipStreamWaitEvent(s, ctx->ev_knn_ready[set], 0));       // looked up while the previous block iterated
+      // the block after this one: on the second stream, into the other set, once the iterations that read it are over
+      if (overlap && it + kblock < m->n_iters) {
+        PSL_HIP(hipEventRecord(ctx->ev_knn_free, s));                       // everything enqueued so far used set^1 last
+        PSL_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_knn_free, 0));
+        int rc = prefetch(it + kblock, set ^ 1, ctx->stream2);
+        if (rc) return rc;
+        PSL_HIP(hipEventRecord(ctx->ev_knn_ready[set ^ 1], ctx->stream2));
+      }
     }
-    ctx->pre_I = pre_I + (size_t)(it % kblock) * n * S * K;
-    ctx->pre_cnt = pre_cnt + (size_t)(it % kblock) * n * S;
-    const RayBufs b = slice(it % kblock);
+    const int cur = (it / kblock) & 1;
+    ctx->pre_I = pre_Is[cur] + (size_t)(it % kblock) * n * S * K;
+    ctx->pre_cnt = pre_cnts[cur] + (size_t)(it % kblock) * n * S;
+    const RayBufs b = slice(cur, it % kblock);
     ra.rays_o = b.rays_o; ra.rays_d = b.rays_d; ra.gt_depth = b.gd; ra.r_query = b.rq;
     ra.depth = b.depth; ra.var = b.var; ra.rgb = b.rgb; ra.valid_ray = b.valid;
     ra.flags = PSL_FEAT_GRAD | (color_stage ? (PSL_STAGE_COLOR | (m->train_decoder ? PSL_PARAM_GRAD : 0)) : 0);
@@ -1096,6 +1130,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
                        m->n_geo_iters, m->w_color, m->loss_out);
     PSL_LAUNCH_CHECK();
   }
+  pre_guard.ok = true;
   return PSL_OK;
 }
 
