@@ -249,7 +249,7 @@ struct ProfScope {  // brackets a kernel class with HIP events on the launch str
 // ---- internal launchers (defined in the .hip files) -------------------------
 int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
-             int n_rays, int* I_out, int* cnt_out, hipStream_t s);
+             int n_rays, int* I_out, int* cnt_out, hipStream_t s, int max_blocks = 0);
 struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_rows; float lr_bc1, sqrt_bc2;
                      unsigned char* touched;   // [n_rows] set by the backward scatter when a row received a gradient
                      int* upto; };             // [n_rows] iterations of this call already applied to the row (-1: m = v = 0)

@@ -459,18 +459,15 @@ __device__ __forceinline__ unsigned dpp_shr1(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
 }
 
-__global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
-                                                   const int* __restrict__ cell_start,
-                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                   const float* __restrict__ depth, const float* __restrict__ z_vals,
-                                                   const float* __restrict__ r_query,
-                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
-                                                   int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                   unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
-  const int ray = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (ray >= n_rays) return;
+__device__ __forceinline__ void knn_ray2_one(int ray, const GridMeta& m, const float4* __restrict__ spos,
+                                             const int* __restrict__ cell_start,
+                                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                             const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                             const float* __restrict__ r_query,
+                                             float r_fixed, float r2_fixed, float near_s, float far_s,
+                                             int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                             unsigned long long& cand_total, const int* __restrict__ coarse) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
-  const GridMeta m = *meta;
   float r, r2;
   if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
   float qx[S], qy[S], qz[S];
@@ -610,7 +607,28 @@ __global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ 
     const u64 inr = __ballot(lane < S * K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2));
     if (lane < S) cnt_out[ray * S + lane] = __popcll((inr >> (8 * lane)) & 0xFFull);
   }
-  if (cand_counter && lane == 0) atomicAdd(cand_counter, n_cand);
+  cand_total += n_cand;
+}
+
+// One wavefront per ray; with fewer wavefronts than rays (the mapper's block prefetch on the side stream is launched
+// THROTTLED: two workgroups per CU, so that the decode kernels of the main stream keep finding free slots) every
+// wavefront walks rays wave, wave + #waves, ...
+__global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                   const int* __restrict__ cell_start,
+                                                   const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                   const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                                   const float* __restrict__ r_query,
+                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
+                                                   int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                                   unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
+  const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+  const GridMeta m = *meta;
+  unsigned long long cand = 0;
+  for (int ray = wave0; ray < n_rays; ray += n_waves)
+    knn_ray2_one(ray, m, spos, cell_start, rays_o, rays_d, depth, z_vals, r_query, r_fixed, r2_fixed, near_s, far_s, I_out,
+                 cnt_out, cand, coarse);
+  if (cand_counter && (threadIdx.x & 63) == 0 && cand) atomicAdd(cand_counter, cand);
 }
 
 // sample_near_pcl marching test (src/neural_point.py:232-249): one wave per (ray, step); a step "hits" when at least
@@ -686,7 +704,7 @@ int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by lau
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
-             const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s) {
+             const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s, int max_blocks) {
   if (n_rays <= 0) return PSL_OK;
   if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
   // 0 = by launch size: from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the
@@ -705,7 +723,9 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     return PSL_OK;
   }
   if (ver >= 2) {
-    hipLaunchKernelGGL(k_knn_rays2, dim3((n_rays + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+    int blocks = (n_rays + 3) / 4;
+    if (max_blocks > 0) blocks = std::min(blocks, max_blocks);      // throttled: every wavefront walks several rays
+    hipLaunchKernelGGL(k_knn_rays2, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
     PSL_LAUNCH_CHECK();

@@ -732,6 +732,7 @@ int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
 int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
+int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -1033,8 +1034,11 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, st, pbs[set].gd, pbs[set].active, n);
       PSL_LAUNCH_CHECK(); }
     ProfScope ps(ctx, PROF_KNN, st, 108.0 * nb * n * S);
+    // on the side stream the lookup is THROTTLED (g_knn_side_blocks workgroups, ~2 per CU): left alone its 10^4
+    // workgroups fill every CU and the decode kernels of the main stream wait for slots (one of them measured at
+    // 845 us instead of 52); it has a whole block of iterations (~8 ms) to finish
     return knn_rays(ctx, pbs[set].rays_o, pbs[set].rays_d, pbs[set].gd, nullptr, pbs[set].rq, nb * n, pre_Is[set],
-                    pre_cnts[set], st);
+                    pre_cnts[set], st, st == s ? 0 : g_knn_side_blocks);
   };
   for (int it = 0; it < m->n_iters; ++it) {
     // stage switch (Mapper.py:420-423): joint_iter <= n_geo_iters -> geometry
