@@ -225,24 +225,16 @@ def test_map_native_matches_dropin():
     assert torch.equal(n[0][mask], n[4][mask]) and torch.equal(n[1][mask], n[5][mask])
 
 
-def test_map_native_scheduling_switches_agree():
-    """The scheduling devices of psl_map_iters -- lazy Adam replay (work lists, dense catch-up at block ends), the dW chunk
-    reduction inside the Adam launch, the k-NN prefetch of the next block on the side stream (throttled, a wavefront walks
-    several rays) -- change WHEN things are computed, not what: a 150-iteration mapping call (three prefetch blocks, both
-    stages, decoder training) gives the same losses and rows with each of them switched off.  (Runs differ by the order
-    of the float atomics of the feature scatter only.)"""
+def _map_switch_runs(n_it, variants, dev):
+    """psl_map_iters on the small scene with the A/B switches of `variants` ({name: {option: value}}); the same draws."""
     from point_slam_amd import _lib
-    dev = torch.device("cuda:0")
     cfg, cam, frames, pts = _scene(dev)
     L = _lib.lib()
-    n_it = 150
-    res = {}
-    draws = None
-    variants = {"all_on": {}, "dense_adam": {b"lazy_adam": 0}, "separate_dw_reduce": {b"dw_fused": 0},
-                "knn_on_main_stream": {b"knn_overlap": 0}}
+    res, draws = {}, None
+    keys = (b"lazy_adam", b"dw_fused", b"knn_overlap")
     try:
         for name, opts in variants.items():
-            for k in (b"lazy_adam", b"dw_fused", b"knn_overlap"):
+            for k in keys:
                 _lib.check(L.psl_debug_option(k, opts.get(k, 1)))
             s = _slam(cfg, cam, "native", dev)
             s.seed_points(pts)
@@ -255,24 +247,48 @@ def test_map_native_scheduling_switches_agree():
             s._map_native(window, sel, row_map, n_it, 200, draws=draws)
             torch.cuda.synchronize()
             res[name] = (s.last_losses[:, 0].cpu(), s.npc.geo_feats[sel.long()].cpu(), s.npc.col_feats[sel.long()].cpu(),
-                         s.theta.cpu())
+                         s.theta.cpu(), s.last_losses[:, 1].cpu())
     finally:
-        for k in (b"lazy_adam", b"dw_fused", b"knn_overlap"):
+        for k in keys:
             _lib.check(L.psl_debug_option(k, 1))
-    ref = res["all_on"]
-    assert bool(torch.isfinite(ref[0]).all()) and float(ref[0][-1]) < float(ref[0][0])      # it optimised
-    for name, r in res.items():
-        if name == "all_on":
-            continue
-        loss_rel = float(((r[0] - ref[0]).abs() / ref[0].abs()).max())
-        dg = (r[1] - ref[1]).abs().flatten()
-        dc = (r[2] - ref[2]).abs().flatten()
-        dth = (r[3] - ref[3]).abs()
-        report(test="map_scheduling_switch", variant=name, loss_rel_max=loss_rel, geo_frac_gt_1e3=float((dg > 1e-3).float().mean()),
-               col_frac_gt_1e3=float((dc > 1e-3).float().mean()), theta_max=float(dth.max()))
-        # 150 Adam steps amplify the atomics' rounding noise on rows with tiny gradients: distributions, as above
-        assert loss_rel < 2e-3, name
-        assert float((dg > 1e-3).float().mean()) < 2e-2 and float((dc > 1e-3).float().mean()) < 2e-2, name
+    return res
+
+
+def _switch_metrics(r, ref):
+    dg = (r[1] - ref[1]).abs().flatten()
+    dc = (r[2] - ref[2]).abs().flatten()
+    return dict(loss_rel_max=float(((r[0] - ref[0]).abs() / ref[0].abs()).max()),
+                loss_rel_mean=float(((r[0] - ref[0]).abs() / ref[0].abs()).mean()),
+                geo_frac_gt_1e3=float((dg > 1e-3).float().mean()), col_frac_gt_1e3=float((dc > 1e-3).float().mean()),
+                geo_mean=float(dg.mean()), col_mean=float(dc.mean()), theta_max=float((r[3] - ref[3]).abs().max()))
+
+
+def test_map_native_scheduling_switches_agree():
+    """The scheduling devices of psl_map_iters -- lazy Adam replay (work lists, dense catch-up at block ends), the dW chunk
+    reduction inside the Adam launch, the k-NN prefetch of the next block on the side stream (throttled, a wavefront walks
+    several rays) -- change WHEN things are computed, not what.  Runs differ by the order of the float atomics of the
+    feature scatter, and Adam amplifies that noise (rows with tiny gradients move ~lr per step in a direction the noise
+    decides), so the yardstick is a second run of the SAME configuration:
+      * 24 iterations (replay gaps up to ~20 steps, noise still small): lazy vs dense Adam within 3x the noise;
+      * 150 iterations (three prefetch blocks, both stages, decoder training): every switch within 3x the noise."""
+    dev = torch.device("cuda:0")
+    keys = ("loss_rel_max", "loss_rel_mean", "geo_mean", "col_mean", "geo_frac_gt_1e3", "col_frac_gt_1e3")
+    for n_it, variants in ((24, {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0}}),
+                           (150, {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0},
+                                  "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0}})):
+        res = _map_switch_runs(n_it, variants, dev)
+        ref = res["all_on"]
+        # it optimised: the depth term (the total switches definition with the stage) went down
+        assert bool(torch.isfinite(ref[0]).all()) and float(ref[4][-8:].mean()) < float(ref[4][:8].mean())
+        noise = _switch_metrics(res["all_on_again"], ref)
+        report(test="map_scheduling_switch", iters=n_it, variant="all_on_again (noise)", **noise)
+        for name, r in res.items():
+            if name in ("all_on", "all_on_again"):
+                continue
+            mt = _switch_metrics(r, ref)
+            report(test="map_scheduling_switch", iters=n_it, variant=name, **mt)
+            for key in keys:
+                assert mt[key] <= 3.0 * noise[key] + 2e-6, (n_it, name, key, mt[key], noise[key])
 
 
 def test_compact_feature_gradients_match_dense():
