@@ -157,7 +157,9 @@ def roofline_of(prof, traffic=None):
         per[k]["frac"] = per[k]["achieved"] / per[k]["peak"]
     if not per:
         return None, {}
-    dom = max((k for k in per if k != "misc"), key=lambda k: per[k]["total_ms"])
+    # "knn_side_stream": the mapper's k-NN block prefetch, throttled to two workgroups per CU on a second stream while
+    # the decode kernels of the previous block run -- its (stretched) duration is not on the critical path
+    dom = max((k for k in per if k not in ("misc", "knn_side_stream")), key=lambda k: per[k]["total_ms"])
     r = per[dom]
     tr = (traffic or {}).get(dom)
     roof = dict(kernel=dom, bound=r["bound"], achieved=round(r["achieved"], 4), peak=r["peak"], unit=r["unit"],

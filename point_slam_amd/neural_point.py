@@ -85,6 +85,12 @@ class HipNeuralPointCloud(object):
     def handle(self):
         return self._h
 
+    def __reduce__(self):
+        # the reference shares its cloud between the tracker and mapper PROCESSES through a BaseManager proxy
+        # (src/Point_SLAM.py:256-281); a native context (device buffers, grid index) belongs to one process
+        raise TypeError("HipNeuralPointCloud cannot be pickled or sent to another process: run tracker and mapper in one "
+                        "process per GPU (INTEGRATION.md section 2)")
+
     def cloud_pos_device(self, first=0, count=None):
         """Positions [count,3] of points [first, first+count) as a device tensor (no host copy)."""
         n = self.pts_num()

@@ -72,3 +72,13 @@ def test_every_npc_use_of_the_reference_callers_is_served():
     inst_attrs = {"device"}      # set in __init__ on both classes (Renderer.py:53 even calls it -- dead branch there)
     missing = [u for u in sorted(used) if not hasattr(HipNeuralPointCloud, u) and u not in inst_attrs]
     assert not missing, missing
+
+
+def test_native_point_cloud_refuses_to_cross_processes():
+    """The reference shares its cloud between processes through a BaseManager proxy; a native context cannot travel:
+    pickling must fail loudly instead of producing a dead handle on the other side."""
+    import pickle
+    from point_slam_amd.neural_point import HipNeuralPointCloud
+    obj = HipNeuralPointCloud.__new__(HipNeuralPointCloud)      # no native context needed for the check
+    with pytest.raises(TypeError, match="one process per GPU"):
+        pickle.dumps(obj)
