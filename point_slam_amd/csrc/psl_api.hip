@@ -293,7 +293,7 @@ extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
 
 static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
                                          "adam", "misc", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
-                                         "decode_bwd_track", "knn_side_stream"};
+                                         "decode_bwd_track", "knn_side_stream", "knn_prefetch"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 

@@ -127,6 +127,7 @@ constexpr int kMaxCoarse = kMaxCells / 4 + 1024;   // worst case: a grid that is
 enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BWD, PROF_DECODE_BWD, PROF_DW,
                 PROF_ADAM, PROF_MISC, PROF_DECODE_FWD_GEO, PROF_DECODE_BWD_GEO, PROF_DECODE_FWD_TRK, PROF_DECODE_BWD_TRK,
                 PROF_KNN_SIDE,   // the mapper's k-NN block prefetch while it runs on the side stream (off the critical path)
+                PROF_KNN_PREFETCH,   // ... and on the main stream (first block of a call): the per-ray kernel, 10^4..10^5 rays per launch
                 PROF_N };
 inline int prof_decode_slot(int flags, bool bwd) {
   if (!(flags & PSL_STAGE_COLOR)) return bwd ? PROF_DECODE_BWD_GEO : PROF_DECODE_FWD_GEO;

@@ -1033,7 +1033,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
                          nb);
       hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, st, pbs[set].gd, pbs[set].active, n);
       PSL_LAUNCH_CHECK(); }
-    ProfScope ps(ctx, PROF_KNN, st, 108.0 * nb * n * S);
+    ProfScope ps(ctx, st == s ? PROF_KNN_PREFETCH : PROF_KNN_SIDE, st, 108.0 * nb * n * S);
     // on the side stream the lookup is THROTTLED (g_knn_side_blocks workgroups, ~2 per CU): left alone its 10^4
     // workgroups fill every CU and the decode kernels of the main stream wait for slots (one of them measured at
     // 845 us instead of 52); it has a whole block of iterations (~8 ms) to finish
