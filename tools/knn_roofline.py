@@ -17,14 +17,14 @@ L = _lib.lib()
 out = []
 
 
-def measure(label, fn, queries_per_launch):
+def measure(label, fn, queries_per_launch, cls="knn"):
     fn()                                   # warm
     torch.cuda.synchronize()
     L.psl_knn_candidates(slam.npc.handle)
     _lib.check(L.psl_profile_enable(slam.npc.handle, 1))
     fn()
     torch.cuda.synchronize()
-    prof = B.kernel_profile(slam)["knn"]
+    prof = B.kernel_profile(slam)[cls]
     _lib.check(L.psl_profile_enable(slam.npc.handle, 0))
     cand = int(L.psl_knn_candidates(slam.npc.handle))
     n = prof["launches"]
@@ -41,6 +41,7 @@ fr = frames[0]
 measure("tracker 200 rays x 20 iterations", lambda: slam.track(fr, cams0[0]), 1000)
 window = slam.keyframes[-4:] + [fr]
 sel, row_map = slam.frustum_select(fr, fr.c2w)
-measure("mapper prefetch 64 iterations x 1000 rays", lambda: slam._map_native(window, sel, row_map, 64, 200), 64 * 1000 * 5)
+measure("mapper prefetch 64 iterations x 1000 rays", lambda: slam._map_native(window, sel, row_map, 64, 200), 64 * 1000 * 5,
+        cls="knn_prefetch")       # one block: looked up on the main stream, unthrottled
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/knn_roofline.json", "w"), indent=1)
