@@ -313,9 +313,10 @@ __device__ __forceinline__ void knn_scan_rows(const GridMeta& m, const float4* _
 __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
                                          const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
                                          float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr,
-                                         const int* __restrict__ coarse = nullptr) {
+                                         const int* __restrict__ coarse = nullptr, int* n_pass = nullptr) {
   float rho = m.cell;
   unsigned long long cand = 0;
+  int passes = 0;
   if (coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
     const u64 sentinel = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
 #pragma unroll
@@ -331,10 +332,12 @@ __device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __rest
 #pragma unroll
     for (int j = 0; j < K; ++j) best[j] = sentinel;
     knn_scan_rows(m, spos, cell_start, qx, qy, qz, re, best, 0, 1, cand);
+    ++passes;
     if (last || best[K - 1] != sentinel) break;
     rho *= 2.0f;
   }
   if (n_cand) *n_cand = cand;
+  if (n_pass) *n_pass = passes;
 }
 
 __device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lane, unsigned& ib_out, unsigned& db_out,
@@ -353,6 +356,12 @@ __device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lan
   cnt_out = cnt;
 }
 
+// PSL_KNN_TRACE=1: per-query cost distribution of the one-wavefront-per-sample kernel (shader cycles, candidates, passes),
+// dumped by psl_debug_option("knn_trace_dump", 1)
+struct KnnTrace { unsigned long long n, sum_cyc, max_cyc, sum_cand, max_cand, sum_pass, hist_cyc[24], hist_cand[24], hist_pass[4]; };
+__device__ KnnTrace g_knn_trace;
+__device__ __forceinline__ int log2_bucket(unsigned long long v) { int b = 0; while (v > 1 && b < 23) { v >>= 1; ++b; } return b; }
+
 // ray mode: one wave per SAMPLE (5 per ray); I_out [R*5][8] int32, cnt_out [R*5]
 __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                   const int* __restrict__ cell_start,
@@ -361,9 +370,11 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
                                                   const float* __restrict__ r_query,
                                                   float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                   int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                  unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
+                                                  unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse,
+                                                  int trace) {
   const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (p >= n_rays * S) return;
+  const unsigned long long t0 = trace ? clock64() : 0ull;
   const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
   const GridMeta m = *meta;
@@ -375,11 +386,20 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
                rays_d[ray * 3 + 2], zq, qx, qy, qz);
   u64 best[K];
   unsigned long long n_cand = 0;
-  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand, coarse);
+  int n_pass = 0;
+  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand, coarse, &n_pass);
   unsigned ib, db; int cnt;
   knn_emit(best, r2, lane, ib, db, cnt);
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
+  if (trace && lane == 0) {
+    const unsigned long long cyc = clock64() - t0;
+    atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
+    atomicAdd(&g_knn_trace.sum_cand, n_cand); atomicMax(&g_knn_trace.max_cand, n_cand);
+    atomicAdd(&g_knn_trace.sum_pass, (unsigned long long)n_pass);
+    atomicAdd(&g_knn_trace.hist_cyc[log2_bucket(cyc)], 1ull); atomicAdd(&g_knn_trace.hist_cand[log2_bucket(n_cand + 1)], 1ull);
+    atomicAdd(&g_knn_trace.hist_pass[min(n_pass, 3)], 1ull);
+  }
 }
 
 // ray mode for SMALL launches (the tracker: 200 rays = 1000 queries, one wavefront each would leave every SIMD with a
@@ -732,10 +752,30 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     return PSL_OK;
   }
   int blocks = (n_rays * S + 3) / 4;
+  static int trace = -1;
+  if (trace < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace = (e && e[0] == '1') ? 1 : 0; }
+  // (the candidate counter costs one same-address atomic per query: only while the bench's class timers are on)
   hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
+                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
+                     (ctx->prof_on || trace) ? ctx->knn_cand : nullptr, ctx->coarse, trace);
   PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
+int knn_trace_dump() {
+  KnnTrace t;
+  if (hipMemcpyFromSymbol(&t, HIP_SYMBOL(g_knn_trace), sizeof(t)) != hipSuccess) return PSL_ERR_HIP;
+  const double n = (double)std::max<unsigned long long>(t.n, 1);
+  fprintf(stderr, "[psl knn trace] queries %llu | cycles mean %.0f max %llu | candidates mean %.1f max %llu | passes mean %.2f (1: %llu, 2: %llu, 3+: %llu)\n",
+          t.n, t.sum_cyc / n, t.max_cyc, t.sum_cand / n, t.max_cand, t.sum_pass / n, t.hist_pass[1], t.hist_pass[2], t.hist_pass[3]);
+  fprintf(stderr, "[psl knn trace] cycles histogram (log2 buckets):");
+  for (int b = 0; b < 24; ++b) if (t.hist_cyc[b]) fprintf(stderr, " 2^%d:%llu", b, t.hist_cyc[b]);
+  fprintf(stderr, "\n[psl knn trace] candidates histogram (log2 buckets):");
+  for (int b = 0; b < 24; ++b) if (t.hist_cand[b]) fprintf(stderr, " 2^%d:%llu", b, t.hist_cand[b]);
+  fprintf(stderr, "\n");
+  t = KnnTrace{};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_trace), &t, sizeof(t)) != hipSuccess) return PSL_ERR_HIP;
   return PSL_OK;
 }
 
