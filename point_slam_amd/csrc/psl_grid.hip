@@ -257,6 +257,92 @@ __device__ __forceinline__ bool wave_box_empty(const GridMeta& m, const int* __r
 // r-sized neighbourhood holds several thousand candidates.
 // The (cz,cy) rows of the cube are x-runs of cells = contiguous ranges of `spos`; their [begin,end) pairs are
 // fetched 64 rows at a time, one row per lane, then walked with coalesced 16 B/lane candidate loads.
+__device__ __forceinline__ unsigned dpp_shr1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1 (lane 0 of a row keeps 0)
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFull), l);
+  return ((u64)hi << 32) | lo;
+}
+
+// One query, sorted top-8 ACROSS lanes (entry j in lane j < 8; the trace of the tracker's launches showed half of a
+// query's ~30 k cycles in the 8-deep compare/select chain that a wave-uniform list costs per accepted candidate, ~45
+// of them per query): an insertion is one DPP shift + two 64-bit selects, the threshold one 64-bit readlane of lane 7.
+// Same keys, same order: bit-identical answers to knn_scan_rows / wave_knn.
+__device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const float4* __restrict__ spos,
+                                                   const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                                   float re, u64& mine, u64& thr, unsigned long long& cand) {
+  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
+  CellBox bx;
+  box_of(m, qx, qy, qz, re, bx);
+  const int ny_b = bx.hi[1] - bx.lo[1] + 1;
+  const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
+  auto row_range = [&](int row, int& beg, int& end) {
+    beg = 0; end = 0;
+    if (row < nrows) {
+      const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+      const int rowbase = (cz * m.ny + cy) * m.nx;
+      beg = cell_start[rowbase + bx.lo[0]];
+      end = cell_start[rowbase + bx.hi[0] + 1];
+    }
+  };
+  int beg, end, nbeg, nend;
+  row_range(grp, beg, end);
+  for (int rb = 0; rb < nrows; rb += 4) {
+    row_range(rb + 4 + grp, nbeg, nend);
+    int j = beg + l16;
+    // two chunks of every row in flight: rows hold ~45 candidates, i.e. three dependent loads with one-deep prefetch
+    float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 c1 = (j + 16 < end) ? spos[j + 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+    while (__ballot(j < end)) {
+      const bool valid = j < end;
+      const int jn = j + 16;
+      const float4 c2 = (jn + 16 < end) ? spos[jn + 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+      cand += (unsigned long long)__popcll(__ballot(valid));
+      const unsigned idx = __float_as_uint(c.w);
+      const float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
+      const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
+      u64 mask = __ballot(valid && key < thr);
+      while (mask) {
+        const u64 kk = readlane64(key, __builtin_ctzll(mask));
+        const u64 prev = ((u64)dpp_shr1((unsigned)(mine >> 32)) << 32) | dpp_shr1((unsigned)(mine & 0xFFFFFFFFull));
+        mine = (kk < prev) ? prev : ((kk < mine) ? kk : mine);
+        thr = readlane64(mine, K - 1);
+        mask &= mask - 1;
+        if (mask) mask &= __ballot(valid && key < thr);
+      }
+      j = jn; c = c1; c1 = c2;
+    }
+    beg = nbeg; end = nend;
+  }
+}
+
+// expanding search with the lane-distributed list; on return lane j < 8 holds entry j in `mine`
+__device__ __forceinline__ void wave_knn_lane(const GridMeta& m, const float4* __restrict__ spos,
+                                              const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
+                                              float r2, u64& mine, unsigned long long& cand, const int* __restrict__ coarse,
+                                              int& passes) {
+  float rho = m.cell;
+  passes = 0;
+  if (coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
+    mine = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
+    return;
+  }
+  for (;;) {
+    const bool last = rho >= r;
+    const float re = last ? r : rho;
+    const float t2 = last ? r2 : __fmul_rn(rho, rho);
+    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
+    mine = sentinel;
+    u64 thr = sentinel;
+    knn_scan_rows_lane(m, spos, cell_start, qx, qy, qz, re, mine, thr, cand);
+    ++passes;
+    if (last || thr != sentinel) break;
+    rho *= 2.0f;
+  }
+}
+
 // one pass of the expanding search for one wavefront: scans rows wsub*4 .. of every nsub*4 rows of the cube
 // [q - re, q + re] (nsub wavefronts share a query), inserting keys below best[K-1] into `best`
 __device__ __forceinline__ void knn_scan_rows(const GridMeta& m, const float4* __restrict__ spos,
@@ -384,12 +470,13 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   float qx, qy, qz;
   sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
                rays_d[ray * 3 + 2], zq, qx, qy, qz);
-  u64 best[K];
+  u64 mine;
   unsigned long long n_cand = 0;
   int n_pass = 0;
-  wave_knn(m, spos, cell_start, qx, qy, qz, r, r2, best, &n_cand, coarse, &n_pass);
-  unsigned ib, db; int cnt;
-  knn_emit(best, r2, lane, ib, db, cnt);
+  wave_knn_lane(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass);
+  // after an early exit the sentinel threshold was rho^2 <= r2: every kept entry has d2 <= rho^2 <= r2
+  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
+  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
   if (trace && lane == 0) {
@@ -475,10 +562,6 @@ __global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict_
 //    insertion is one DPP shift plus two 64-bit selects for all five lists at once, one candidate per list per step,
 //    instead of an 8-deep compare/select chain on wave-uniform registers per candidate;
 //  * results are the same keys (distance bits << 32 | index) as in the one-query kernel: bit-identical answers.
-__device__ __forceinline__ unsigned dpp_shr1(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-}
-
 __device__ __forceinline__ void knn_ray2_one(int ray, const GridMeta& m, const float4* __restrict__ spos,
                                              const int* __restrict__ cell_start,
                                              const float* __restrict__ rays_o, const float* __restrict__ rays_d,
