@@ -629,11 +629,10 @@ __device__ __forceinline__ void knn_ray2_one(int ray, const GridMeta& m, const f
       row_range(rb + 4 + grp, nbeg, nend);      // next step's ranges are in flight while this step's rows are scanned
       int j = beg + l16;
       float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 c1 = (j + 16 < end) ? spos[j + 16] : make_float4(0.f, 0.f, 0.f, 0.f);
       while (__ballot(j < end)) {
         const bool valid = j < end;
         const int jn = j + 16;
-        const float4 c2 = (jn + 16 < end) ? spos[jn + 16] : make_float4(0.f, 0.f, 0.f, 0.f);     // two chunks of the row in flight
+        const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row
         n_cand += (unsigned long long)__popcll(__ballot(valid));
         const unsigned idx = __float_as_uint(c.w);
         u64 key[S], pend[S];
@@ -683,7 +682,7 @@ __device__ __forceinline__ void knn_ray2_one(int ray, const GridMeta& m, const f
             thr[s] = ((u64)thi << 32) | tlo;
           }
         }
-        j = jn; c = c1; c1 = c2;
+        j = jn; c = cn;
       }
       beg = nbeg; end = nend;
     }
