@@ -266,13 +266,21 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l) {
   return ((u64)hi << 32) | lo;
 }
 
+// insertion of a wave-uniform key kk < thr into the lane-distributed sorted list (entry j in lane j < 8)
+__device__ __forceinline__ void lane_list_insert(u64& mine, u64& thr, u64 kk) {
+  const u64 prev = ((u64)dpp_shr1((unsigned)(mine >> 32)) << 32) | dpp_shr1((unsigned)(mine & 0xFFFFFFFFull));
+  mine = (kk < prev) ? prev : ((kk < mine) ? kk : mine);
+  thr = readlane64(mine, K - 1);
+}
+
 // One query, sorted top-8 ACROSS lanes (entry j in lane j < 8; the trace of the tracker's launches showed half of a
 // query's ~30 k cycles in the 8-deep compare/select chain that a wave-uniform list costs per accepted candidate, ~45
 // of them per query): an insertion is one DPP shift + two 64-bit selects, the threshold one 64-bit readlane of lane 7.
 // Same keys, same order: bit-identical answers to knn_scan_rows / wave_knn.
 __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const float4* __restrict__ spos,
                                                    const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                                   float re, u64& mine, u64& thr, unsigned long long& cand) {
+                                                   float re, u64& mine, u64& thr, unsigned long long& cand,
+                                                   int wsub = 0, int nsub = 1) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   CellBox bx;
   box_of(m, qx, qy, qz, re, bx);
@@ -287,10 +295,11 @@ __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const floa
       end = cell_start[rowbase + bx.hi[0] + 1];
     }
   };
+  const int step = 4 * nsub;                     // nsub wavefronts share a query: this one takes rows 4 wsub .. of every step
   int beg, end, nbeg, nend;
-  row_range(grp, beg, end);
-  for (int rb = 0; rb < nrows; rb += 4) {
-    row_range(rb + 4 + grp, nbeg, nend);
+  row_range(4 * wsub + grp, beg, end);
+  for (int rb = 4 * wsub; rb < nrows; rb += step) {
+    row_range(rb + step + grp, nbeg, nend);
     int j = beg + l16;
     // two chunks of every row in flight: rows hold ~45 candidates, i.e. three dependent loads with one-deep prefetch
     float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -305,10 +314,7 @@ __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const floa
       const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
       u64 mask = __ballot(valid && key < thr);
       while (mask) {
-        const u64 kk = readlane64(key, __builtin_ctzll(mask));
-        const u64 prev = ((u64)dpp_shr1((unsigned)(mine >> 32)) << 32) | dpp_shr1((unsigned)(mine & 0xFFFFFFFFull));
-        mine = (kk < prev) ? prev : ((kk < mine) ? kk : mine);
-        thr = readlane64(mine, K - 1);
+        lane_list_insert(mine, thr, readlane64(key, __builtin_ctzll(mask)));
         mask &= mask - 1;
         if (mask) mask &= __ballot(valid && key < thr);
       }
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict_
     if (wsub == 0) { if (lane < K) I_out[p * K + lane] = -1; if (lane == 0) cnt_out[p] = 0; }
     return;
   }
-  u64 best[K];
+  u64 mine, thr;
   unsigned long long n_cand = 0;
   float rho = m.cell;
   for (;;) {
@@ -525,29 +531,27 @@ __global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict_
     const float re = last ? r : rho;
     const float t2 = last ? r2 : __fmul_rn(rho, rho);
     const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = sentinel;
-    knn_scan_rows(m, spos, cell_start, qx, qy, qz, re, best, wsub, 4, n_cand);
-#pragma unroll
-    for (int j = 0; j < K; ++j) if (lane == j) sbest[wsub][j] = best[j];
+    mine = sentinel; thr = sentinel;
+    knn_scan_rows_lane(m, spos, cell_start, qx, qy, qz, re, mine, thr, n_cand, wsub, 4);
+    if (lane < K) sbest[wsub][lane] = mine;
     __syncthreads();
-    // every wavefront merges the other three lists into its own: the four rows sets are disjoint, so are the keys
+    // every wavefront merges the other three lists into its own: the four row sets are disjoint, so are the keys
     for (int o = 1; o < 4; ++o) {
       const int w2 = (wsub + o) & 3;
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const u64 kk = sbest[w2][j];
-        if (kk < best[K - 1]) topk_insert(best, kk);
+        if (kk < thr) lane_list_insert(mine, thr, kk);
       }
     }
     __syncthreads();
-    if (last || best[K - 1] != sentinel) break;
+    if (last || thr != sentinel) break;
     rho *= 2.0f;
   }
   if (lane == 0 && cand_counter) atomicAdd(cand_counter, n_cand);
   if (wsub != 0) return;
-  unsigned ib, db; int cnt;
-  knn_emit(best, r2, lane, ib, db, cnt);
+  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
+  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) cnt_out[p] = cnt;
 }
