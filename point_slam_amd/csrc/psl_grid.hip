@@ -816,9 +816,10 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
   // 0 = by launch size: from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the
   // shared candidate scan of one wavefront per ray (2); below that one wavefront per sample (1).  3 = four wavefronts
-  // per sample sharing the rows of every pass: measured EQUAL to (1) on the tracker's 200-ray launches (68 us both,
-  // profiles/r02_knn_small_ab.txt) -- those launches are not bound by the serial row walk of a wavefront -- so it
-  // stays an option (PSL_KNN_SMALL=3), covered by the exactness tests.
+  // per sample sharing the rows of every pass: measured no faster than (1) on the tracker's 200-ray launches, before
+  // and after both got the lane-distributed list (68 vs 67 us, then 67 vs 63 us; profiles/r02_knn_small_ab.txt) --
+  // those launches are not bound by the serial row walk of a wavefront -- so it stays an option (PSL_KNN_SMALL=3),
+  // covered by the exactness tests.
   static int small_ver = -1;
   if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] == '3') ? 3 : 1; }
   const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : small_ver);
