@@ -281,7 +281,7 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 
 // one thread: quaternion chain of dL/dR, then Adam on the 7 pose parameters
 __device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&gT)[3], float* cam_tensor, float* adam_mv,
-                                          int step, float lr_T, float lr_q) {
+                                          int step, float lr_T, float lr_q, const AdamBias* host_bias = nullptr) {
   float qr = cam_tensor[0], qi = cam_tensor[1], qj = cam_tensor[2], qk = cam_tensor[3];
   float nn = qr * qr + qi * qi + qj * qj + qk * qk;
   float s = 2.0f / nn;
@@ -303,7 +303,8 @@ __device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&
               G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
   float ds = -s * s;   // d s / d q_x = -s^2 q_x
   float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
-  const AdamBias bias = adam_bias(step);   // once, not per parameter: two double pow() on a single thread
+  // once, not per parameter; k_track_pre gets the two double pow() from the host (they were ~40 % of its 13 us)
+  const AdamBias bias = host_bias ? *host_bias : adam_bias(step);
 #pragma unroll
   for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, bias);
 #pragma unroll
@@ -361,7 +362,8 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
                                                     const float4* __restrict__ dp2, float near_s, float far_s, RayBufs b,
                                                     int n, float* cam_tensor, float* adam_mv, int step, float lr_T,
                                                     float lr_q, psl_cam_intr cam, int H0, int H1, int W0, int W1,
-                                                    const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx) {
+                                                    const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx,
+                                                    AdamBias bias) {
   __shared__ float red[16][12];
   const int r = threadIdx.x;
   if (do_step) {
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
         for (int k = 0; k < 3; ++k) { float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][a * 3 + k]; G[a][k] = t; }
         float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][9 + a]; gT[a] = t;
       }
-      pose_adam(G, gT, cam_tensor, adam_mv, step, lr_T, lr_q);
+      pose_adam(G, gT, cam_tensor, adam_mv, step, lr_T, lr_q, &bias);
       __threadfence_block();
     }
     __syncthreads();          // the new pose is visible to every thread of the workgroup
@@ -814,10 +816,15 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
+    // bias corrections of Adam step `step0 + it` with the formulas of adam_bias(), evaluated here instead of by one thread
+    AdamBias bias;
+    const int step = std::max(t->step0 + it, 1);
+    bias.bc1 = 1.0 - pow((double)0.9f, (double)step);
+    bias.sqrt_bc2 = (float)sqrt(1.0 - pow((double)0.999f, (double)step));
     hipLaunchKernelGGL(k_track_pre, dim3(1), dim3(1024), 0, s, do_step, do_setup, (const float4*)rw.dp, (const float4*)rw.dp2,
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, b, n, t->cam_tensor, t->adam_state, t->step0 + it,
                        t->lr_T, t->lr_quat, t->cam, eh, t->cam.H - eh, ew, t->cam.W - ew, fdev,
-                       t->pix_idx + (size_t)std::min(it, t->n_iters - 1) * n);
+                       t->pix_idx + (size_t)std::min(it, t->n_iters - 1) * n, bias);
   };
   for (int it = 0; it < t->n_iters; ++it) {
     if (fused) {
