@@ -303,7 +303,7 @@ __device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&
               G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
   float ds = -s * s;   // d s / d q_x = -s^2 q_x
   float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
-  // once, not per parameter; k_track_pre gets the two double pow() from the host (they were ~40 % of its 13 us)
+  // once, not per parameter; k_track_pre gets the two double pow() from the host (measured: 13.0 -> 12.5 us)
   const AdamBias bias = host_bias ? *host_bias : adam_bias(step);
 #pragma unroll
   for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, bias);
