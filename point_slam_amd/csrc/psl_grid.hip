@@ -273,9 +273,10 @@ __device__ __forceinline__ void lane_list_insert(u64& mine, u64& thr, u64 kk) {
   thr = readlane64(mine, K - 1);
 }
 
-// One query, sorted top-8 ACROSS lanes (entry j in lane j < 8; the trace of the tracker's launches showed half of a
-// query's ~30 k cycles in the 8-deep compare/select chain that a wave-uniform list costs per accepted candidate, ~45
-// of them per query): an insertion is one DPP shift + two 64-bit selects, the threshold one 64-bit readlane of lane 7.
+// One query, sorted top-8 ACROSS lanes (entry j in lane j < 8).  A wave-uniform list costs an 8-deep compare/select
+// chain (~300 cycles) per accepted candidate, ~45 of them per query on the tracker's launches (58.5 k cycles per query in
+// the trace; 49.9 k with this list and the second chunk in flight): here an insertion is one DPP shift + two 64-bit
+// selects, the threshold one 64-bit readlane of lane 7.
 // Same keys, same order: bit-identical answers to knn_scan_rows / wave_knn.
 __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const float4* __restrict__ spos,
                                                    const int* __restrict__ cell_start, float qx, float qy, float qz,
