@@ -106,7 +106,12 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         state["added"] += slam.npc.pts_num() - n_base
         if world > 1 and state["mapped"] % args.exchange_every == 0:
             # new points (cross-rank dedupe), features of shared rows and the colour decoder are reconciled
+            import time as _t
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
             state["sync"].exchange(slam.npc, slam.theta)
+            torch.cuda.synchronize()
+            state.setdefault("exchange_s", []).append(_t.perf_counter() - t0)
         if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
             slam.keyframes.append(fr)
             if len(slam.keyframes) > 40:        # the reference keeps every keyframe on the CPU; bounded here
@@ -131,13 +136,20 @@ def pmc_traffic(mix):
     """HBM bytes per launch of each kernel class from the PMC pass of the same command (tools/pmc_traffic.sh: separate
     rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md applied there);
     rocprofv3 cannot run inside the timed process, so the figures are read from the committed summary."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_{mix}.json")
-    if not os.path.exists(path):
-        return {}
-    try:
-        return json.load(open(path))
-    except Exception:
-        return {}
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{mix}.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        meta = d.pop("_meta", {}) if isinstance(d, dict) else {}
+        meta.update(file=os.path.relpath(path, ROOT), kind="offline PMC pass (separate rocprofv3 --pmc runs), not measured "
+                                                           "in this process")
+        d["_source"] = meta
+        return d
+    return {}
 
 
 def roofline_of(prof, traffic=None):
@@ -167,7 +179,28 @@ def roofline_of(prof, traffic=None):
                 avg_launch_us=round(r["avg_us"], 2), launches=r["launches"])
     if tr:
         roof["traffic_detail"] = tr
+    roof["traffic_source"] = (traffic or {}).get("_source") if tr else None
     return roof, per
+
+
+def parity_vs_oracle(slam, cfg, cam, frame):
+    """Part of the cpu_baseline leg (the only place bench.py touches oracle/): ONE tracker iteration, one geometry-stage and
+    one colour-stage mapper iteration of the configured pixel budgets on the map AS THE RUN LEFT IT (>= 1 M points, trained
+    features and decoder), evaluated by the HIP path through the C ABI and by the pinned oracle on identical inputs --
+    outside every timed region.  The float that goes into config.render_loss_rel_err_vs_reference is the largest of the
+    three loss-level relative errors (BASELINE.json: <= 1e-4)."""
+    from tests import parity_probe as PP
+    st = PP.oracle_state(slam)
+    tr, mp = cfg["tracking"], cfg["mapping"]
+    cases = [("tracker", tr["pixels"]), ("map_geometry", mp["pixels"]), ("map_color", mp["pixels"])]
+    detail = [PP.probe(slam, cfg, cam, frame, k, n, seed=31 + j, state=st) for j, (k, n) in enumerate(cases)]
+    worst = max(max(d["loss_rel"], d["geo_loss_rel"], d["col_loss_rel"]) for d in detail)
+    keep = ("kind", "n_pix", "rays", "points", "loss", "loss_ref", "loss_rel", "geo_loss_rel", "col_loss_rel",
+            "depth_rel_max", "rgb_abs_max", "g_rays_o_rel_l2", "g_rays_d_rel_l2", "g_geo_rel_l2", "g_col_rel_l2",
+            "g_params_rel_l2")
+    return worst, dict(checker="oracle/pointslam_oracle.py (pinned to the unmodified reference by tests/test_oracle_golden.py)",
+                       cases=[{k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in d.items() if k in keep}
+                              for d in detail])
 
 
 def cpu_baseline(cfg, cam, n_points):
@@ -242,14 +275,30 @@ def cpu_baseline(cfg, cam, n_points):
                        f"{mp['iters']}/{mp['every_frame']} map iters ({r:.0%} geometry stage) per frame")
 
 
+def self_launch(n):
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver's scaling run may call it): re-exec under torch.distributed.run,
+        # one rank per GPU; rank 0 of the children prints the JSON line on the inherited stdout
+        raise SystemExit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X (no CPU fallback for the product path)")
     # PSL_BENCH_SHARE_GPU=1 (debug only): all ranks on cuda:0 with the gloo backend, to exercise the N>1 code path
@@ -257,6 +306,9 @@ def main():
     share = os.environ.get("PSL_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         f"(PSL_BENCH_SHARE_GPU=1 runs all ranks on cuda:0 over gloo, for one-GPU boxes)")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if os.environ.get("PSL_POISON") == "1":
@@ -318,6 +370,19 @@ def main():
 
     points_end = slam.npc.pts_num()
     mapped_total = max(state["mapped"], 1)
+    per_rank = None
+    if world > 1:
+        # a last, untimed exchange: afterwards every replica must hold the same map
+        t0 = time.perf_counter()
+        state["sync"].exchange(slam.npc, slam.theta)
+        torch.cuda.synchronize()
+        t_ex = time.perf_counter() - t0
+        mine = dict(rank=rank, points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
+                    added=state["added"], mapped=state["mapped"], final_exchange_ms=round(t_ex * 1e3, 3),
+                    exchange_ms=[round(x * 1e3, 3) for x in state.get("exchange_s", [])],
+                    feat_checksum=float(slam.npc.get_geo_feats().double().sum()))
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # (3) SURVEY.md 8(d): tracking-only and mapping-only rates next to the combined one (single GPU; after the measured
     #     regions, on frames already seen: 10 tracked frames, then 2 mapped frames at their true poses)
     split = None
@@ -357,14 +422,27 @@ def main():
                        "points_added_per_mapped_frame": round(state["added"] / mapped_total, 1),
                        "mapped_frames": state["mapped"],
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
-                       "render_loss_rel_err_vs_reference": "<=1e-4 (tests/test_hip_parity.py, tests/test_hip_slam.py)"},
+                       "keyframes_kept": "last 40 (the reference keeps every keyframe on the CPU)",
+                       # measured in this run by the cpu_baseline leg (parity_vs_oracle); null when that leg is off
+                       "render_loss_rel_err_vs_reference": None},
             "roofline": roof,
             "profiled_ms_per_step": round(dt_prof / args.steps * 1e3, 3) if dt_prof else None,
             "split": split,
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in per.items()},
         }
+        if per_rank is not None:
+            out["config"]["per_rank"] = per_rank
+            out["config"]["replicas_identical_after_exchange"] = (
+                len({r["points_after_final_exchange"] for r in per_rank}) == 1 and
+                len({r["feat_checksum"] for r in per_rank}) == 1)
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                worst, detail = parity_vs_oracle(slam, cfg, cam, frames[args.warmup + args.steps - 1])
+                out["config"]["render_loss_rel_err_vs_reference"] = float(f"{worst:.4g}")
+                out["config"]["render_loss_parity"] = detail
+            except Exception as e:
+                out["config"]["render_loss_parity"] = {"error": repr(e)}
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, cam, args.points)
             except Exception as e:      # the baseline must never take the measured line down with it

@@ -461,10 +461,16 @@ class _Adam:
     """torch.optim.Adam as the loops use it: one step counter per tensor, tensors whose gradient is None are
     skipped (their counter does not advance) -- the semantics of torch >= 2.0's zero_grad(set_to_none=True)."""
 
-    def __init__(self):
+    def __init__(self, zero_grad_names=()):
         self.state = {}
+        # torch 1.12 (the reference's env.yaml:61): zero_grad() leaves ZERO TENSORS on parameters that have had a gradient
+        # before, and Adam steps them (the counter advances; m = v = 0 keep p where it is).  Names listed here get a
+        # zero gradient instead of None -- the colour-decoder tensors from the second mapped frame on.
+        self.zero_grad_names = set(zero_grad_names)
 
     def step(self, name: str, p: Tensor, g: Optional[Tensor], lr: float) -> Tensor:
+        if g is None and name in self.zero_grad_names:
+            g = torch.zeros_like(p)
         if g is None:
             return p
         st = self.state.setdefault(name, dict(step=0, m=torch.zeros_like(p), v=torch.zeros_like(p)))
@@ -496,7 +502,8 @@ def mapper_rays(frames, pix_it, cam):
 
 
 def mapper_iterations(cfg, P, cloud, geo_feats, col_feats, sel, frames, pix, fb, n_geo_iters, cam, coef=0.1,
-                      exposure_feats=None, init=False, record=None):
+                      exposure_feats=None, init=False, record=None, torch1_zero_grads=False, lr_override=None,
+                      train_decoder=None):
     """The joint_iter loop of Mapper.optimize_map (src/Mapper.py:408-568, no BA) for pre-drawn pixels `pix`
     [n_iters][F][ppf] and fallback vectors `fb` [n_iters][2][32].  The frustum-selected rows `sel` of both feature
     sets, the colour decoder (all of color_decoder.parameters(), :358-360) and -- ScanNet -- the current frame's
@@ -511,14 +518,19 @@ def mapper_iterations(cfg, P, cloud, geo_feats, col_feats, sel, frames, pix, fb,
     P = {k: v.detach().clone() for k, v in P.items()}
     train_keys = [k for k in P if k.startswith("color_decoder.") and k != "color_decoder.embedder._B"
                   and P[k].dtype.is_floating_point] if not mp["fix_color_decoder"] else []
+    if train_decoder is not None and not train_decoder:
+        train_keys = []                     # colour refinement: fix_color_decoder forced (Mapper.py:717)
     exposure = cfg["model"]["encode_exposure"]
     ex_cur = exposure_feats[-1].detach().clone() if exposure else None
-    opt = _Adam()
+    # torch1_zero_grads: the decoder tensors carry zero .grad tensors from the previous mapped frame (see _Adam)
+    opt = _Adam(train_keys if torch1_zero_grads else ())
     n_iters = pix.shape[0]
     losses = []
     for it in range(n_iters):
         stage = "geometry" if it <= n_geo_iters else "color"                       # Mapper.py:420-423
         lr = stage_tab[stage]
+        if lr_override is not None:                                                # colour refinement, Mapper.py:427-430
+            lr = lr_override
         gp, cp = geo_p.clone().requires_grad_(True), col_p.clone().requires_grad_(True)
         Pg = {k: (v.clone().requires_grad_(True) if k in train_keys else v) for k, v in P.items()}
         ex = ex_cur.clone().requires_grad_(True) if exposure else None

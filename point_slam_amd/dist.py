@@ -71,6 +71,10 @@ def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True) -> List[
     rad = npc.point_radius(n_base, n_now - n_base)
     p_all, g_all, c_all, r_all, counts = exchange_new_points(pos, geo, col, rad, group)
     npc.truncate(n_base)
+    if n_now != n_base and hasattr(npc, "_build"):
+        # truncating invalidates the index; a rank whose own block is empty (or comes later) would otherwise run the
+        # dedupe test of the first foreign block against a stale index while its peers carry on -> desynchronised ranks
+        npc._build()
     off = 0
     for k, c in enumerate(counts):
         pk, gk, ck, rk = p_all[off:off + c], g_all[off:off + c], c_all[off:off + c], r_all[off:off + c]

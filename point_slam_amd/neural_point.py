@@ -130,10 +130,13 @@ class HipNeuralPointCloud(object):
         return self.radius_query
 
     def get_geo_feats(self):
-        return self.geo_feats
+        # a detached VIEW of the store (no copy): in-place writes by a caller reach the cloud -- as with the reference's
+        # shared tensor -- but autograd history never attaches to the store itself (the reference's BaseManager proxy
+        # hands out a detached copy, neural_point.py:64-67)
+        return self.geo_feats.detach() if self.geo_feats is not None else None
 
     def get_col_feats(self):
-        return self.col_feats
+        return self.col_feats.detach() if self.col_feats is not None else None
 
     def update_geo_feats(self, feats, indices=None):
         assert torch.is_tensor(feats), 'use tensor to update features'

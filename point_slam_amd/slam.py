@@ -225,7 +225,9 @@ class HipSLAM:
         a.ws, a.loss_out, a.best_out = self._ws_track.data_ptr(), losses.data_ptr(), best.data_ptr()
         a.pix_full_image = 1 if full else 0
         keep_ex = None
-        if self.encode_exposure:        # Tracker.py:269-271,305-311: latent cloned from the shared one, lr 0.001 for both
+        if self.encode_exposure:
+            # Tracker.py:269-271: latent cloned from the shared one.  BOTH optimiser branches add the latent and
+            # mlp_exposure.parameters() with lr 0.001 (separate_LR: Tracker.py:307-311; single camera tensor: :316-320)
             ex_feat = self.exposure_feat.clone().contiguous()
             ex, keep_ex = self._exposure_block(ex_feat, 0.001)
             a.exposure = C.pointer(ex)
@@ -302,8 +304,8 @@ class HipSLAM:
         mp, cam, dev = self.cfg["mapping"], self.cam, self.device
         n = n_pixels or mp["pixels_adding"]
         if first:
-            valid = frame.depth[frame.depth > 0]
-            scale = float((valid.median() / 2.5) ** 2) if valid.numel() else 1.0
+            # Mapper.py:304-306: gt_depth.median() over the WHOLE image, sensor holes (zeros) included
+            scale = float((frame.depth.median() / 2.5) ** 2)
             n = int(min(max(n * scale, n), 3 * n))
         idx = torch.randint(cam["H"] * cam["W"], (n,), device=dev)
         added = self._add_batch(frame, c2w, idx, False)
