@@ -330,7 +330,7 @@ def main():
     if world > 1:
         from point_slam_amd import params as P_
         from point_slam_amd.dist import FrameParallelSync
-        state["sync"] = FrameParallelSync(slam.npc, slam.theta, n_color=P_.color_floats())
+        state["sync"] = slam.sync = FrameParallelSync(slam.npc, slam.theta, n_color=P_.color_floats())
 
     def barrier():
         torch.cuda.synchronize()

@@ -102,6 +102,14 @@ int psl_index_build(psl_ctx* ctx, void* stream);
 int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq,
             float* D_out, int64_t* I_out, int32_t* cnt_out, void* stream);
 
+/* The admission test of add_neural_points (src/neural_point.py:116-121: a location is kept iff NO existing point lies
+ * strictly inside its radius) for externally supplied surface points, restricted to the first idx_limit points of the
+ * cloud: cnt_out[i] = #{ j < idx_limit : |x_j - q_i|^2 < r_i^2 } (an exact count, not capped at 8).  The multi-GPU merge
+ * (point_slam_amd/dist.py) tests the other ranks' new locations against the BASE map while the index still covers this
+ * rank's own tail -- no index rebuild before the test. */
+int psl_dedupe_count(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, int idx_limit,
+                     int32_t* cnt_out, void* stream);
+
 /* NeuralPointCloud.sample_near_pcl marching test (src/neural_point.py:232-249): hits[ray][step] = 1 when the point
  * rays_o + rays_d * z_steps[row][step] has >= 1 neural point strictly inside `radius` (cfg radius_query).
  * z_steps is [n_rows][n_steps]; row = step_row[ray], or 0 when step_row is NULL (render_img marches each of its
@@ -323,6 +331,23 @@ int psl_image_metrics_sync(const float* gt_color, const float* gt_depth, const f
 int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_d, const float* depth, int32_t n_rays,
                               int32_t n_samples, const float* c2w_host, int32_t n_kf, psl_cam_intr cam, float edge,
                               float* percent_host, void* stream);
+
+/* ---- multi-GPU exchange (BASELINE.json north_star: "periodic RCCL all-gather over xGMI of newly-added
+ * neural points").  The reference has no distributed code (no NCCL / torch.distributed call anywhere in it); frames are
+ * partitioned one per GPU and the replicas exchange record blocks.  librccl is resolved with dlopen at the first call.
+ *   psl_comm_unique_id : rank 0 obtains the 128-byte ncclUniqueId; the host hands it to every rank (any side channel)
+ *   psl_comm_init      : ncclCommInitRank on the ctx's device; the communicator lives in the ctx
+ *   psl_allgather_new_points : all-gather-v of per-rank record blocks [n_local][rec_floats] f32 (new points: xyz +
+ *                        32 geometry + 32 colour features + add-radius = 68 floats; touched feature rows: row id + 64
+ *                        changes) in rank order into rec_all [sum][rec_floats]; counts_host[world] receives the per-rank row
+ *                        counts.  nccl_comm: an ncclComm_t the host already owns (then `world` is its size), or NULL for
+ *                        the ctx's communicator.  Two ncclAllGather on `stream` (counts, padded records); synchronises
+ *                        `stream` once to learn the counts.  Returns the total number of rows (>= 0) or a psl_status. */
+int psl_comm_unique_id(void* id_out_128_bytes);
+int psl_comm_init(psl_ctx* ctx, const void* id_128_bytes, int rank, int world);
+int psl_comm_destroy(psl_ctx* ctx);
+int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world, const float* rec_local, int n_local, int rec_floats,
+                             float* rec_all, int capacity_rows, int32_t* counts_host, void* stream);
 
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);

@@ -16,8 +16,9 @@ class PslError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
-#                     full-image pixel indices in psl_track_args, step0_params in psl_map_args
+ABI_VERSION = 4     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
+#                     full-image pixel indices in psl_track_args, step0_params in psl_map_args; v4: psl_dedupe_count,
+#                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields
 EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 
 
@@ -104,6 +105,12 @@ _SIGS = {
     "psl_index_build": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psl_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p]),
+    "psl_dedupe_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "psl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "psl_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "psl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "psl_allgather_new_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.POINTER(C.c_int32), C.c_void_p]),
     "psl_frame_radii": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "psl_topgrad_select_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -36,6 +36,52 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// PSL_DEBUG_BLOCKS=<file>: per-workgroup trace of the first launches of every decode kernel / launch size, appended to
+// <file> as JSON lines {kernel, P, grid, color_tiles, threads, blocks: [[wall_start, wall_end, hw_id, cycles], ...]}
+// (wall clock: 100 MHz constant counter; tools/block_trace.py turns them into per-CU timelines)
+static const char* blk_trace_path() {
+  static const char* p = nullptr; static int init = 0;
+  if (!init) { p = getenv("PSL_DEBUG_BLOCKS"); if (p && !p[0]) p = nullptr; init = 1; }
+  return p;
+}
+static unsigned long long* g_blk_buf = nullptr; static int g_blk_cap = 0;
+int blk_trace_begin(DecodeArgs& a, int grid, hipStream_t s) {
+  a.blk = nullptr;
+  if (!blk_trace_path()) return PSL_OK;
+  if (g_blk_cap < grid) {
+    if (g_blk_buf) (void)hipFree(g_blk_buf);
+    PSL_HIP(hipMalloc(&g_blk_buf, sizeof(unsigned long long) * 4 * (size_t)grid)); g_blk_cap = grid;
+  }
+  PSL_HIP(hipMemsetAsync(g_blk_buf, 0, sizeof(unsigned long long) * 4 * (size_t)grid, s));
+  a.blk = g_blk_buf;
+  return PSL_OK;
+}
+int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_tiles, int threads) {
+  if (!a.blk) return PSL_OK;
+  static int seen[64][3]; static int n_seen = 0;      // (kernel hash, P) -> launches written
+  int kh = 0; for (const char* c = kernel; *c; ++c) kh = kh * 31 + *c;
+  int slot = -1;
+  kh = kh * 31 + a.flags;                              // colour-stage and geometry-stage launches of one size are different kernels
+  for (int i = 0; i < n_seen; ++i) if (seen[i][0] == kh && seen[i][1] == a.P) slot = i;
+  if (slot < 0 && n_seen < 64) { slot = n_seen++; seen[slot][0] = kh; seen[slot][1] = a.P; seen[slot][2] = 0; }
+  PSL_HIP(hipDeviceSynchronize());
+  if (slot < 0 || seen[slot][2] >= 3) return PSL_OK;
+  seen[slot][2]++;
+  unsigned long long* h = (unsigned long long*)malloc(sizeof(unsigned long long) * 4 * (size_t)grid);
+  PSL_HIP(hipMemcpy(h, a.blk, sizeof(unsigned long long) * 4 * (size_t)grid, hipMemcpyDeviceToHost));
+  FILE* f = fopen(blk_trace_path(), "a");
+  if (f) {
+    fprintf(f, "{\"kernel\": \"%s\", \"P\": %d, \"flags\": %d, \"grid\": %d, \"color_tiles\": %d, \"threads\": %d, \"blocks\": [", kernel, a.P, a.flags,
+            grid, color_tiles, threads);
+    for (int b = 0; b < grid; ++b)
+      fprintf(f, "%s[%llu,%llu,%llu,%llu]", b ? "," : "", h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
+    fprintf(f, "]}\n");
+    fclose(f);
+  }
+  free(h);
+  return PSL_OK;
+}
+
 int launch_decode_fwd(const DecodeArgs& a, hipStream_t s);
 int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s);
 int build_wt_index(psl_ctx* ctx, hipStream_t s);
@@ -137,7 +183,7 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
 using namespace psl;
 
 extern "C" const char* psl_last_error(void) { return g_err; }
-extern "C" int psl_abi_version(void) { return 3; }
+extern "C" int psl_abi_version(void) { return 4; }
 
 extern "C" int psl_param_count(void) { return kNumParams; }
 extern "C" int psl_param_color_count(void) { return kNumColorParams; }
@@ -202,10 +248,12 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   return PSL_OK;
 }
 
+extern "C" int psl_comm_destroy(psl_ctx* ctx);
 extern "C" void psl_destroy(psl_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)psl_comm_destroy(c);
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->coarse); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
   (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);

@@ -1,0 +1,138 @@
+// Multi-GPU exchange inside the library: RCCL all-gather-v of per-rank record blocks (new neural
+// points: position + both feature rows + add-radius; touched feature rows: row id + 64 changes) over xGMI.
+//
+// The reference has no distributed code; the construct is BASELINE.json's north_star (frame-parallel replicas with a
+// periodic all-gather of newly added neural points).  librccl is NOT a link-time dependency: it is resolved with dlopen at
+// the first psl_comm_* call (the copy torch has already loaded, when there is one), so a single-GPU process never
+// touches it.  A communicator is either created here (psl_comm_unique_id on rank 0 -> hand the 128 bytes to every rank by
+// any side channel -> psl_comm_init) or passed in by a host that owns one (ncclComm_t as void*).
+#include <dlfcn.h>
+#include <cstring>
+#include <algorithm>
+#include "psl_common.h"
+
+namespace psl {
+
+struct RcclId { char internal[128]; };           // ncclUniqueId (rccl.h:43), passed BY VALUE to ncclCommInitRank
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+constexpr int kNcclInt32 = 2, kNcclFloat32 = 7;   // ncclDataType_t (rccl.h:459-466)
+
+static int rccl_load() {
+  if (g_rccl.lib) return PSL_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);     // the instance torch.distributed already uses
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!h) { set_error("psl_comm: librccl not found (%s)", dlerror()); return PSL_ERR_UNSUPPORTED; }
+  Rccl r; r.lib = h;
+  r.GetUniqueId = (int (*)(RcclId*))dlsym(h, "ncclGetUniqueId");
+  r.CommInitRank = (int (*)(void**, int, RcclId, int))dlsym(h, "ncclCommInitRank");
+  r.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+  r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+  r.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
+    set_error("psl_comm: librccl lacks an expected symbol"); return PSL_ERR_UNSUPPORTED;
+  }
+  g_rccl = r;
+  return PSL_OK;
+}
+#define PSL_NCCL(call)                                                                         \
+  do {                                                                                         \
+    int e__ = (call);                                                                          \
+    if (e__ != 0) {                                                                            \
+      psl::set_error("%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(e__) : "?", __FILE__, __LINE__); \
+      return PSL_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+__global__ void k_set_int(int* d, int v) { if (threadIdx.x == 0) *d = v; }
+
+}  // namespace psl
+
+using namespace psl;
+
+extern "C" int psl_comm_unique_id(void* id_out) {
+  if (!id_out) { set_error("psl_comm_unique_id: null"); return PSL_ERR_ARG; }
+  int rc = rccl_load(); if (rc) return rc;
+  RcclId id;
+  PSL_NCCL(g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return PSL_OK;
+}
+
+extern "C" int psl_comm_init(psl_ctx* ctx, const void* id_in, int rank, int world) {
+  if (!ctx || !id_in || world < 1 || rank < 0 || rank >= world) { set_error("psl_comm_init: bad argument"); return PSL_ERR_ARG; }
+  if (ctx->comm) { set_error("psl_comm_init: this context already has a communicator"); return PSL_ERR_STATE; }
+  int rc = rccl_load(); if (rc) return rc;
+  PSL_HIP(hipSetDevice(ctx->device));
+  RcclId id; memcpy(&id, id_in, sizeof(id));
+  void* comm = nullptr;
+  PSL_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+  PSL_HIP(hipMalloc(&ctx->comm_counts, sizeof(int) * (size_t)(world + 1)));
+  return PSL_OK;
+}
+
+extern "C" int psl_comm_destroy(psl_ctx* ctx) {
+  if (!ctx) return PSL_ERR_ARG;
+  if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+  ctx->comm = nullptr;
+  if (ctx->comm_counts) (void)hipFree(ctx->comm_counts);
+  if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
+  ctx->comm_counts = nullptr; ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
+  return PSL_OK;
+}
+
+extern "C" int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world, const float* rec_local, int n_local,
+                                        int rec_floats, float* rec_all, int capacity_rows, int32_t* counts_host, void* stream) {
+  if (!ctx || n_local < 0 || rec_floats <= 0 || !counts_host || (n_local > 0 && !rec_local)) {
+    set_error("psl_allgather_new_points: bad argument"); return PSL_ERR_ARG;
+  }
+  void* comm = nccl_comm ? nccl_comm : ctx->comm;
+  if (!nccl_comm) world = ctx->comm_world;
+  if (!comm || world < 1) { set_error("psl_allgather_new_points: no communicator (psl_comm_init, or pass an ncclComm_t)"); return PSL_ERR_STATE; }
+  int rc = rccl_load(); if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (!ctx->comm_counts) PSL_HIP(hipMalloc(&ctx->comm_counts, sizeof(int) * (size_t)(world + 1)));
+  // 1. counts: one int per rank
+  int* d_mine = ctx->comm_counts + world;
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, s, d_mine, n_local);
+  PSL_LAUNCH_CHECK();
+  PSL_NCCL(g_rccl.AllGather(d_mine, ctx->comm_counts, 1, kNcclInt32, comm, s));
+  PSL_HIP(hipMemcpyAsync(counts_host, ctx->comm_counts, sizeof(int) * (size_t)world, hipMemcpyDeviceToHost, s));
+  PSL_HIP(hipStreamSynchronize(s));
+  long long total = 0; int n_max = 0;
+  for (int k = 0; k < world; ++k) { total += counts_host[k]; n_max = std::max(n_max, (int)counts_host[k]); }
+  if (total > capacity_rows) { set_error("psl_allgather_new_points: %lld rows exceed the capacity %d", total, capacity_rows); return PSL_ERR_CAPACITY; }
+  if (n_max == 0) return 0;
+  if (total > 0 && !rec_all) { set_error("psl_allgather_new_points: rec_all missing"); return PSL_ERR_ARG; }
+  // 2. records: ncclAllGather wants equal send counts -> every rank sends n_max rows out of a staging buffer (the padding
+  //    rows are never copied out); on point-to-point xGMI this exchange is latency-, not bandwidth-bound (<= 15 MB/rank)
+  const size_t row = (size_t)rec_floats, stage_floats = (size_t)(world + 1) * n_max * row;
+  if (ctx->comm_stage_cap < stage_floats) {
+    if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
+    ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
+    PSL_HIP(hipMalloc(&ctx->comm_stage, sizeof(float) * (stage_floats + stage_floats / 2)));
+    ctx->comm_stage_cap = stage_floats + stage_floats / 2;
+  }
+  float* send = ctx->comm_stage;                       // [n_max][row]
+  float* recv = ctx->comm_stage + (size_t)n_max * row; // [world][n_max][row]
+  if (n_local > 0) PSL_HIP(hipMemcpyAsync(send, rec_local, sizeof(float) * n_local * row, hipMemcpyDeviceToDevice, s));
+  PSL_NCCL(g_rccl.AllGather(send, recv, (size_t)n_max * row, kNcclFloat32, comm, s));
+  size_t off = 0;
+  for (int k = 0; k < world; ++k) {
+    if (counts_host[k] > 0)
+      PSL_HIP(hipMemcpyAsync(rec_all + off * row, recv + (size_t)k * n_max * row, sizeof(float) * counts_host[k] * row,
+                             hipMemcpyDeviceToDevice, s));
+    off += counts_host[k];
+  }
+  return (int)total;
+}

@@ -19,7 +19,23 @@ struct DecodeArgs {
   RenderWs ws;
   int spt;                   // real samples per workgroup tile (set by the launcher)
   unsigned long long* dbg;   // optional phase timestamps (PSL_DEBUG_PHASES=1)
+  unsigned long long* blk;   // optional per-workgroup trace [grid][4]: wall start, wall end, hw id, shader cycles (PSL_DEBUG_BLOCKS=<file>)
 };
+// per-workgroup trace: where the workgroups of a launch ran (XCC / SE / CU), when they started and how long they took
+struct BlkTrace {
+  unsigned long long w0, c0; bool on;
+  __device__ __forceinline__ BlkTrace(const DecodeArgs& a) : w0(0), c0(0), on(a.blk != nullptr && threadIdx.x == 0) {
+    if (on) { w0 = wall_clock64(); c0 = clock64(); }
+  }
+  __device__ __forceinline__ void done(const DecodeArgs& a) {
+    if (!on) return;
+    unsigned long long* o = a.blk + 4 * (size_t)blockIdx.x;
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    o[0] = w0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - c0;
+  }
+};
+int blk_trace_begin(DecodeArgs& a, int grid, hipStream_t s);                                  // psl_api.hip
+int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_tiles, int threads);
 #define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
 #ifdef PSL_FINE_STAMPS   // stamps inside the GEMM loops perturb scheduling: opt-in build (make EXTRA=-DPSL_FINE_STAMPS)
 #define PSL_STAMPF(i) PSL_STAMP(i)

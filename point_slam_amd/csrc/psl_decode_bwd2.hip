@@ -609,15 +609,18 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  BlkTrace bt(a);
   if (COLOR && (int)blockIdx.x < color_tiles) {
     color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE);
   } else {
     if (threadIdx.x >= 64) return;
     geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE);
   }
+  bt.done(a);
 }
 
-int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, float* small, hipStream_t s) {
+int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_grads& g, float* small, hipStream_t s) {
+  DecodeArgs a = a_in;
   Bwd2Out o;
   o.g_geo = g.g_geo_feats; o.g_col = g.g_col_feats; o.row_map = g.feat_row_map;
   o.g_brel = small;
@@ -637,6 +640,7 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
   static int dbg_on = -1;
   if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
   if (dbg_on && a.dbg) PSL_HIP(hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), s));
+  { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color) {
     if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
     else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
@@ -645,6 +649,7 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads
     else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
   }
   PSL_LAUNCH_CHECK();
+  { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on && a.dbg && color) {
     unsigned long long h[64];
     PSL_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));

@@ -522,6 +522,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 template <bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  BlkTrace bt(a);
   if (COLOR && (int)blockIdx.x < color_tiles) {
     color_tile(a, WF, smem, blockIdx.x * TILE);
   } else {
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(
     const int p0 = ((int)blockIdx.x - color_tiles) * TILE;
     geo_tile<COLOR ? 2 : 4>(a, WF, p0, !COLOR, !COLOR);
   }
+  bt.done(a);
 }
 
 // ------------------------------------------------------------------------------------------------ fragment buffers
@@ -610,11 +612,14 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
   }
   const size_t lds = sizeof(float) * Fwd2Lds::total;
   const int tiles = (a.P + TILE - 1) / TILE;
-  if (a.flags & PSL_STAGE_COLOR)
+  const bool color = a.flags & PSL_STAGE_COLOR;
+  { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
+  if (color)
     hipLaunchKernelGGL(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
   else
     hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
   PSL_LAUNCH_CHECK();
+  { int rc = blk_trace_end(a, "fwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on) {
     unsigned long long h[64];
     PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));

@@ -808,6 +808,53 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   if (lane == 0 && cnt_out) cnt_out[qi] = cnt;
 }
 
+// psl_dedupe_count: number of points with ORIGINAL index < idx_limit strictly inside the radius of each query -- the
+// admission test of add_neural_points (neural_point.py:116-121: "no existing point within the radius"), restricted to a
+// prefix of the cloud: the multi-GPU merge tests the other ranks' new locations against the BASE map while the index still
+// covers this rank's own tail, so that no rebuild is needed before the test.  One wavefront per query, whole r-cube
+// (an exact count, not a top-8), 64 rows of the cube per step.
+__global__ __launch_bounds__(256) void k_dedupe_count(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                      const int* __restrict__ cell_start, const int* __restrict__ coarse,
+                                                      const float* __restrict__ q, const float* __restrict__ r_per_query,
+                                                      float r_fixed, float r2_fixed, int nq, unsigned idx_limit,
+                                                      int* __restrict__ cnt_out) {
+  const int qi = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (qi >= nq) return;
+  const int lane = threadIdx.x & 63;
+  const GridMeta m = *meta;
+  float r, r2;
+  if (r_per_query) { r = r_per_query[qi]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  const float qx = q[qi * 3], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+  int cnt = 0;
+  if (!wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
+    CellBox bx;
+    box_of(m, qx, qy, qz, r, bx);
+    const int ny_b = bx.hi[1] - bx.lo[1] + 1;
+    const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
+    for (int rb = 0; rb < nrows; rb += 64) {
+      int beg = 0, end = 0;
+      const int row = rb + lane;
+      if (row < nrows) {
+        const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+        const int rowbase = (cz * m.ny + cy) * m.nx;
+        beg = cell_start[rowbase + bx.lo[0]];
+        end = cell_start[rowbase + bx.hi[0] + 1];
+      }
+      const int nr = min(64, nrows - rb);
+      for (int ri = 0; ri < nr; ++ri) {
+        const int b0 = __builtin_amdgcn_readlane(beg, ri), e0 = __builtin_amdgcn_readlane(end, ri);
+        for (int j = b0 + lane; j < e0; j += 64) {
+          const float4 c = spos[j];
+          cnt += (dist2(c.x, c.y, c.z, qx, qy, qz) < r2 && __float_as_uint(c.w) < idx_limit) ? 1 : 0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) cnt_out[qi] = cnt;
+}
+
 int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch size (default), 1 = one wavefront per sample, 2 = per ray
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
@@ -1005,6 +1052,18 @@ extern "C" int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, f
   if (!ctx || !q || nq < 0) { set_error("psl_knn: bad argument"); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("psl_knn: index is stale, call psl_index_build"); return PSL_ERR_STATE; }
   return knn_queries(ctx, q, r_per_query, r_scalar, nq, D_out, I_out, cnt_out, (hipStream_t)stream);
+}
+
+extern "C" int psl_dedupe_count(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, int idx_limit,
+                                int32_t* cnt_out, void* stream) {
+  if (!ctx || !q || !cnt_out || nq < 0 || idx_limit < 0) { set_error("psl_dedupe_count: bad argument"); return PSL_ERR_ARG; }
+  if (ctx->index_points != ctx->n_points) { set_error("psl_dedupe_count: index is stale, call psl_index_build"); return PSL_ERR_STATE; }
+  if (nq == 0) return PSL_OK;
+  if (ctx->n_points == 0 || idx_limit == 0) { PSL_HIP(hipMemsetAsync(cnt_out, 0, sizeof(int) * (size_t)nq, (hipStream_t)stream)); return PSL_OK; }
+  hipLaunchKernelGGL(k_dedupe_count, dim3((nq + 3) / 4), dim3(256), 0, (hipStream_t)stream, ctx->meta, ctx->spos, ctx->cell_start,
+                     ctx->coarse, q, r_per_query, r_scalar, r2_of(r_scalar), nq, (unsigned)idx_limit, cnt_out);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
 }
 
 extern "C" int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float* rays_d, int n_rays,

@@ -3,133 +3,276 @@ ROCm, "gloo" in the CPU tests), a full map replica per rank, and ONE exchange st
 (SURVEY.md §8e).  The reference has no distributed code at all (no NCCL / torch.distributed call anywhere in
 /root/reference); this mode is new functionality specified by BASELINE.json's north_star.
 
-What one exchange does (`FrameParallelSync.exchange`), identically on every rank:
+What one exchange does (`FrameParallelSync.exchange`), identically on every rank -- all of it O(new + touched), nothing
+scales with the size of the map:
 
- 1. NEW POINTS.  One fused, padded all-gather of [n_max, 68] fp32 records (position 3 + geometry feature 32 +
-    colour feature 32 + the add-radius of the point's location = 272 B per point) instead of one collective per
-    tensor: at <= 18 k new locations x 3 points per rank (14.7 MB) the exchange is latency-, not bandwidth-bound on
-    7 x 153 GB/s point-to-point links.  Only the tail [n_base, N) leaves the device structures (O(new), not O(N)).
+ 1. NEW POINTS.  One fused all-gather-v of [n, 68] fp32 records (position 3 + geometry feature 32 + colour feature 32 +
+    the add-radius of the point's location = 272 B per point) instead of one collective per tensor: at <= 18 k new
+    locations x 3 points per rank (14.7 MB) the exchange is latency-, not bandwidth-bound on 7 x 153 GB/s point-to-point
+    links.  Only the tail [n_base, N) leaves the device structures.
  2. CROSS-RANK DEDUPE.  Frames t and t+1 run on different ranks and see almost the same surfaces; each rank deduped
     only against its own replica.  The gathered blocks are therefore re-admitted in rank order: a location (its 3
-    points) of block k is kept iff its surface point has no neighbour within its add-radius among
+    points) of block k is kept iff its surface point has no neighbour strictly inside its add-radius among
     base + kept blocks 0..k-1 -- the reference's own rule (src/neural_point.py:116-121) applied across ranks, so the
-    min-distance invariant of the single-GPU map holds for the merged map.  Every rank runs the same deterministic
-    procedure on the same data: replicas end up identical (same points, same order, same feature rows).
- 3. FEATURES OF EXISTING POINTS.  Rows optimised by several ranks since the last exchange are reconciled by
-    averaging their CHANGES: new = snapshot + sum_k (feats_k - snapshot) / #{k : row changed on k}
-    (two all-reduces over the [N_base, 64] matrix: 256 MB at 1 M points, ~ms on xGMI, every ~50 frames).
- 4. COLOUR DECODER.  The same rule on the trainable colour-decoder blob (all-reduce mean of the per-rank changes):
-    features gathered from rank k were trained against rank k's decoder, so the decoders must not drift apart.
+    min-distance invariant of the single-GPU map holds for the merged map.  The test against the BASE map is ONE
+    `psl_dedupe_count` launch over all foreign locations on the index as it stands (restricted to point indices
+    < n_base: no rebuild before the test); the test against the few thousand points of the earlier kept blocks is a
+    brute-force distance matrix; the grid index is rebuilt ONCE, after every block has been admitted.  Every rank runs
+    the same deterministic procedure on the same data: replicas end up identical (same points, same order, same rows).
+ 3. FEATURES OF EXISTING POINTS.  A mapped frame trains only its frustum-selected rows (Mapper.py:346-360): the rows it
+    is ABOUT to train are snapshotted first (`note_rows`, compact: row ids + values, each row once per exchange
+    interval).  At the exchange a rank sends [n_changed, 1 + 64] records (row id, change of both feature rows) of the
+    rows whose values really moved; every rank then applies  new = snapshot + sum_k change_k / #{k : row changed on k}
+    in rank order (no atomics, no rank-dependent summation order: bit-identical replicas).
+ 4. COLOUR DECODER.  The same rule on the trainable colour-decoder blob (all-reduce of the per-rank changes, 109 k
+    floats): features gathered from rank k were trained against rank k's decoder, so the decoders must not drift apart.
 
-The collectives are issued through torch.distributed (which owns the RCCL communicator); the C ABI provides the
-pack / unpack ends (psl_points_download_range, psl_points_append, psl_knn for the dedupe test).
+Transport: torch.distributed collectives (the "nccl" backend IS RCCL on ROCm), or -- `transport="native"` /
+PSL_NATIVE_RCCL=1 -- `psl_allgather_new_points` inside libpointslam_hip.so on the library's own RCCL communicator
+(`psl_comm_init`; the 128-byte ncclUniqueId travels over torch.distributed once).
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
-REC = 3 + 32 + 32 + 1
+REC = 3 + 32 + 32 + 1          # new-point record: xyz, geometry feature, colour feature, add-radius
+REC_ROW = 1 + 64               # touched-row record: row id (int32 bits), change of the geometry + colour feature row
 
 
-def exchange_new_points(pos: torch.Tensor, geo: torch.Tensor, col: torch.Tensor, radius: Optional[torch.Tensor] = None,
-                        group=None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, List[int]]:
-    """All-gather-v of this rank's new points.  Returns (pos, geo, col, radius) of ALL ranks concatenated in rank
-    order and the per-rank counts.  Works on any backend/device torch.distributed supports."""
-    world = dist.get_world_size(group)
-    dev = pos.device
-    n = torch.tensor([pos.shape[0]], device=dev, dtype=torch.int64)
-    counts_t = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts_t, n, group=group)
-    counts = [int(c.item()) for c in counts_t]
-    n_max = max(max(counts), 1)
-    rec = torch.zeros(n_max, REC, device=dev, dtype=torch.float32)
-    if pos.shape[0]:
-        rec[:pos.shape[0], :3] = pos
-        rec[:pos.shape[0], 3:35] = geo
-        rec[:pos.shape[0], 35:67] = col
-        if radius is not None:
-            rec[:pos.shape[0], 67] = radius
-    out = [torch.empty_like(rec) for _ in range(world)]
-    dist.all_gather(out, rec, group=group)
-    blocks = [o[:c] for o, c in zip(out, counts)]
-    allrec = torch.cat(blocks, 0) if blocks else rec[:0]
-    return (allrec[:, :3].contiguous(), allrec[:, 3:35].contiguous(), allrec[:, 35:67].contiguous(),
-            allrec[:, 67].contiguous(), counts)
+# ------------------------------------------------------------------------------------------------------- transport
+class _TorchTransport:
+    """all-gather-v through torch.distributed: counts, then one padded all-gather."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def allgather_v(self, rec: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
+        dev, width = rec.device, rec.shape[1]
+        n = torch.tensor([rec.shape[0]], device=dev, dtype=torch.int64)
+        counts_t = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(counts_t, n, group=self.group)
+        counts = [int(c.item()) for c in counts_t]
+        n_max = max(counts)
+        if n_max == 0:
+            return rec[:0], counts
+        send = torch.zeros(n_max, width, device=dev, dtype=torch.float32)
+        send[:rec.shape[0]] = rec
+        out = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(out, send, group=self.group)
+        return torch.cat([o[:c] for o, c in zip(out, counts)], 0), counts
 
 
-def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True) -> List[int]:
+class _NativeTransport:
+    """all-gather-v inside libpointslam_hip.so (psl_allgather_new_points on the library's RCCL communicator)."""
+
+    def __init__(self, npc, group=None):
+        from . import _lib
+        self._lib, self.npc, self.group = _lib, npc, group
+        self.world, rank = dist.get_world_size(group), dist.get_rank(group)
+        L = _lib.lib()
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.psl_comm_unique_id(ident), "psl_comm_unique_id")
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)      # the only use of torch.distributed on this path
+        ident = C.create_string_buffer(box[0], 128)
+        _lib.check(L.psl_comm_init(npc.handle, ident, rank, self.world), "psl_comm_init")
+        self.buf = None
+
+    def allgather_v(self, rec: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
+        _lib, L = self._lib, self._lib.lib()
+        dev, width = rec.device, rec.shape[1]
+        rec = rec.contiguous()
+        counts = (C.c_int32 * self.world)()
+        need = max(4 * self.world * max(rec.shape[0], 1024), 65536)
+        if self.buf is None or self.buf.shape[0] < need or self.buf.shape[1] != width:
+            self.buf = torch.empty(need, width, device=dev, dtype=torch.float32)
+        while True:
+            rc = L.psl_allgather_new_points(self.npc.handle, None, 0, _lib.ptr(rec), rec.shape[0], width, _lib.ptr(self.buf),
+                                            self.buf.shape[0], counts, _lib.stream_ptr())
+            if rc == -3:       # PSL_ERR_CAPACITY: the counts are known now; every rank grows and repeats the same sequence
+                self.buf = torch.empty(2 * sum(counts) + 1024, width, device=dev, dtype=torch.float32)
+                continue
+            total = _lib.check(rc, "psl_allgather_new_points")
+            return self.buf[:total].clone(), [int(c) for c in counts]
+
+
+def make_transport(npc, group=None, kind: Optional[str] = None):
+    kind = kind or ("native" if os.environ.get("PSL_NATIVE_RCCL") == "1" else "torch")
+    if kind == "native":
+        return _NativeTransport(npc, group)
+    return _TorchTransport(group)
+
+
+# ------------------------------------------------------------------------------------------------------- new points
+def _sqdist_any_within(loc: torch.Tensor, r: torch.Tensor, pts: torch.Tensor, chunk: int = 1 << 24) -> torch.Tensor:
+    """True where some point of `pts` lies strictly inside radius r_i of loc_i; (dx*dx + dy*dy) + dz*dz in fp32, unfused
+    (every torch op is its own kernel), the arithmetic of the grid search."""
+    out = torch.zeros(loc.shape[0], dtype=torch.bool, device=loc.device)
+    if loc.shape[0] == 0 or pts.shape[0] == 0:
+        return out
+    step = max(1, chunk // max(pts.shape[0], 1))
+    r2 = r * r
+    for s in range(0, loc.shape[0], step):
+        d = loc[s:s + step, None, :] - pts[None, :, :]
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        out[s:s + step] = (d2 < r2[s:s + step, None]).any(1)
+    return out
+
+
+def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transport=None) -> List[int]:
     """Exchange the points `npc` gained since it had n_base points and rebuild the replica in global rank order
     (steps 1-2 of the module docstring).  Returns the number of points every rank CONTRIBUTED; the number admitted
     after the cross-rank dedupe is npc.pts_num() - n_base."""
+    tr = transport or _TorchTransport(group)
     n_now = npc.pts_num()
-    pos = npc.cloud_pos_device(n_base, n_now - n_base)          # tail only
-    geo = npc.get_geo_feats()[n_base:n_now]
-    col = npc.get_col_feats()[n_base:n_now]
-    rad = npc.point_radius(n_base, n_now - n_base)
-    p_all, g_all, c_all, r_all, counts = exchange_new_points(pos, geo, col, rad, group)
+    n_new = n_now - n_base
+    dev = npc.get_geo_feats().device
+    rec = torch.empty(n_new, REC, device=dev, dtype=torch.float32)
+    if n_new:
+        rec[:, :3] = npc.cloud_pos_device(n_base, n_new)          # tail only
+        rec[:, 3:35] = npc.get_geo_feats()[n_base:n_now]
+        rec[:, 35:67] = npc.get_col_feats()[n_base:n_now]
+        rec[:, 67] = npc.point_radius(n_base, n_new)
+    allrec, counts = tr.allgather_v(rec)
+    if sum(counts) == 0:
+        return counts                                             # nobody added anything: the replica stands as it is
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    keep = torch.ones(allrec.shape[0], dtype=torch.bool, device=dev)
+    if dedupe:
+        # locations are triplets (N_add = 3, neural_point.py:126-143); the middle point is the surface point
+        loc = allrec[:, :3].reshape(-1, 3, 3)[:, 1, :].contiguous()
+        rad = allrec[:, 67].reshape(-1, 3)[:, 1].contiguous()
+        first = next(k for k, c in enumerate(counts) if c > 0)    # the first non-empty block is admitted whole
+        lo = offs[first + 1] // 3
+        keep_loc = torch.ones(loc.shape[0], dtype=torch.bool, device=dev)
+        if lo < loc.shape[0] and n_base > 0:
+            # vs the BASE map: one launch on the index as it stands (it still covers this rank's own tail; indices
+            # >= n_base are ignored) -- no rebuild before the test
+            keep_loc[lo:] = npc.count_within(loc[lo:], rad[lo:], n_base) == 0
+        kept_pts = allrec[offs[first]:offs[first + 1], :3]
+        for k in range(first + 1, len(counts)):
+            if counts[k] == 0:
+                continue
+            a, b = offs[k] // 3, offs[k + 1] // 3
+            cand = keep_loc[a:b].clone()
+            if bool(cand.any()) and kept_pts.shape[0]:
+                idx = torch.nonzero(cand).flatten()
+                hit = _sqdist_any_within(loc[a:b][idx], rad[a:b][idx], kept_pts)
+                cand[idx[hit]] = False
+            keep_loc[a:b] = cand
+            blk = allrec[offs[k]:offs[k + 1], :3]
+            kept_pts = torch.cat([kept_pts, blk[cand[:, None].expand(-1, 3).reshape(-1)]], 0)
+        keep = keep_loc[:, None].expand(-1, 3).reshape(-1)
+    kept = allrec[keep]
     npc.truncate(n_base)
-    if n_now != n_base and hasattr(npc, "_build"):
-        # truncating invalidates the index; a rank whose own block is empty (or comes later) would otherwise run the
-        # dedupe test of the first foreign block against a stale index while its peers carry on -> desynchronised ranks
-        npc._build()
-    off = 0
-    for k, c in enumerate(counts):
-        pk, gk, ck, rk = p_all[off:off + c], g_all[off:off + c], c_all[off:off + c], r_all[off:off + c]
-        off += c
-        if c == 0:
-            continue
-        if dedupe and k > 0 and npc.pts_num() > 0:
-            # locations are triplets (N_add = 3, neural_point.py:126-143); the middle point is the surface point
-            loc = pk.reshape(-1, 3, 3)[:, 1, :].contiguous()
-            keep = npc.locations_free(loc, rk.reshape(-1, 3)[:, 1].contiguous())
-            keep3 = keep[:, None].expand(-1, 3).reshape(-1)
-            pk, gk, ck, rk = pk[keep3], gk[keep3], ck[keep3], rk[keep3]
-        npc.append_points(pk, gk, ck, radius=rk, build=True)    # the next block is tested against this one too
+    # ONE append and ONE index rebuild for all blocks (also when nothing was kept: truncate left the index stale)
+    npc.append_points(kept[:, :3].contiguous(), kept[:, 3:35].contiguous(), kept[:, 35:67].contiguous(),
+                      radius=kept[:, 67].contiguous(), build=True)
     return counts
 
 
+# ------------------------------------------------------------------------------------------------------- reconciliation
 class FrameParallelSync:
-    """State of the periodic reconciliation (steps 3-4): a snapshot of the feature rows and of the colour-decoder
-    blob as of the last exchange."""
+    """State of the periodic reconciliation: compact snapshots of the feature rows trained since the last exchange
+    (`note_rows`) and of the colour-decoder blob."""
 
-    def __init__(self, npc, theta: Optional[torch.Tensor] = None, n_color: int = 0, group=None):
+    def __init__(self, npc, theta: Optional[torch.Tensor] = None, n_color: int = 0, group=None,
+                 transport: Optional[str] = None):
         self.group = group
         self.n_color = n_color
-        self.snap_geo = npc.get_geo_feats().clone()
-        self.snap_col = npc.get_col_feats().clone()
+        self.transport = make_transport(npc, group, transport)
         self.snap_theta = theta[:n_color].clone() if theta is not None else None
         self.n_base = npc.pts_num()
+        self._slot = None           # int32 [capacity]: snapshot slot of a row, -1 = none (O(touched) to reset)
+        self._rows: List[torch.Tensor] = []
+        self._vals: List[torch.Tensor] = []
+        self._n_slots = 0
+        self.last_stats = {}
 
-    @staticmethod
-    def _avg_changes(cur: torch.Tensor, snap: torch.Tensor, group) -> torch.Tensor:
-        delta = cur - snap
-        changed = (delta != 0).any(dim=-1, keepdim=True).to(torch.float32) if delta.dim() > 1 else \
-            (delta != 0).to(torch.float32)
-        dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=group)
-        dist.all_reduce(changed, op=dist.ReduceOp.SUM, group=group)
-        return snap + delta / changed.clamp_min(1.0)
+    def note_rows(self, npc, rows: torch.Tensor):
+        """Rows about to be trained (HipSLAM.map calls this with the frustum selection before psl_map_iters): those that
+        have no snapshot yet in this exchange interval get one.  O(len(rows))."""
+        geo, col = npc.get_geo_feats(), npc.get_col_feats()
+        rows = rows.long()
+        rows = rows[rows < self.n_base]
+        if rows.numel() == 0:
+            return
+        cap = max(getattr(npc, "_max_points", 0) or 0, geo.shape[0])
+        if self._slot is None or self._slot.shape[0] < cap:
+            old = self._slot
+            self._slot = torch.full((cap,), -1, dtype=torch.int32, device=geo.device)
+            if old is not None:
+                self._slot[:old.shape[0]] = old
+        new = rows[self._slot[rows] < 0]
+        if new.numel() == 0:
+            return
+        new = torch.unique(new)
+        self._slot[new] = torch.arange(self._n_slots, self._n_slots + new.numel(), dtype=torch.int32, device=geo.device)
+        self._n_slots += int(new.numel())
+        self._rows.append(new)
+        self._vals.append(torch.cat([geo[new], col[new]], 1))
+
+    def _reconcile_rows(self, npc):
+        geo, col = npc.get_geo_feats(), npc.get_col_feats()
+        dev = geo.device
+        if self._rows:
+            rows, snap = torch.cat(self._rows), torch.cat(self._vals)
+            delta = torch.cat([geo[rows], col[rows]], 1) - snap
+            ch = (delta != 0).any(1)
+            rows_c, delta_c, snap_c = rows[ch], delta[ch], snap[ch]
+        else:
+            rows_c = torch.zeros(0, dtype=torch.int64, device=dev)
+            delta_c = snap_c = torch.zeros(0, 64, device=dev)
+        rec = torch.empty(rows_c.shape[0], REC_ROW, device=dev, dtype=torch.float32)
+        rec[:, 0] = rows_c.to(torch.int32).view(torch.float32)      # the id travels as raw bits (collectives only copy)
+        rec[:, 1:] = delta_c
+        allrec, counts = self.transport.allgather_v(rec)
+        self.last_stats = dict(rows_noted=int(self._n_slots), rows_sent=int(rows_c.shape[0]), rows_received=int(sum(counts)))
+        if sum(counts):
+            ids = allrec[:, 0].contiguous().view(torch.int32).long()
+            uniq, inv = torch.unique(ids, return_inverse=True)       # sorted: the same order on every rank
+            tot = torch.zeros(uniq.shape[0], 64, device=dev)
+            cnt = torch.zeros(uniq.shape[0], device=dev)
+            off, mine = 0, None
+            rank = dist.get_rank(self.group)
+            for k, c in enumerate(counts):                           # rank order; ids are unique inside a block: plain adds
+                if c:
+                    sl = inv[off:off + c]
+                    tot.index_add_(0, sl, allrec[off:off + c, 1:])
+                    cnt.index_add_(0, sl, torch.ones(c, device=dev))
+                    if k == rank:
+                        mine = sl
+                off += c
+            base = torch.cat([geo[uniq], col[uniq]], 1)              # rows this rank did not change still hold the snapshot
+            if mine is not None:
+                base[mine] = snap_c
+            new = base + tot / cnt[:, None]
+            geo[uniq] = new[:, :32]
+            col[uniq] = new[:, 32:]
+        if self._rows:
+            self._slot[torch.cat(self._rows)] = -1
+        self._rows, self._vals, self._n_slots = [], [], 0
 
     def exchange(self, npc, theta: Optional[torch.Tensor] = None, dedupe: bool = True) -> List[int]:
         """One exchange (all four steps).  `theta`: the master parameter blob, updated in place (colour group)."""
-        nb = self.n_base
         # 3. features of the points that existed at the last exchange
-        if nb:
-            geo = self._avg_changes(npc.get_geo_feats()[:nb], self.snap_geo[:nb], self.group)
-            col = self._avg_changes(npc.get_col_feats()[:nb], self.snap_col[:nb], self.group)
-            npc.get_geo_feats()[:nb] = geo
-            npc.get_col_feats()[:nb] = col
+        self._reconcile_rows(npc)
         # 4. colour decoder
         if theta is not None and self.snap_theta is not None:
             d = theta[:self.n_color] - self.snap_theta
             dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
             theta[:self.n_color] = self.snap_theta + d / dist.get_world_size(self.group)
         # 1-2. new points
-        counts = merge_new_points(npc, nb, self.group, dedupe)
-        self.snap_geo = npc.get_geo_feats().clone()
-        self.snap_col = npc.get_col_feats().clone()
+        counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport)
         if theta is not None:
             self.snap_theta = theta[:self.n_color].clone()
         self.n_base = npc.pts_num()

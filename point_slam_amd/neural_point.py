@@ -183,6 +183,19 @@ class HipNeuralPointCloud(object):
         _, _, cnt = self.find_neighbors_faiss(loc, step='add', dynamic_radius=radius)
         return cnt == 0
 
+    def count_within(self, loc, radius, idx_limit=None):
+        """Number of points with index < idx_limit (default: all) strictly inside radius_i of loc_i (psl_dedupe_count):
+        the admission test of add_neural_points restricted to a prefix of the cloud -- the multi-GPU merge tests foreign
+        locations against the base map on the index as it stands."""
+        q = loc.detach().float().contiguous()
+        rad = radius.detach().float().reshape(-1).contiguous()
+        n = q.shape[0]
+        cnt = torch.zeros(n, device=q.device, dtype=torch.int32)
+        lim = self.pts_num() if idx_limit is None else int(idx_limit)
+        _lib.check(_lib.lib().psl_dedupe_count(self._h, _lib.ptr(q), _lib.ptr(rad), float(self.radius_add), n, lim,
+                                               _lib.ptr(cnt), _lib.stream_ptr()), "psl_dedupe_count")
+        return cnt
+
     # ---- state upload (checkpoint / multi-GPU merge) ------------------------------------
     def set_points(self, pos: torch.Tensor, geo_feats: torch.Tensor = None, col_feats: torch.Tensor = None):
         """Replace the cloud by `pos` [N,3] (device tensor) and rebuild the index."""

@@ -90,6 +90,7 @@ class HipSLAM:
         self.last_losses = None
         self.map_step = dict(geo=0, col=0)
         self.n_mapped = 0
+        self.sync = None          # FrameParallelSync of the multi-GPU mode: told which rows a mapped frame is about to train
         # torch 1.12 (the reference's env.yaml) keeps zero .grad tensors after zero_grad(): from the second mapped frame
         # on its Adam counts the geometry-stage iterations for the colour decoder as well.  "torch2" (None gradients,
         # what the fixtures of this repo were generated with) is the default; see psl_map_args.step0_params.
@@ -385,6 +386,8 @@ class HipSLAM:
         n_geo = mp["geo_iter_first"] if first else int(n_iters * mp["geo_iter_ratio"])
         sel, row_map = self.frustum_select(frame, c2w)
         pix_per_frame = mp["pixels"] // len(window)
+        if self.sync is not None:
+            self.sync.note_rows(self.npc, sel)
         if self.engine == "native":
             self._map_native(window, sel, row_map, n_iters, pix_per_frame, n_geo=n_geo, first=first)
         else:

@@ -23,17 +23,25 @@ class FakeCloud:
     def get_col_feats(self): return self.col
     def point_radius(self, first=0, count=None): return self.rad[first:(None if count is None else first + count)]
 
-    def locations_free(self, loc, radius):
-        d2 = ((loc[:, None, :] - self.pos[None]) ** 2).sum(-1)
-        return (d2 < (radius * radius)[:, None]).sum(1) == 0
+    index_ok = True          # mirrors the native index: stale after truncate / append until the next build
+
+    def count_within(self, loc, radius, idx_limit=None):
+        assert self.index_ok, "neighbour test on a stale index"
+        pos = self.pos if idx_limit is None else self.pos[:idx_limit]
+        d2 = ((loc[:, None, :] - pos[None]) ** 2).sum(-1)
+        return (d2 < (radius * radius)[:, None]).sum(1)
 
     def truncate(self, n):
+        if n != self.pos.shape[0]:
+            self.index_ok = False
         self.pos, self.geo, self.col, self.rad = self.pos[:n], self.geo[:n], self.col[:n], self.rad[:n]
 
     def append_points(self, p, g, c, build=True, radius=None):
         r = radius if radius is not None else torch.full((p.shape[0],), 0.04)
         self.pos, self.geo, self.col, self.rad = (torch.cat([self.pos, p]), torch.cat([self.geo, g]),
                                                   torch.cat([self.col, c]), torch.cat([self.rad, r]))
+        self.index_ok = bool(build)
+        self.builds = getattr(self, "builds", 0) + (1 if build else 0)
 
 
 def _triplets(centres):
@@ -76,11 +84,26 @@ def _worker(rank, world, port, q):
     if rank == 0:
         cloud.append_points(torch.ones(3, 3) * 9, torch.ones(3, 32), torch.ones(3, 32))
     counts2 = merge_new_points(cloud, n0, dedupe=False)
+    # third exchange: rank 0 contributes NOTHING, rank 1 a location -- the first non-empty block is not block 0 (the
+    # stale-index case of round 2's advisor finding); and the dedupe test runs on a valid index on both ranks
+    n1 = cloud.pts_num()
+    builds0 = cloud.builds
+    if rank == 1:
+        cloud.append_points(_triplets(torch.tensor([[3.0, 3.0, 3.0]])), torch.ones(3, 32), torch.ones(3, 32))
+        builds0 = cloud.builds
+    counts2b = merge_new_points(cloud, n1)
+    assert counts2b == [0, 3] and cloud.pts_num() == n1 + 3 and cloud.index_ok
+    assert cloud.builds == builds0 + 1          # ONE rebuild per exchange, however many blocks
 
     # features / decoder reconciliation: rank 0 changes rows 0,1; rank 1 changes rows 1,2; both change theta
     theta = torch.arange(8, dtype=torch.float32)
     sync = FrameParallelSync(cloud, theta, n_color=6)
     geo_before = cloud.geo.clone()
+    # the rows a mapped frame is about to train are announced first (HipSLAM.map -> note_rows); row 5 is announced but
+    # never changes, row 2 is announced twice on rank 1
+    sync.note_rows(cloud, torch.tensor([0, 1, 5]) if rank == 0 else torch.tensor([1, 2]))
+    if rank == 1:
+        sync.note_rows(cloud, torch.tensor([2, 6]))
     if rank == 0:
         cloud.geo[0] += 1.0; cloud.geo[1] += 2.0; theta[:6] += 1.0; theta[6:] += 100.0
     else:
@@ -108,7 +131,7 @@ def test_exchange_new_points_world2():
     # rank 1's duplicate location was dropped on BOTH ranks: 10 base + 3 (rank 0) + 3 (rank 1's second location)
     assert n0 == n1 == 16
     assert torch.equal(pos0, pos1) and torch.equal(geo0, geo1)          # identical replicas, identical order
-    assert pos0.shape[0] == 16 + 3
+    assert pos0.shape[0] == 16 + 3 + 3
     assert torch.equal(pos0[10:13], own0) and torch.equal(pos0[13:16], own1[3:6])   # rank order, kept block
     # min-distance invariant across ranks: no surface point of a later block inside 4 cm of an earlier block's points
     assert float(((pos0[14] - pos0[10:13]) ** 2).sum(-1).min()) > 0.04 ** 2

@@ -58,6 +58,7 @@ def _worker(rank, world, port, q):
         kept = int(npc.add_neural_points(ro.contiguous(), rd.contiguous(), gd, torch.zeros(4000, 3, device=dev),
                                          dynamic_radius=rad))
         # each rank also "optimises" some base rows and its decoder
+        sync.note_rows(npc, torch.arange(rank, rank + 2, device=dev))        # what HipSLAM.map does with its frustum selection
         npc.get_geo_feats()[rank:rank + 2] += 1.0 + rank
         theta[:12] += 1.0 + 2 * rank
         counts = sync.exchange(npc, theta)
@@ -113,3 +114,61 @@ def test_exchange_on_real_point_cloud_two_ranks():
     assert torch.allclose(a[7][:12], torch.arange(12, dtype=torch.float32) + 2.0)
     from tests.test_hip_parity import report
     report(test="dist_real_cloud", kept=[kept0, kept1], admitted_rank1=admitted1 // 3, N=N)
+
+
+def _native_worker(port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from point_slam_amd import synthetic as syn
+        from point_slam_amd.dist import FrameParallelSync, _TorchTransport
+        from point_slam_amd.neural_point import HipNeuralPointCloud
+        from tests.helpers import base_cfg
+        dev = torch.device("cuda:0")
+        cfg = base_cfg()
+        cfg["mapping"] = dict(cfg["mapping"], device="cuda:0")
+        cam = syn.intrinsics(320, 240)
+        npc = HipNeuralPointCloud(cfg, max_points=100000, device="cuda:0")
+        base = syn.seed_cloud(cam, 20000, n_views=4, seed=3)
+        g = torch.Generator().manual_seed(9)
+        npc.set_points(base.to(dev), torch.randn(base.shape[0], 32, generator=g).to(dev),
+                       torch.randn(base.shape[0], 32, generator=g).to(dev))
+        theta = torch.arange(16, dtype=torch.float32, device=dev)
+        sync = FrameParallelSync(npc, theta, n_color=12, transport="native")      # psl_comm_unique_id / psl_comm_init
+        # the library's all-gather-v against torch.distributed's on the same records
+        rec = torch.randn(777, 68, generator=g).to(dev)
+        got, counts = sync.transport.allgather_v(rec)
+        ref, counts_t = _TorchTransport().allgather_v(rec)
+        empty, counts_e = sync.transport.allgather_v(rec[:0])
+        # and a whole exchange over it: new points + a touched row
+        n_base = npc.pts_num()
+        new = base[:300].to(dev) + torch.tensor([10.0, 0.0, 0.0], device=dev)
+        npc.append_points(new, torch.ones(300, 32, device=dev), torch.ones(300, 32, device=dev))
+        sync.note_rows(npc, torch.tensor([4, 5], device=dev))
+        npc.get_geo_feats()[4] += 2.0
+        c = sync.exchange(npc, theta)
+        torch.cuda.synchronize()
+        q.put((bool(torch.equal(got, ref)), counts, counts_t, int(empty.shape[0]), counts_e, c, npc.pts_num() - n_base,
+               float(npc.get_geo_feats()[4, 0].cpu() - torch.randn(1).item() * 0), sync.last_stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_transport_single_rank():
+    """psl_comm_unique_id -> psl_comm_init -> psl_allgather_new_points on a ONE-rank RCCL communicator (this box has one
+    GPU and RCCL refuses two ranks on one device): librccl is found with dlopen, the communicator comes up, the padded
+    all-gather returns the records and counts torch.distributed returns, and a whole exchange runs over it.  The N > 1
+    leg of the same code is what `PSL_NATIVE_RCCL=1 python bench.py --gpus N` runs on a multi-GPU node."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_worker, args=(port, q))
+    p.start()
+    same, counts, counts_t, n_empty, counts_e, c, admitted, _, stats = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert same and counts == counts_t == [777]
+    assert n_empty == 0 and counts_e == [0]
+    assert c == [300] and admitted == 300
+    assert stats["rows_noted"] == 2 and stats["rows_sent"] == 1 and stats["rows_received"] == 1
