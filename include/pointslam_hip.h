@@ -296,7 +296,8 @@ int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream);
 
 /* Mapper.get_mask_from_c2w (src/Mapper.py:120-168): frustum feature selection.  c2w_host: [16] row-major 4x4
  * (host memory).  Writes the ascending index list sel_out[<=N] and row_map_out[N]; synchronises and returns
- * the count.  depth_max = max of the depth image (:161-162). */
+ * the count.  Points whose bilinear lookup is 0 take depth_max (:161-162: np.max over the PER-POINT lookups): pass a negative
+ * depth_max to have that maximum taken on the device (the reference's rule), or a value >= 0 to impose one. */
 int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host, psl_cam_intr cam, const float* depth, float depth_max,
                             float edge, int32_t* sel_out, int32_t* row_map_out, int* n_sel_host, void* stream);
 

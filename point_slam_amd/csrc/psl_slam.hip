@@ -622,22 +622,22 @@ __global__ __launch_bounds__(128) void k_exposure_step(float* mlp, float* feats,
 // ------------------------------------------------------------------ frustum feature selection
 // Mapper.get_mask_from_c2w (src/Mapper.py:120-168): project every neural point with the frame pose, bilinear
 // sensor-depth lookup (cv2.remap INTER_LINEAR, constant-0 border), keep points inside the (edge-enlarged) image
-// whose camera depth lies in [0, depth+0.5].  Zero depths are replaced by the image maximum (:161-162).
-__global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
-                                                       psl_cam_intr cam, const float* __restrict__ depth, float depth_max,
-                                                       float edge, int* __restrict__ flags) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pos[i];
+// whose camera depth lies in [0, depth+0.5].  Zero lookups are replaced by the maximum over the per-point lookups
+// (:161-162).
+// projection + bilinear sensor-depth lookup of one point (cv2.remap INTER_LINEAR, constant-0 border)
+struct FrustumPt { float u, v, d, mz; };
+__device__ __forceinline__ FrustumPt frustum_point(const float4 p, const float* __restrict__ w2c, const psl_cam_intr& cam,
+                                                  const float* __restrict__ depth) {
   double x = (double)w2c[0] * p.x + (double)w2c[1] * p.y + (double)w2c[2] * p.z + (double)w2c[3];
   double y = (double)w2c[4] * p.x + (double)w2c[5] * p.y + (double)w2c[6] * p.z + (double)w2c[7];
   double zc = (double)w2c[8] * p.x + (double)w2c[9] * p.y + (double)w2c[10] * p.z + (double)w2c[11];
   x = -x;                                  // cam_cord[:, 0] *= -1
   double z = zc + 1e-5;
-  float u = (float)(((double)cam.fx * x + (double)cam.cx * zc) / z);
-  float v = (float)(((double)cam.fy * y + (double)cam.cy * zc) / z);
-  float u0 = floorf(u), v0 = floorf(v);
-  float fu = u - u0, fv = v - v0;
+  FrustumPt o;
+  o.u = (float)(((double)cam.fx * x + (double)cam.cx * zc) / z);
+  o.v = (float)(((double)cam.fy * y + (double)cam.cy * zc) / z);
+  float u0 = floorf(o.u), v0 = floorf(o.v);
+  float fu = o.u - u0, fv = o.v - v0;
   float d = 0.f;
 #pragma unroll
   for (int dv = 0; dv < 2; ++dv)
@@ -652,10 +652,35 @@ __global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict_
       if (ok) val = depth[(size_t)(int)vf * cam.W + (int)uf];
       d += val * (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
     }
-  if (d == 0.f) d = depth_max;
-  bool inb = (u < (float)cam.W - edge) && (u > edge) && (v < (float)cam.H - edge) && (v > edge);
-  float mz = (float)(-z);
-  flags[i] = (inb && mz >= 0.f && mz <= d + 0.5f) ? 1 : 0;
+  o.d = d;
+  o.mz = (float)(-z);
+  return o;
+}
+
+// np.max(depths) of Mapper.py:161-162: the maximum over the PER-POINT lookups (not over the image); non-negative floats
+// order like their bit patterns
+__global__ __launch_bounds__(256) void k_frustum_dmax(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
+                                                      psl_cam_intr cam, const float* __restrict__ depth, unsigned* dmax_bits) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float d = 0.f;
+  if (i < n) { d = frustum_point(pos[i], w2c, cam, depth).d; if (!(d >= 0.f)) d = 0.f; }
+  unsigned b = __float_as_uint(d);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
+  if ((threadIdx.x & 63) == 0 && b) atomicMax(dmax_bits, b);
+}
+
+__global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
+                                                       psl_cam_intr cam, const float* __restrict__ depth, float depth_max,
+                                                       const unsigned* __restrict__ dmax_bits, float edge,
+                                                       int* __restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const FrustumPt f = frustum_point(pos[i], w2c, cam, depth);
+  float d = f.d;
+  if (d == 0.f) d = dmax_bits ? __uint_as_float(*dmax_bits) : depth_max;
+  bool inb = (f.u < (float)cam.W - edge) && (f.u > edge) && (f.v < (float)cam.H - edge) && (f.v > edge);
+  flags[i] = (inb && f.mz >= 0.f && f.mz <= d + 0.5f) ? 1 : 0;
 }
 
 // ordered compaction of flags -> sel[n_sel] (ascending point index) and row_map[n] (-1 = not selected)
@@ -1180,8 +1205,14 @@ extern "C" int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host /*[16
   float* w2c_dev = ctx->d_small;   // 12 floats
   PSL_HIP(hipMemcpyAsync(w2c_dev, w2c, sizeof(w2c), hipMemcpyHostToDevice, s));
   int* flags = ctx->cell_of;   // free between index builds
+  unsigned* dmax_bits = nullptr;
+  if (depth_max < 0.f) {       // the reference's rule: maximum over the per-point lookups, taken on the device
+    dmax_bits = (unsigned*)(ctx->d_counter + 1);
+    PSL_HIP(hipMemsetAsync(dmax_bits, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_frustum_dmax, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth, dmax_bits);
+  }
   hipLaunchKernelGGL(k_frustum_flags, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth,
-                     depth_max, edge, flags);
+                     depth_max, dmax_bits, edge, flags);
   hipLaunchKernelGGL(k_flag_block_sums, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags);
   hipLaunchKernelGGL(k_flag_scan_top, dim3(1), dim3(1024), 0, s, ctx->scan_flags, nblk, ctx->d_counter);
   hipLaunchKernelGGL(k_flag_compact, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags, sel_out, row_map_out);

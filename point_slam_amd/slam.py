@@ -323,33 +323,33 @@ class HipSLAM:
 
     def frustum_select(self, frame: Frame, c2w: torch.Tensor):
         """Mapper.get_mask_from_c2w (Mapper.py:120-168) on the device: returns (sel int32[n_sel], row_map int32[N]).
-        Points whose bilinear depth lookup is 0 take the maximum over the per-point lookups (:161-162); the image
-        maximum bounds it from above and is what the kernel is given."""
+        Points whose bilinear depth lookup is 0 take the maximum over the PER-POINT lookups (:161-162), reduced on the
+        device (depth_max = -1)."""
         L = _lib.lib()
         N = self.npc.pts_num()
         sel = torch.empty(N, dtype=torch.int32, device=self.device)
         row_map = torch.empty(N, dtype=torch.int32, device=self.device)
         c2w_h = (C.c_float * 16)(*c2w.detach().float().cpu().reshape(-1).tolist())
         n_sel = C.c_int(0)
-        dmax = float(frame.depth.max())
-        _lib.check(L.psl_frustum_select_sync(self.npc.handle, c2w_h, self.cam_intr, _lib.ptr(frame.depth), dmax,
+        _lib.check(L.psl_frustum_select_sync(self.npc.handle, c2w_h, self.cam_intr, _lib.ptr(frame.depth), -1.0,
                                              float(self.cfg["mapping"]["frustum_edge"]), _lib.ptr(sel),
                                              _lib.ptr(row_map), C.byref(n_sel), _lib.stream_ptr()),
                    "psl_frustum_select_sync")
         return sel[:n_sel.value], row_map
 
-    def select_window(self, frame: Frame, c2w=None) -> List[Frame]:
+    def select_window(self, frame: Frame, c2w=None, size=None, method=None) -> List[Frame]:
         """Keyframe selection of Mapper.optimize_map (:263-276): mapping_window_size-2 keyframes among all but the last
         one -- at random ('global', random_select) or among those that overlap the current view ('overlap',
         keyframe_selection_overlap :170-235: 200 pixels x 8 frustum samples projected into every keyframe, the
         overlapping ones in random order) -- then the last keyframe and the current frame."""
         mp = self.cfg["mapping"]
-        k = mp["mapping_window_size"] - 2
+        k = (size or mp["mapping_window_size"]) - 2
+        method = method or mp.get("keyframe_selection_method", "overlap")
         win: List[Frame] = []
         if len(self.keyframes) > 0:
             older = self.keyframes[:-1]
             if older and k > 0:
-                if mp.get("keyframe_selection_method", "overlap") == "overlap" and c2w is not None:
+                if method == "overlap" and c2w is not None:
                     from . import frame_ops
                     cam = self.cam
                     idx = torch.randint(cam["H"] * cam["W"], (200,), device=self.device)
@@ -395,7 +395,28 @@ class HipSLAM:
         self.n_mapped += 1
         return added, int(sel.shape[0])
 
-    def _map_native(self, window, sel, row_map, n_iters, ppf, draws=None, n_geo=None, first=False):
+    def refine(self, frame: Frame, c2w: torch.Tensor, n_outer=5, n_iters=None):
+        """End-of-run colour refinement (Mapper.run, Mapper.py:706-720,740-747; optimize_map :316,:346-360,:427-430):
+        five optimize_map calls with twice the iterations over a window of twice the size drawn at random from ALL
+        keyframes ('global'), no point adding, no frustum selection (every row of both feature sets sits in the optimiser),
+        colour decoder frozen, geo_iter_ratio 0 (iteration 0 still runs stage 'geometry', :420-421), geometry lr 0 and
+        colour lr = color_lr / 10 in both stages.  Native engine: psl_map_iters with sel = all rows."""
+        if self.engine != "native":
+            raise NotImplementedError("HipSLAM.refine runs on the native engine")
+        mp = self.cfg["mapping"]
+        frame.c2w = c2w
+        n_iters = n_iters or 2 * mp["iters"]
+        N = self.npc.pts_num()
+        sel = torch.arange(N, dtype=torch.int32, device=self.device)
+        lr = dict(geo_geo=0.0, geo_col=0.0, col=mp["stage"]["color"]["color_lr"] / 10.0, dec=mp["stage"]["color"]["decoders_lr"])
+        for _ in range(n_outer):
+            window = self.select_window(frame, None, size=2 * mp["mapping_window_size"], method="global")
+            ppf = mp["pixels"] // len(window)
+            self._map_native(window, sel, sel, n_iters, ppf, n_geo=0, lr=lr, train_decoder=False)
+        return n_outer * n_iters
+
+    def _map_native(self, window, sel, row_map, n_iters, ppf, draws=None, n_geo=None, first=False, lr=None,
+                    train_decoder=None):
         L = _lib.lib()
         mp, cam, dev = self.cfg["mapping"], self.cam, self.device
         W = len(window)
@@ -427,9 +448,11 @@ class HipSLAM:
         a.adam_geo, a.adam_col, a.adam_params = adam_geo.data_ptr(), adam_col.data_ptr(), adam_par.data_ptr()
         a.step0_geo, a.step0_col = 0, 0
         a.step0_params = (a.n_geo_iters + 1) if (self.adam_zero_grad_semantics == "torch1" and self.n_mapped > 0) else 0
-        a.train_decoder = 0 if mp["fix_color_decoder"] else 1
+        a.train_decoder = (0 if mp["fix_color_decoder"] else 1) if train_decoder is None else int(bool(train_decoder))
         a.lr_geo_geo_stage, a.lr_geo_color_stage = st["geometry"]["geometry_lr"], st["color"]["geometry_lr"]
         a.lr_col, a.lr_decoder = st["color"]["color_lr"], st["color"]["decoders_lr"]
+        if lr is not None:          # colour refinement (Mapper.py:427-430)
+            a.lr_geo_geo_stage, a.lr_geo_color_stage, a.lr_col, a.lr_decoder = lr["geo_geo"], lr["geo_col"], lr["col"], lr["dec"]
         a.w_color, a.sigmoid_coef = mp["w_color_loss"], self.cfg["rendering"]["sigmoid_coef_mapper"]
         a.ws, a.loss_out = self._ws_map.data_ptr(), losses.data_ptr()
         keep_ex = None

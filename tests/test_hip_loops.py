@@ -93,6 +93,59 @@ def test_map_iters_native_matches_reference_loop(case):
         assert rep["exposure_abs"] < 1e-4 and rep["exposure_mlp_abs"] < 2e-3
 
 
+def test_colour_refinement_native_matches_reference():
+    """HipSLAM's end-of-run refinement step (psl_map_iters with sel = all rows, geometry lr 0, colour lr / 10, decoder
+    frozen, iteration 0 in stage 'geometry') vs the reference's optimize_map(color_refine=True) (fixture
+    mapper_refine_replica, Mapper.py:706-720,427-430)."""
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    fx = load_npz("mapper_refine_replica")
+    cfg, cam = loop_cfg(fx), loop_cam(fx)
+    s = _slam(cfg, cam, fx, dev, fx["cfg_name"])
+    window = [Frame(k, f["depth"].to(dev), f["color"].to(dev), r_query=f["r_query"].to(dev), c2w=f["c2w"].to(dev))
+              for k, f in enumerate(mapper_frames(fx, False))]
+    N = s.npc.pts_num()
+    sel = torch.arange(N, dtype=torch.int32, device=dev)
+    n_iters, ppf = fx["n_iters"], fx["mapping_pixels"] // 3
+    draws = (fx["pix"].to(dev).int().reshape(n_iters, 3 * ppf).contiguous(), fx["fb"].to(dev).contiguous())
+    st = cfg["mapping"]["stage"]["color"]
+    theta0 = s.theta.clone()
+    s._map_native(window, sel, sel, n_iters, ppf, draws=draws, n_geo=0, train_decoder=False,
+                  lr=dict(geo_geo=0.0, geo_col=0.0, col=st["color_lr"] / 10.0, dec=st["decoders_lr"]))
+    torch.cuda.synchronize()
+    ls = s.last_losses.cpu().double()[:, 0]
+    rel = (ls - fx["ref_losses"]).abs() / fx["ref_losses"].abs()
+    dc = (s.npc.col_feats.cpu() - fx["ref_col_final"]).abs()
+    rep = dict(test="colour_refinement_vs_reference", loss_rel_first=float(rel[0]), loss_rel_max=float(rel.max()),
+               col_max=float(dc.max()), col_frac_gt_1e5=float((dc > 1e-5).float().mean()),
+               col_moved=float((fx["ref_col_final"] - fx["col"]).abs().max()))
+    report(**rep)
+    assert rep["loss_rel_first"] < 1e-5 and rep["loss_rel_max"] < 1e-4
+    assert torch.equal(s.npc.geo_feats.cpu(), fx["geo"])           # geometry lr 0: bit-identical rows
+    assert torch.equal(s.theta, theta0)                            # frozen decoder
+    assert rep["col_max"] < 1e-3 and rep["col_frac_gt_1e5"] < 5e-3
+
+
+def test_refine_runs_five_passes_over_all_rows():
+    """HipSLAM.refine: 5 x (2 x iters) iterations, 'global' window of twice the size, all N rows trainable, nothing added."""
+    from point_slam_amd.slam import Frame, HipSLAM
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _long_scene(dev, n_pts=30000)
+    cfg["mapping"].update(iters=6, pixels=300, mapping_window_size=2)
+    s = HipSLAM(cfg, cam, device="cuda:0", max_points=100000, engine="native")
+    s.seed_points(pts, seed=3)
+    s.keyframes = [frames[0], frames[1]]
+    geo0, col0, theta0, n0 = s.npc.geo_feats.clone(), s.npc.col_feats.clone(), s.theta.clone(), s.npc.pts_num()
+    total = s.refine(frames[2], frames[2].c2w)
+    torch.cuda.synchronize()
+    assert total == 5 * 12 and s.npc.pts_num() == n0
+    assert torch.equal(s.npc.geo_feats, geo0) and torch.equal(s.theta, theta0)
+    moved = (s.npc.col_feats != col0).any(1)
+    assert int(moved.sum()) > 1000                                 # colour rows all over the views moved ...
+    assert float((s.npc.col_feats - col0).abs().max()) < 5 * 12 * cfg["mapping"]["stage"]["color"]["color_lr"] / 10 * 1.01
+    assert bool(torch.isfinite(s.last_losses).all())
+
+
 @pytest.mark.parametrize("case", ["tracker_iters_tum", "tracker_iters_scannet"])
 def test_track_iters_native_matches_reference_loop(case):
     from point_slam_amd.slam import Frame

@@ -136,6 +136,47 @@ def test_frustum_select_matches_oracle():
     assert torch.equal(got, torch.sort(got).values)
 
 
+def test_frustum_select_uses_the_per_point_depth_maximum():
+    """Mapper.py:161-162: points whose bilinear depth lookup is 0 (sensor holes) take np.max over the PER-POINT lookups, not
+    the image maximum.  A frame whose depth image holds a far outlier region that no map point projects into tells the two
+    rules apart: with the image maximum every point behind a hole would be selected (round 2's superset)."""
+    from oracle import pointslam_oracle as O
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    fr0 = frames[1]
+    H, W = cam["H"], cam["W"]
+    # drop the cloud points that project into the top-left 40 x 40 pixels, then put a 100 m outlier there
+    w2c = torch.linalg.inv(fr0.c2w.cpu().double())
+    pc = (w2c[:3, :3] @ pts.double().T + w2c[:3, 3:4]).T
+    z = pc[:, 2] + 1e-5
+    u = (cam["fx"] * (-pc[:, 0]) + cam["cx"] * pc[:, 2]) / z
+    v = (cam["fy"] * pc[:, 1] + cam["cy"] * pc[:, 2]) / z
+    corner = (u > -2) & (u < 42) & (v > -2) & (v < 42) & (z < 0)
+    cloud = pts[~corner]
+    g = torch.Generator().manual_seed(8)
+    depth = fr0.depth.cpu() * 0.5                      # the sensor sees closer surfaces than the map holds
+    depth[torch.rand(H, W, generator=g) < 0.15] = 0.0  # holes
+    depth[:40, :40] = 100.0
+    fr = Frame(1, depth.to(dev), fr0.color, fr0.r_add, fr0.r_query, fr0.c2w)
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(cloud)
+    sel, _ = s.frustum_select(fr, fr.c2w)
+    got = set(sel.cpu().tolist())
+    ref = set(O.frustum_select(cloud, fr.c2w.cpu(), depth, H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                               cfg["mapping"]["frustum_edge"]).tolist())
+    # what the image-maximum rule would select
+    d_pt = O.bilinear_zero_border(depth, u[~corner].float(), v[~corner].float())
+    inb = (u[~corner] < W + 4) & (u[~corner] > -4) & (v[~corner] < H + 4) & (v[~corner] > -4)
+    mz = (-z[~corner]).float()
+    loose = set(torch.nonzero(inb & (mz >= 0) & (mz <= torch.where(d_pt == 0, torch.tensor(100.0), d_pt) + 0.5)).flatten().tolist())
+    report(test="frustum_per_point_max", n_sel=len(got), n_ref=len(ref), n_image_max_rule=len(loose), sym_diff=len(got ^ ref),
+           per_point_max=float(d_pt.max()))
+    assert float(d_pt.max()) < 10.0                    # no point sees the outlier
+    assert len(loose) > len(ref) + 1000                # the rules differ on this frame
+    assert len(got ^ ref) <= max(3, len(ref) // 2000)
+
+
 def test_frustum_select_points_in_the_camera_plane():
     """Points whose camera-space z is ~0 project to +-inf / NaN pixel coordinates (Mapper.py:150-153 divides by
     z + 1e-5).  The reference drops them (cv2.remap outside the image -> 0, mask false); a float->int conversion of such
@@ -225,10 +266,11 @@ def test_map_native_matches_dropin():
     assert torch.equal(n[0][mask], n[4][mask]) and torch.equal(n[1][mask], n[5][mask])
 
 
-def _map_switch_runs(n_it, variants, dev):
+def _map_switch_runs(n_it, variants, dev, frozen_decoder=False):
     """psl_map_iters on the small scene with the A/B switches of `variants` ({name: {option: value}}); the same draws."""
     from point_slam_amd import _lib
     cfg, cam, frames, pts = _scene(dev)
+    cfg["mapping"]["fix_color_decoder"] = bool(frozen_decoder)
     L = _lib.lib()
     res, draws = {}, None
     keys = (b"lazy_adam", b"dw_fused", b"knn_overlap")
@@ -268,15 +310,20 @@ def test_map_native_scheduling_switches_agree():
     reduction inside the Adam launch, the k-NN prefetch of the next block on the side stream (throttled, a wavefront walks
     several rays) -- change WHEN things are computed, not what.  Runs differ by the order of the float atomics of the
     feature scatter, and Adam amplifies that noise (rows with tiny gradients move ~lr per step in a direction the noise
-    decides), so the yardstick is a second run of the SAME configuration:
-      * 24 iterations (replay gaps up to ~20 steps, noise still small): lazy vs dense Adam within 3x the noise;
-      * 150 iterations (three prefetch blocks, both stages, decoder training): every switch within 3x the noise."""
+    decides):
+      * 24 iterations (replay gaps up to ~20 steps, decoder training, noise still small): every switch within 3x the
+        difference between two runs of the SAME configuration;
+      * 150 iterations (three prefetch blocks, both stages) with the colour decoder FROZEN -- the decoder group is what
+        amplifies rounding noise chaotically (tests/test_hip_loops.py::test_map_iters_140_iterations_vs_oracle anchors
+        those long loops to the oracle instead) -- every switch agrees with the default to 2e-5.
+    (Round 2 compared 150 decoder-training iterations against a same-configuration noise yardstick: two draws of a
+    chaotic quantity, no discriminating power and a flaky bound.)"""
     dev = torch.device("cuda:0")
     keys = ("loss_rel_max", "loss_rel_mean", "geo_mean", "col_mean", "geo_frac_gt_1e3", "col_frac_gt_1e3")
-    for n_it, variants in ((24, {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0}}),
-                           (150, {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0},
-                                  "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0}})):
-        res = _map_switch_runs(n_it, variants, dev)
+    all_variants = {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0},
+                    "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0}}
+    for n_it, variants, frozen in ((24, all_variants, False), (150, all_variants, True)):
+        res = _map_switch_runs(n_it, variants, dev, frozen_decoder=frozen)
         ref = res["all_on"]
         # it optimised: the depth term (the total switches definition with the stage) went down
         assert bool(torch.isfinite(ref[0]).all()) and float(ref[4][-8:].mean()) < float(ref[4][:8].mean())
@@ -286,7 +333,10 @@ def test_map_native_scheduling_switches_agree():
             if name in ("all_on", "all_on_again"):
                 continue
             mt = _switch_metrics(r, ref)
-            report(test="map_scheduling_switch", iters=n_it, variant=name, **mt)
+            report(test="map_scheduling_switch", iters=n_it, variant=name, frozen_decoder=frozen, **mt)
+            if frozen:
+                assert mt["loss_rel_max"] <= 2e-5 and mt["geo_mean"] <= 2e-5 and mt["col_mean"] <= 2e-5, (n_it, name, mt)
+                continue
             for key in keys:
                 assert mt[key] <= 3.0 * noise[key] + 2e-6, (n_it, name, key, mt[key], noise[key])
 
