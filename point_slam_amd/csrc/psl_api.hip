@@ -126,6 +126,7 @@ RenderWs carve_ws(float* base, int n_rays, int flags) {
     if (color) {
       w.c_y = take(Pp * 5 * HC);
       w.d_out3 = take(Pp * 4);
+      w.dcc = take(Pp * C);
       if (relpos) {
         w.n_h1 = take(Pp * K * HC);
         if (flags & PSL_PTS_GRAD) w.n_out = take(Pp * K * C);     // only dL/dw -> dL/dp needs F_theta's outputs
@@ -345,7 +346,7 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap; int knn_trace_dump(); }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_decode_split; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
@@ -354,6 +355,7 @@ extern "C" int psl_debug_option(const char* name, int value) {
   if (!strcmp(name, "track_fused")) { psl::g_track_fused = value; return PSL_OK; }
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_overlap")) { psl::g_knn_overlap = value; return PSL_OK; }
+  if (!strcmp(name, "decode_split")) { psl::g_decode_split = value; return PSL_OK; }
   if (!strcmp(name, "knn_trace_dump")) return psl::knn_trace_dump();
   set_error("psl_debug_option: unknown option %s", name);
   return PSL_ERR_ARG;

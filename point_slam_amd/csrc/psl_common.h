@@ -311,6 +311,7 @@ struct RenderWs {
   float* d_out3;     // [Ppad][4]
   float* dp;         // [Ppad][4]
   float* dp2;        // [Ppad][4]  geometry-branch share of dL/dp (register-chained backward: written by another workgroup)
+  float* dcc;        // [Ppad][32] dL/d(interpolated colour feature), masked: trunk backward -> F_theta backward (split kernels)
   int64_t total;
 };
 RenderWs carve_ws(float* base, int n_rays, int flags);
