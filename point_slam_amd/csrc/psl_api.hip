@@ -82,9 +82,7 @@ int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_t
   return PSL_OK;
 }
 
-int launch_decode_fwd(const DecodeArgs& a, hipStream_t s);
 int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a, hipStream_t s);
-int build_wt_index(psl_ctx* ctx, hipStream_t s);
 int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s);
 int launch_composite_fwd(const float4* raw, const float* z, const float* gt_depth, float near_s, float far_s,
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
@@ -158,7 +156,7 @@ static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& 
   d.rays_o = a->rays_o; d.rays_d = a->rays_d; d.depth = a->gt_depth; d.zv = a->z_vals; d.r_query = a->r_query;
   d.pos = ctx->pos;
   d.geo_feats = a->geo_feats; d.col_feats = a->col_feats;
-  d.master = a->params; d.wt = ctx->wt; d.Bcol = a->col_embed_B;
+  d.master = a->params; d.Bcol = a->col_embed_B;
   d.fb_geo = a->fallback_geo; d.fb_col = a->fallback_col; d.affine = a->exposure_affine;
   d.ws = carve_ws(a->ws, a->n_rays, flags);
   if (ctx->pre_I) { d.ws.I = ctx->pre_I; d.ws.cnt = ctx->pre_cnt; }   // neighbours answered ahead (psl_map_iters)
@@ -222,15 +220,11 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->scan_tmp, sizeof(int) * 4096)); psl::poison(c->scan_tmp, sizeof(int) * 4096);
   PSL_HIP(hipMalloc(&c->bounds, sizeof(int) * 8)); psl::poison(c->bounds, sizeof(int) * 8);
   PSL_HIP(hipMalloc(&c->meta, sizeof(GridMeta))); psl::poison(c->meta, sizeof(GridMeta));
-  PSL_HIP(hipMalloc(&c->wt, sizeof(float) * kWtFloats)); psl::poison(c->wt, sizeof(float) * kWtFloats);
-  PSL_HIP(hipMalloc(&c->wt_index, sizeof(int) * kColorFloats)); psl::poison(c->wt_index, sizeof(int) * kColorFloats);
   PSL_HIP(hipMalloc(&c->wf, sizeof(float) * kFFloats)); psl::poison(c->wf, sizeof(float) * kFFloats);
   PSL_HIP(hipMalloc(&c->wb, sizeof(float) * kBFloats)); psl::poison(c->wb, sizeof(float) * kBFloats);
   PSL_HIP(hipMalloc(&c->wf_index, sizeof(int) * kColorFloats));
   PSL_HIP(hipMalloc(&c->wb_index, sizeof(int) * kColorFloats));
-  { const char* e = getenv("PSL_DECODE"); c->decode_version = (e && e[0] == '1') ? 1 : 2; }
-  { const char* e = getenv("PSL_DECODE_BWD"); c->decode_bwd_version = (e && e[0] == '1') ? 1 : 2; }
-  { int rc = build_wt_index(c, nullptr); if (rc) return rc; rc = build_frag_index(c, nullptr); if (rc) return rc;
+  { int rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
   PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
@@ -240,8 +234,8 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   dbg_range("pos", c->pos, sizeof(float4) * np); dbg_range("spos", c->spos, sizeof(float4) * np);
   dbg_range("cell_of", c->cell_of, sizeof(int) * np); dbg_range("cell_start", c->cell_start, sizeof(int) * (kMaxCells + 1));
   dbg_range("cell_fill", c->cell_fill, sizeof(int) * kMaxCells); dbg_range("coarse", c->coarse, sizeof(int) * kMaxCoarse);
-  dbg_range("scan_tmp", c->scan_tmp, sizeof(int) * 4096); dbg_range("wt", c->wt, sizeof(float) * kWtFloats);
-  dbg_range("wt_index", c->wt_index, sizeof(int) * kColorFloats); dbg_range("wf", c->wf, sizeof(float) * kFFloats);
+  dbg_range("scan_tmp", c->scan_tmp, sizeof(int) * 4096);
+  dbg_range("wf", c->wf, sizeof(float) * kFFloats);
   dbg_range("wb", c->wb, sizeof(float) * kBFloats); dbg_range("wf_index", c->wf_index, sizeof(int) * kColorFloats);
   dbg_range("wb_index", c->wb_index, sizeof(int) * kColorFloats); dbg_range("d_small", c->d_small, 256);
   dbg_range("d_expo", c->d_expo, sizeof(float) * 64 * (12 + 128 + 12)); dbg_range("adam_rows", c->adam_rows, 8 * kAdamRowSlots);
@@ -257,7 +251,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)psl_comm_destroy(c);
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->coarse); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
-  (void)hipFree(c->wt); (void)hipFree(c->wt_index); (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
+  (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
   (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->stream2) {
@@ -283,14 +277,13 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   if (a->n_rays == 0) return PSL_OK;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
-  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_weights(ctx, a->params, s); if (rc) return rc;
-                rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
+  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
   if (!ctx->pre_I)
   { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
   { ProfScope ps(ctx, prof_decode_slot(d.flags, false), s, fwd_flops_per_sample(d.flags) * d.P);
-    rc = (ctx->decode_version >= 2) ? launch_decode_fwd2(ctx, d, s) : launch_decode_fwd(d, s); if (rc) return rc; }
+    rc = launch_decode_fwd2(ctx, d, s); if (rc) return rc; }
   if (!ctx->fused_ray)     // psl_map_iters composites, takes the loss and back-propagates it in one kernel of its own
   { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
     rc = launch_composite_fwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
@@ -319,7 +312,7 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
   if (rc) return rc;
   if ((a->flags & PSL_PTS_GRAD) && (g->g_rays_o || g->g_rays_d)) {
     ProfScope ps(ctx, PROF_MISC, s);
-    rc = launch_ray_grad((const float4*)d.ws.dp, ctx->decode_bwd_version >= 2 ? (const float4*)d.ws.dp2 : nullptr, a->z_vals,
+    rc = launch_ray_grad((const float4*)d.ws.dp, (const float4*)d.ws.dp2, a->z_vals,
                          a->gt_depth, d.near_s, d.far_s, a->n_rays, g->g_rays_o, g->g_rays_d, s);
     if (rc) return rc;
   }

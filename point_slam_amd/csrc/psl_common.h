@@ -82,32 +82,6 @@ constexpr int PI_G_B = 37;
 constexpr int PI_G_L = 38;
 constexpr int PI_G_OUT = 48;
 
-// --------------------------------------------- forward ("wt") layout: [Kpad][N]
-// Every linear layer used as an MFMA B operand in the FORWARD pass is kept
-// transposed ([in][out], in padded to a multiple of 4, zero rows) so that a
-// wave's B fragment (4 k-rows x 16 columns) is four 64-byte segments.
-struct WtDesc { int pi; int Kin, N, Kpad, split, gap; };
-// split/gap: input index k maps to padded row (k < split ? k : k + gap)
-constexpr WtDesc kWt[] = {
-    {PI_C_FCC + 0, C, HC, C, C, 0}, {PI_C_FCC + 2, C, HC, C, C, 0}, {PI_C_FCC + 4, C, HC, C, C, 0},
-    {PI_C_FCC + 6, C, HC, C, C, 0}, {PI_C_FCC + 8, C, HC, C, C, 0},
-    {PI_C_N1, NX, HC, NX, NX, 0}, {PI_C_N2, HC, C, HC, HC, 0},
-    {PI_C_L + 0, EC, HC, EC, EC, 0}, {PI_C_L + 2, HC, HC, HC, HC, 0}, {PI_C_L + 4, HC, HC, HC, HC, 0},
-    {PI_C_L + 6, EC + HC, HC, EC + HC, EC + HC, 0}, {PI_C_L + 8, HC, HC, HC, HC, 0},
-    {PI_G_FCC + 0, C, HG, C, C, 0}, {PI_G_FCC + 2, C, HG, C, C, 0}, {PI_G_FCC + 4, C, HG, C, C, 0},
-    {PI_G_FCC + 6, C, HG, C, C, 0}, {PI_G_FCC + 8, C, HG, C, C, 0},
-    {PI_G_L + 0, EG, HG, EGP, EG, 0}, {PI_G_L + 2, HG, HG, HG, HG, 0}, {PI_G_L + 4, HG, HG, HG, HG, 0},
-    {PI_G_L + 6, EG + HG, HG, EGP + HG, EG, EGP - EG}, {PI_G_L + 8, HG, HG, HG, HG, 0},
-};
-constexpr int kNumWt = sizeof(kWt) / sizeof(kWt[0]);
-constexpr int WT_C_FCC = 0, WT_C_N1 = 5, WT_C_N2 = 6, WT_C_L = 7, WT_G_FCC = 12, WT_G_L = 17;
-constexpr int wtoff(int i) {
-  int o = 0;
-  for (int j = 0; j < i; ++j) o += kWt[j].Kpad * kWt[j].N;
-  return o;
-}
-constexpr int kWtFloats = wtoff(kNumWt);
-
 // ---------------------------------------------------------- grid (spatial index)
 constexpr int kMaxCells = 1 << 22;
 struct GridMeta {      // lives in device memory; written by k_grid_meta
@@ -154,16 +128,11 @@ struct psl_ctx {
   int* coarse = nullptr; // [kMaxCoarse] points per 4x4x4 block of cells: lets a query in empty space stop at once
   int* scan_tmp;         // block sums for the scan
   int* bounds;           // 6 ints: ordered-int min/max
-  // forward-layout weights (rebuilt per render call from the master blob)
-  float* wt;
-  int* wt_index = nullptr;   // [kColorFloats] master element -> forward-layout element (or -1)
   // fragment-major weight copies of the register-chained decode kernels (psl_frag.h) and their inverse maps
   float* wf = nullptr;       // forward fragments + aligned biases
   float* wb = nullptr;       // backward (transposed) fragments
   int* wf_index = nullptr;   // [kColorFloats] master element -> element of wf (or -1)
   int* wb_index = nullptr;   // [kColorFloats] master element -> element of wb (or -1)
-  int decode_version = 2;    // PSL_DECODE=1 selects the LDS-staged forward of round 1 (A/B comparisons)
-  int decode_bwd_version = 2;   // PSL_DECODE_BWD=1: the LDS-staged backward of round 1
   // dW partial slabs
   float* dw_slabs;
   int dw_slab_cap;       // number of slabs allocated
@@ -262,7 +231,7 @@ constexpr int kAdamTabLds = 72;   // >= the k-NN prefetch block (64 iterations) 
 constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache lines
 struct AdamLazy { const float4* tab; const int* list; const int* count; long long list_cap; int it;
                   unsigned long long* rows_done; int base; };
-struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2; const int* wt_index; float* wt;
+struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2;
                     const int* wf_index; float* wf; const int* wb_index; float* wb;
                     // slabs != null: g is not read; the gradient of element e is the ordered sum of its chunk partials
                     // (what k_dw_reduce would have written), taken inside the Adam launch
@@ -279,7 +248,6 @@ int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_dept
                          const AdamWorklist* wl = nullptr);
 int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, float* D_out,
                 int64_t* I_out, int* cnt_out, hipStream_t s);
-int repack_weights(psl_ctx* ctx, const float* master, hipStream_t s);
 int repack_frags(psl_ctx* ctx, const float* master, hipStream_t s);
 int build_frag_index(psl_ctx* ctx, hipStream_t s);
 

@@ -13,11 +13,9 @@ struct DecodeArgs {
   const float4* pos;
   const float *geo_feats, *col_feats;
   const float* master;   // torch-layout parameter blob
-  const float* wt;       // forward-layout weights
   const float* Bcol;     // [3][20]
   const float *fb_geo, *fb_col, *affine;
   RenderWs ws;
-  int spt;                   // real samples per workgroup tile (set by the launcher)
   unsigned long long* dbg;   // optional phase timestamps (PSL_DEBUG_PHASES=1)
   unsigned long long* blk;   // optional per-workgroup trace [grid][4]: wall start, wall end, hw id, shader cycles (PSL_DEBUG_BLOCKS=<file>)
 };
@@ -70,13 +68,6 @@ inline double dw_flops_per_sample(int flags) {
 inline double gather_bytes_per_sample(int flags) { return 12.0 + 96.0 + ((flags & PSL_STAGE_COLOR) ? 2048.0 : 1024.0); }
 inline double scatter_bytes_per_sample(int flags) { return (flags & PSL_STAGE_COLOR) ? 4096.0 : 2048.0; }
 
-// LDS strides (floats): even with ld/2 odd => the 16x4 A-fragment reads are bank-conflict free
-constexpr int LD_G = 130;   // geo X: [emb 96 | h 32]
-constexpr int LD_C = 170;   // colour X: [emb 40 | h 128]
-constexpr int LD_CF = 34;   // interpolated feature tiles [16][32]
-constexpr int LD_XN = 54;   // neighbour-MLP input [128][52]
-constexpr int LD_HN = 130;  // neighbour-MLP hidden, per wave [16][128]
-
 // master offsets (floats)
 constexpr int MO(int pi) { return poff(pi); }
 
@@ -99,39 +90,6 @@ __device__ __forceinline__ SampleGeom sample_geom(const DecodeArgs& a, int p) {
 __device__ __forceinline__ float fourier_phase(float x, float y, float z, const float* __restrict__ B, int F, int f) {
   float x2 = __fmul_rn(TWO_PI, x), y2 = __fmul_rn(TWO_PI, y), z2 = __fmul_rn(TWO_PI, z);
   return fmaf(z2, B[2 * F + f], fmaf(y2, B[F + f], __fmul_rn(x2, B[f])));
-}
-
-void choose_tile(int P, int& mt, int& spt);
-
-// NT output column tiles at once: the A fragment is read from LDS once per k-step
-template <int KDIM, int NT>
-__device__ __forceinline__ void gemm16_multi(const float* Xs, int ldx, const float* __restrict__ W, int ldw,
-                                             f32x4 (&acc)[NT]) {
-  const int lane = threadIdx.x & 63;
-  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
-  const float* wp = W + (size_t)(lane >> 4) * ldw + (lane & 15);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // B fragments are fetched KB k-steps ahead as one batch of NT*KB independent loads
-  constexpr int NK = KDIM / 4;
-  constexpr int KB = (NT >= 8) ? 4 : 16;
-#pragma unroll
-  for (int k0 = 0; k0 < NK; k0 += KB) {
-    float wv[KB][NT];
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        wv[kk][t] = (k0 + kk < NK) ? wp[(size_t)(4 * (k0 + kk)) * ldw + 16 * t] : 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-      if (k0 + kk < NK) {
-        float xa = xp[4 * (k0 + kk)];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16(xa, wv[kk][t], acc[t]);
-      }
-    }
-  }
 }
 
 }  // namespace psl

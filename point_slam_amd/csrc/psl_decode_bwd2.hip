@@ -976,4 +976,43 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   return PSL_OK;
 }
 
+int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g_brel, hipStream_t s);
+
+// render backward of the decode stage: the register-chained kernels above, then the parameter-gradient GEMM
+int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads& g, hipStream_t s) {
+  const bool color = a.flags & PSL_STAGE_COLOR;
+  if ((a.flags & PSL_FEAT_GRAD) && (!g.g_geo_feats || (color && !g.g_col_feats))) {
+    set_error("psl_render_bwd: PSL_FEAT_GRAD needs g_geo_feats/g_col_feats"); return PSL_ERR_ARG;
+  }
+  if ((a.flags & PSL_PARAM_GRAD) && !g.g_params) { set_error("psl_render_bwd: PSL_PARAM_GRAD needs g_params"); return PSL_ERR_ARG; }
+  if ((a.flags & PSL_HAS_AFFINE) && !g.g_exposure_affine) { set_error("psl_render_bwd: affine gradient buffer missing"); return PSL_ERR_ARG; }
+  // small accumulators: [0..31] dB_rel, [32..47] affine  (ctx->d_small)
+  float* small = ctx->d_small;     // cleared by the compositing-backward kernel that always runs just before
+  static unsigned long long* dbg = nullptr;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  DecodeArgs a2 = a;
+  if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
+  {
+    ProfScope ps(ctx, prof_decode_slot(a.flags, true), s, bwd_flops_per_sample(a.flags) * a.P);
+    int rc = launch_decode_bwd2(ctx, a2, g, small, s);
+    if (rc) return rc;
+  }
+  if ((a.flags & PSL_HAS_AFFINE) && color)
+    PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
+  if (a.flags & PSL_PARAM_GRAD) {
+    if (color) {
+      ProfScope ps(ctx, PROF_DW, s, dw_flops_per_sample(a.flags) * a.P);
+      int rc = launch_dw(ctx, a, g.g_params, small, s);
+      if (rc) return rc;
+    } else {
+      // geometry stage: the colour decoder is not evaluated; the geometry decoder is frozen
+      // (mapping.fix_geo_decoder, configs/point_slam.yaml:47) -> all-zero parameter gradient
+      PSL_HIP(hipMemsetAsync(g.g_params, 0, sizeof(float) * kMasterFloats, s));
+    }
+  }
+  return PSL_OK;
+}
+
+
 }  // namespace psl

@@ -96,61 +96,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// acc(16 x 16 slice at column n0) += X[16][K] (LDS, row stride ldx) * W[K][N] (global, row stride ldw).
-// Lane l: A = X[l&15][4*ks + (l>>4)], B = W[4*ks + (l>>4)][n0 + (l&15)]; C/D: col = l&15, row = 4*(l>>4)+reg.
-// Two accumulator chains hide the 40-cycle dependent MFMA latency behind the 32-cycle issue interval.
-template <int KDIM>
-__device__ __forceinline__ f32x4 gemm16(const float* Xs, int ldx, const float* __restrict__ W, int ldw, int n0) {
-  static_assert(KDIM % 4 == 0, "K must be a multiple of 4");
-  const int lane = threadIdx.x & 63;
-  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
-  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
-  constexpr int NK = KDIM / 4;
-  // all B fragments of this product are requested before the first MFMA: ONE exposed L2 latency per product
-  // instead of one per unrolled chunk (the weights are L2-resident; a tile is latency-, not bandwidth-bound)
-  float wv[NK];
-#pragma unroll
-  for (int ks = 0; ks < NK; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks + 1 < NK; ks += 2) {
-    a0 = mfma16(xp[4 * ks], wv[ks], a0);
-    a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1);
-  }
-  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
-  return a0 + a1;
-}
-
-// gemm16 in two halves: request the B fragments early (they depend on the weights only), multiply later
-template <int KDIM>
-__device__ __forceinline__ void fetch_b16(const float* __restrict__ W, int ldw, int n0, float (&wv)[KDIM / 4]) {
-  const int lane = threadIdx.x & 63;
-  const float* wp = W + (size_t)(lane >> 4) * ldw + n0 + (lane & 15);
-#pragma unroll
-  for (int ks = 0; ks < KDIM / 4; ++ks) wv[ks] = wp[(size_t)(4 * ks) * ldw];
-}
-template <int KDIM>
-__device__ __forceinline__ f32x4 mma16(const float* Xs, int ldx, const float (&wv)[KDIM / 4]) {
-  const int lane = threadIdx.x & 63;
-  const float* xp = Xs + (lane & 15) * ldx + (lane >> 4);
-  constexpr int NK = KDIM / 4;
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks + 1 < NK; ks += 2) {
-    a0 = mfma16(xp[4 * ks], wv[ks], a0);
-    a1 = mfma16(xp[4 * ks + 4], wv[ks + 1], a1);
-  }
-  if (NK & 1) a0 = mfma16(xp[4 * (NK - 1)], wv[NK - 1], a0);
-  return a0 + a1;
-}
-
-// store a C/D fragment to a row-major LDS/global tile: dst[row][n0 + col]
-__device__ __forceinline__ void frag_store(float* dst, int ld, int n0, f32x4 v) {
-  const int lane = threadIdx.x & 63;
-  float* p = dst + (4 * (lane >> 4)) * ld + n0 + (lane & 15);
-  p[0] = v[0]; p[ld] = v[1]; p[2 * ld] = v[2]; p[3 * ld] = v[3];
-}
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: hipcc drains
 // vmcnt(0) in front of it, i.e. every barrier would wait for the global STORES of saved activations (HBM write
 // latency, ~1-2 us each) although no wave ever reads them back inside the kernel.

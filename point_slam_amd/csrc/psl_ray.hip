@@ -389,15 +389,13 @@ __global__ __launch_bounds__(256) void k_adam_rows(float* __restrict__ feats, co
 }
 
 // One launch for all Adam groups of a mapper iteration (Mapper.py:394-402,556): geometry feature rows, colour
-// feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the
-// forward-layout copy of each weight it steps (wt_index: master element -> element of the [Kpad][N] copy, -1 for
-// biases / B matrices), which replaces the separate re-pack launch before the next forward.
+// feature rows (colour stage) and the colour-decoder parameters.  The parameter segment also refreshes the two
+// fragment-major copies of each weight it steps (wf_index / wb_index: master element -> element of the forward / backward
+// fragment buffer, -1 for tensors without a copy), which replaces a re-pack launch before the next forward.
 __device__ __forceinline__ void adam_par_apply(const AdamParSeg& par, int i, float g, float b1, float b2, float eps) {
   float pp = par.p[i], mm = par.m[i], vv = par.v[i];
   adam_update(pp, g, mm, vv, par.lr_bc1, par.sqrt_bc2, b1, b2, eps);
   par.p[i] = pp; par.m[i] = mm; par.v[i] = vv;
-  const int w = par.wt_index[i];
-  if (w >= 0) par.wt[w] = pp;
   const int wf = par.wf_index[i], wb = par.wb_index[i];
   if (wf >= 0) par.wf[wf] = pp;
   if (wb >= 0) par.wb[wb] = pp;

@@ -838,7 +838,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     ra.flags |= PSL_HAS_AFFINE; ra.exposure_affine = ex_aff; rg.g_exposure_affine = ex_g;
   }
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
-  const bool fused = n <= 1024 && ctx->decode_bwd_version >= 2 && ctx->decode_version >= 2 && g_track_fused != 0;
+  const bool fused = n <= 1024 && g_track_fused != 0;
   struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
@@ -964,7 +964,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   ctx->fused_ray = true;
   ctx->dw_defer_reduce = g_dw_fused != 0;   // the chunk partials of the dW kernel are summed inside the Adam launch
   std::vector<float4> tab_host;
-  if (ctx->decode_bwd_version >= 2 && m->n_sel > 0) {
+  if (m->n_sel > 0) {
     // lazy Adam of the feature rows (k_map_adam_lazy): upto_geo | upto_col | stamp | count[n_iters] | list | touched_geo |
     // touched_col
     const size_t ns = (size_t)m->n_sel, lcap = std::min<size_t>(2 * (size_t)n * S * K, ns);
@@ -1146,7 +1146,6 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
         sc.upto = ctx->adam_upto ? ctx->adam_upto + m->n_sel : nullptr;
         if (m->train_decoder) {
           sp.p = (float*)m->params; sp.g = g_params; sp.m = m->adam_params; sp.v = m->adam_params + ncol; sp.n = ncol;
-          sp.wt_index = ctx->wt_index; sp.wt = ctx->wt;
           sp.wf_index = ctx->wf_index; sp.wf = ctx->wf; sp.wb_index = ctx->wb_index; sp.wb = ctx->wb;
           if (ctx->dw_defer_reduce) { sp.slabs = ctx->dw_slabs; sp.g_brel = ctx->d_small; sp.ra = ctx->dw_ra; }
         }

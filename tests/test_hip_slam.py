@@ -173,7 +173,7 @@ def test_frustum_select_uses_the_per_point_depth_maximum():
     report(test="frustum_per_point_max", n_sel=len(got), n_ref=len(ref), n_image_max_rule=len(loose), sym_diff=len(got ^ ref),
            per_point_max=float(d_pt.max()))
     assert float(d_pt.max()) < 10.0                    # no point sees the outlier
-    assert len(loose) > len(ref) + 1000                # the rules differ on this frame
+    assert len(loose) > 2 * len(ref) and len(ref) > 50   # the rules differ on this frame
     assert len(got ^ ref) <= max(3, len(ref) // 2000)
 
 
