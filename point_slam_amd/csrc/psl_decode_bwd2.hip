@@ -42,12 +42,36 @@ struct Bwd2Out {
 
 constexpr int LD_E2 = 44;   // colour d(embedding) tile [16][40] (PTSG)
 constexpr int LD_X2 = 22;   // rel-pos part of F_theta's dX1, per wave [16][20]
+// F_theta's backward weight fragments live in LDS (see NbrStage in psl_decode_fwd2.hip for the why): linear2^T (16) then
+// linear1^T (32), contiguous at the start of the backward fragment buffer.
+constexpr int kNbrFragsB = 48;
+static_assert(bfirst(BL_N2) == 0 && bfirst(BL_N1) == 16 && bfirst(BL_C1) == kNbrFragsB, "F_theta fragments lead the backward buffer");
+template <int NT>
+struct NbrStageB {
+  f32x4 v[kNbrFragsB * FRAG / 4 / NT];
+  __device__ __forceinline__ void load(const float* __restrict__ W) {
+#pragma unroll
+    for (int j = 0; j < kNbrFragsB * FRAG / 4 / NT; ++j) v[j] = *reinterpret_cast<const f32x4*>(W + ((size_t)j * NT + threadIdx.x) * 4);
+  }
+  __device__ __forceinline__ void store(float* sW) const {
+#pragma unroll
+    for (int j = 0; j < kNbrFragsB * FRAG / 4 / NT; ++j) *reinterpret_cast<f32x4*>(sW + ((size_t)j * NT + threadIdx.x) * 4) = v[j];
+  }
+};
+__device__ __forceinline__ f32x4 ldsfragb(const float* sW, int frag, int lane) {
+  return *reinterpret_cast<const f32x4*>(sW + frag * FRAG + lane * 4);
+}
+// The 16 KiB dz exchange buffers of the trunk are dead once the last layer's barrier has been passed: the per-wave partial
+// tiles of dL/dc (sDccP) and, after their reduction, the rel-pos tiles of F_theta's backward (sXe) reuse them, which keeps
+// the workgroup at 73 KB -- two per CU -- with the 48 KiB of weight fragments resident.
 struct Bwd2Lds {
   static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oDO = 720, oDB = 784, oAffP = 816,
-                       oGW = oAffP + 16 * 12, oDP = oGW + 128, oDcc = oDP + 64, oDccP = oDcc + 2 * FRAG,
-                       oDZ = oDccP + 16 * FRAG, oDE = oDZ + 2 * 8 * FRAG, oXe = oDE + 16 * LD_E2,
-                       total = oXe + 8 * 16 * LD_X2;       // ~13 K floats = 52 KB
+                       oGW = oAffP + 16 * 12, oDP = oGW + 128, oDcc = oDP + 64, oDZ = oDcc + 2 * FRAG,
+                       oDccP = oDZ, oXe = oDZ, oDE = oDZ + 2 * 8 * FRAG,
+                       total = oDE + 16 * LD_E2,           // ~6.3 K floats = 25 KB
+                       oWn = (total + 3) / 4 * 4, total_nbr = oWn + kNbrFragsB * FRAG;   // 73 KB
 };
+static_assert(8 * 16 * LD_X2 <= 2 * 8 * FRAG, "sXe fits the dz buffers");
 
 // ------------------------------------------------------------------------------------------------ geometry role
 // One wavefront per tile.  d_occ flows for masked samples too (straight-through of the -100 write, Renderer.py:189-190).
@@ -222,6 +246,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   const float* __restrict__ M = a.master;
 
   PSL_STAMP(0);
+  const float* sWn = smem + L::oWn;
+  NbrStageB<WG> stage;
+  if (relpos) stage.load(WB);      // F_theta's backward weights -> LDS; the loads fly during phase 0
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -274,6 +301,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   } else if (PTSG && t < TILE * K + TILE + 32 + 64) {
     sDP[t - TILE * K - TILE - 32] = 0.f;
   }
+  if (relpos) stage.store(smem + L::oWn);
   lds_barrier();
   PSL_STAMP(1);
 
@@ -359,7 +387,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     layer(std::integral_constant<int, 2>{});
     layer(std::integral_constant<int, 1>{});
     layer(std::integral_constant<int, 0>{});
-    // the eight K-split partial tiles of dL/dc meet in LDS
+    // the eight K-split partial tiles of dL/dc meet in LDS (in the dz buffers: every wave is past the last layer's barrier,
+    // and only the pose-gradient instantiation still reads dz after it -- that one synchronises first)
+    if constexpr (PTSG) lds_barrier();
     *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 0) * FRAG + lane * 4) = dccp[0];
     *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 1) * FRAG + lane * 4) = dccp[1];
     if (PTSG && wave < 3) {
@@ -442,7 +472,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       constexpr int b1 = bfirst(BL_N1);
       f32x4 wn[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + j * 2 + 0, lane);
+      for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + j * 2 + 0, lane);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -458,10 +488,10 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         if (st < 3) {
           const int h2 = (st + 1) >> 1, q2 = (st + 1) & 1;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + (4 * h2 + j) * 2 + q2, lane);
+          for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + (4 * h2 + j) * 2 + q2, lane);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b1 + j * 8 + 0, lane);       // first step of the next product
+          for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b1 + j * 8 + 0, lane);       // first step of the next product
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -491,7 +521,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         for (int it = 0; it < 4; ++it) wf4[it] = wn[it];
         if (q < 7) {
 #pragma unroll
-          for (int it = 0; it < 4; ++it) wn[it] = ldfragb(WB, b1 + it * 8 + q + 1, lane);
+          for (int it = 0; it < 4; ++it) wn[it] = ldsfragb(sWn, b1 + it * 8 + q + 1, lane);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -762,12 +792,15 @@ __global__ __launch_bounds__(256, 4) void k_ftheta_bwd(DecodeArgs a, Bwd2Out o, 
   __shared__ float sXe[4 * 16 * LD_X2];     // rel-pos part of dX1, per wave [16][22]
   __shared__ float sRelW[4 * 16 * 3];       // rel positions of a wave's 16 pairs
   __shared__ float sDB[32];                 // dL/dB_rel of this workgroup (30 used)
+  __shared__ __attribute__((aligned(16))) float sWn[kNbrFragsB * FRAG];   // linear2^T, linear1^T fragments
   BlkTrace bt(a);
+  { NbrStageB<256> stage; stage.load(WB); stage.store(sWn); }
   const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
   const float* __restrict__ M = a.master;
-  if (PARG) { if (t < 32) sDB[t] = 0.f; __syncthreads(); }
+  if (PARG && t < 32) sDB[t] = 0.f;
+  __syncthreads();
   const int rt = (int)blockIdx.x * 4 + wave;
   if (rt < n_rt) {
     const int row = rt * 16 + rl;
@@ -803,7 +836,7 @@ __global__ __launch_bounds__(256, 4) void k_ftheta_bwd(DecodeArgs a, Bwd2Out o, 
     constexpr int b1 = bfirst(BL_N1);
     f32x4 wn[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + j * 2 + 0, lane);
+    for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + j * 2 + 0, lane);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -819,10 +852,10 @@ __global__ __launch_bounds__(256, 4) void k_ftheta_bwd(DecodeArgs a, Bwd2Out o, 
       if (st < 3) {
         const int h2 = (st + 1) >> 1, q2 = (st + 1) & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b2 + (4 * h2 + j) * 2 + q2, lane);
+        for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + (4 * h2 + j) * 2 + q2, lane);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wn[j] = ldfragb(WB, b1 + j * 8 + 0, lane);
+        for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b1 + j * 8 + 0, lane);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -846,7 +879,7 @@ __global__ __launch_bounds__(256, 4) void k_ftheta_bwd(DecodeArgs a, Bwd2Out o, 
       for (int it = 0; it < 4; ++it) wf4[it] = wn[it];
       if (q < 7) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) wn[it] = ldfragb(WB, b1 + it * 8 + q + 1, lane);
+        for (int it = 0; it < 4; ++it) wn[it] = ldsfragb(sWn, b1 + it * 8 + q + 1, lane);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -922,11 +955,12 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   const int tiles = (a.P + TILE - 1) / TILE;
   const bool color = a.flags & PSL_STAGE_COLOR;
   const bool ptsg = a.flags & PSL_PTS_GRAD;
-  const size_t lds = sizeof(float) * Bwd2Lds::total;
+  const size_t lds = sizeof(float) * ((a.flags & 0x10000) ? Bwd2Lds::total_nbr : Bwd2Lds::total);
+  const size_t lds_max = sizeof(float) * Bwd2Lds::total_nbr;
   static bool attr_set = false, attr_set2 = false;
   if (!attr_set) {
-    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   const float* WB = ctx->wb;
@@ -936,12 +970,12 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   extern int g_decode_split;
   if (color && !ptsg && (a.flags & 0x10000) && g_decode_split != 0 && (a.P >= 2048 || g_decode_split == 2)) {
     if (!attr_set2) {
-      PSL_HIP(hipFuncSetAttribute((const void*)k_trunk_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      PSL_HIP(hipFuncSetAttribute((const void*)k_trunk_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
       attr_set2 = true;
     }
     const int g_blocks = (tiles + 7) / 8, n_rt = a.ws.Ppad / 2, f_blocks = (n_rt + 3) / 4;
     { int rc = blk_trace_begin(a, tiles + g_blocks, s); if (rc) return rc; }
-    hipLaunchKernelGGL(k_trunk_bwd, dim3(tiles + g_blocks), dim3(WG), lds, s, a, o, WB, tiles, tiles);
+    hipLaunchKernelGGL(k_trunk_bwd, dim3(tiles + g_blocks), dim3(WG), sizeof(float) * Bwd2Lds::total, s, a, o, WB, tiles, tiles);
     PSL_LAUNCH_CHECK();
     { int rc = blk_trace_end(a, "trunk_bwd", tiles + g_blocks, tiles, WG); if (rc) return rc; }
     { int rc = blk_trace_begin(a, f_blocks, s); if (rc) return rc; }

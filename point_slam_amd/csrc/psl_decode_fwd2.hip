@@ -52,10 +52,35 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+constexpr int kNbrFrags = 48;     // fragments of F_theta's two layers (see NbrStage below)
 struct Fwd2Lds {
   static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oCc = 720, oH = oCc + 2 * FRAG,
-                       total = oH + 2 * 8 * FRAG;     // 5.3 K floats = 21 KB
+                       total = oH + 2 * 8 * FRAG,     // 5.3 K floats = 21 KB
+                       oWn = total, total_nbr = oWn + kNbrFrags * FRAG;   // + F_theta's weight fragments: 69 KB
 };
+
+// F_theta's weights in LDS.  A wavefront uses every fragment of F_theta once per 16 pairs, eight (four) wavefronts of a
+// workgroup use the same ones, and fetched per wavefront from L2 one step ahead the fragment latency (~1.3 k cycles), not
+// the MFMA pipe, set the pace of both products (phase stamps: linear1 10.9 k cycles for 3.3 k cycles of MFMA issue).  The
+// 48 fragments of linear1 + linear2 (48 KiB, contiguous at the start of the fragment buffer) are therefore copied into LDS
+// once per workgroup -- all loads of the copy in flight together, ONE L2 round trip -- and read from there (ds_read_b128,
+// ~100 cycles) by every step.
+static_assert(ffirst(FL_N1) == 0 && ffirst(FL_N2) == 32 && ffirst(FL_C0) == kNbrFrags, "F_theta fragments lead the forward buffer");
+template <int NT>
+struct NbrStage {      // the copy in two halves, so that its global loads fly during the set-up phase of the kernel
+  f32x4 v[kNbrFrags * FRAG / 4 / NT];
+  __device__ __forceinline__ void load(const float* __restrict__ W) {
+#pragma unroll
+    for (int j = 0; j < kNbrFrags * FRAG / 4 / NT; ++j) v[j] = *reinterpret_cast<const f32x4*>(W + ((size_t)j * NT + threadIdx.x) * 4);
+  }
+  __device__ __forceinline__ void store(float* sW) const {
+#pragma unroll
+    for (int j = 0; j < kNbrFrags * FRAG / 4 / NT; ++j) *reinterpret_cast<f32x4*>(sW + ((size_t)j * NT + threadIdx.x) * 4) = v[j];
+  }
+};
+__device__ __forceinline__ f32x4 ldsfrag(const float* sW, int frag, int lane) {
+  return *reinterpret_cast<const f32x4*>(sW + frag * FRAG + lane * 4);
+}
 
 // ------------------------------------------------------------------------------------------------ geometry role
 // The geometry decoder of one tile as a flat list of "steps" (one k-group = 4 k-steps for both 16-column output tiles):
@@ -248,13 +273,12 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   // of the batch compute on a clamped sample and their rows are never read.
 
   PSL_STAMP(0);
-  // F_theta's first weight fragments do not depend on anything: requested before the neighbour set-up
+  // F_theta's weight fragments do not depend on anything: their copy into LDS is requested before the neighbour set-up
   constexpr int f1 = ffirst(FL_N1);
-  f32x4 afn[4];
-  if (relpos) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + j * 4 + 0, lane);
-  }
+  const float* sWn = smem + L::oWn;
+  {
+    NbrStage<WG> stage;
+    if (relpos) stage.load(WF);
 
   // ---------------------------------------------------------------- phase 0: neighbours, weights (one thread per pair)
   if (t < TILE * K) {
@@ -278,8 +302,15 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
     }
   }
+    if (relpos) stage.store(smem + L::oWn);
+  }
   lds_barrier();
   PSL_STAMP(1);
+  f32x4 afn[4];
+  if (relpos) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + j * 4 + 0, lane);
+  }
 
   TrunkW tw;
   // ---------------------------------------------------------------- phase F: colour features of the tile
@@ -339,9 +370,9 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         if (st < 7) {
           const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + (4 * h2 + j) * 4 + q2, lane);
+          for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + (4 * h2 + j) * 4 + q2, lane);
         } else {
-          a0n = ldfrag(WF, f2 + 0, lane); a1n = ldfrag(WF, f2 + 8 + 0, lane);     // linear2's first pair
+          a0n = ldsfrag(sWn, f2 + 0, lane); a1n = ldsfrag(sWn, f2 + 8 + 0, lane);     // linear2's first pair
         }
         if (q < 3) {
           const f32x4 b = (q == 0) ? xf[0] : (q == 1 ? xf[1] : xe);
@@ -364,7 +395,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       for (int q = 0; q < 8; ++q) {
         sched_fence();
         const f32x4 a0 = a0n, a1 = a1n;
-        if (q < 7) { a0n = ldfrag(WF, f2 + q + 1, lane); a1n = ldfrag(WF, f2 + 8 + q + 1, lane); }
+        if (q < 7) { a0n = ldsfrag(sWn, f2 + q + 1, lane); a1n = ldsfrag(sWn, f2 + 8 + q + 1, lane); }
         if (q < 4) activate(4 + q);            // second half: needed from q = 4 on
 #pragma unroll
         for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[q][r], nf[0]); nf[1] = mfma16(a1[r], hid[q][r], nf[1]); }
@@ -532,13 +563,13 @@ constexpr int kSplitMinSamples = 2048;
 // F_theta of the 16 pairs row0 .. row0 + 15 of the launch (pair row = 8 * sample + neighbour): neighbour weights
 // (decoder.py:362-368), rel-pos embedding + feature gather, linear1 / softplus / linear2 (decoder.py:371-379), weighted sum
 // over the 8 neighbours and the fallback for samples without neighbours (decoder.py:380-388) -> cc[sample][32].
-__device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float* __restrict__ WF, int row0) {
+__device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float* __restrict__ WF, const float* sWn, int row0) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const float* __restrict__ M = a.master;
   constexpr int f1 = ffirst(FL_N1);
   f32x4 afn[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + j * 4 + 0, lane);
+  for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + j * 4 + 0, lane);
   const int row = row0 + rl;                  // < 8 * Ppad: every per-pair buffer holds that many rows
   const int ps = row >> 3;                    // sample slot (may lie in the padding behind the batch)
   const int p = min(ps, a.P - 1);
@@ -596,9 +627,9 @@ __device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float
     if (st < 7) {
       const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) afn[j] = ldfrag(WF, f1 + (4 * h2 + j) * 4 + q2, lane);
+      for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + (4 * h2 + j) * 4 + q2, lane);
     } else {
-      a0n = ldfrag(WF, f2 + 0, lane); a1n = ldfrag(WF, f2 + 8 + 0, lane);
+      a0n = ldsfrag(sWn, f2 + 0, lane); a1n = ldsfrag(sWn, f2 + 8 + 0, lane);
     }
     if (qq < 3) {
       const f32x4 b = (qq == 0) ? xf[0] : (qq == 1 ? xf[1] : xe);
@@ -618,7 +649,7 @@ __device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float
   for (int qq = 0; qq < 8; ++qq) {
     sched_fence();
     const f32x4 a0 = a0n, a1 = a1n;
-    if (qq < 7) { a0n = ldfrag(WF, f2 + qq + 1, lane); a1n = ldfrag(WF, f2 + 8 + qq + 1, lane); }
+    if (qq < 7) { a0n = ldsfrag(sWn, f2 + qq + 1, lane); a1n = ldsfrag(sWn, f2 + 8 + qq + 1, lane); }
     if (qq < 4) activate(4 + qq);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[qq][r], nf[0]); nf[1] = mfma16(a1[r], hid[qq][r], nf[1]); }
@@ -641,11 +672,14 @@ __device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float
 
 // grid: [0, f_blocks) F_theta row tiles, four per workgroup; then the geometry role, four tiles per workgroup
 __global__ __launch_bounds__(256, 4) void k_ftheta_fwd(DecodeArgs a, const float* __restrict__ WF, int f_blocks, int n_rt, int tiles) {
+  __shared__ __attribute__((aligned(16))) float sWn[kNbrFrags * FRAG];
   BlkTrace bt(a);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if ((int)blockIdx.x < f_blocks) {
+    { NbrStage<256> stage; stage.load(WF); stage.store(sWn); }
+    __syncthreads();
     const int rt = (int)blockIdx.x * 4 + wave;
-    if (rt < n_rt) ftheta_fwd_rows(a, WF, rt * 16);
+    if (rt < n_rt) ftheta_fwd_rows(a, WF, sWn, rt * 16);
   } else {
     const int tile = ((int)blockIdx.x - f_blocks) * 4 + wave;
     if (tile < tiles) geo_tile<2>(a, WF, tile * TILE, false, false);
@@ -858,8 +892,14 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
     PSL_HIP(hipMemsetAsync(dbg, 0, 64 * sizeof(unsigned long long), s));
     a.dbg = dbg;
   }
-  const size_t lds = sizeof(float) * Fwd2Lds::total;
+  const size_t lds = sizeof(float) * ((a.flags & 0x10000) ? Fwd2Lds::total_nbr : Fwd2Lds::total);
   const int tiles = (a.P + TILE - 1) / TILE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PSL_HIP(hipFuncSetAttribute((const void*)k_decode_fwd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(float) * Fwd2Lds::total_nbr)));
+    attr_set = true;
+  }
   const bool color = a.flags & PSL_STAGE_COLOR;
   extern int g_decode_split;
   if (color && (a.flags & 0x10000) && g_decode_split != 0 && (a.P >= kSplitMinSamples || g_decode_split == 2)) {

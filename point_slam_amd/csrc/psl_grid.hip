@@ -455,6 +455,225 @@ struct KnnTrace { unsigned long long n, sum_cyc, max_cyc, sum_cand, max_cand, su
 __device__ KnnTrace g_knn_trace;
 __device__ __forceinline__ int log2_bucket(unsigned long long v) { int b = 0; while (v > 1 && b < 23) { v >>= 1; ++b; } return b; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Flat candidate enumeration for SMALL launches (the tracker: 1 000 queries, about one wavefront per SIMD).  The sorted
+// positions (16 MB at 1 M points) and the cell table do not fit an XCD's 4 MB L2, so every dependent step of a query is a
+// ~2 k-cycle trip to the memory side, and a lone wavefront hides none of it: the row walk above costs a pass over the r-cube
+// (81 rows) ~60 k cycles, a three-pass query 130-240 k (PSL_KNN_TRACE: 2 % of the queries, and the launch lasts as long as
+// its slowest query).  Here a pass is TWO dependent trips however large its box:
+//   1. the [begin, end) ranges of ALL rows of the box, one or two per lane, requested together; a wave scan of their
+//      lengths gives every candidate a position in the concatenated list (empty rows drop out);
+//   2. lane l owns the contiguous slice [l q, (l + 1) q) of that list, q = ceil(T / 64), and requests its candidates eight
+//      at a time -- up to 512 records in flight per wavefront instead of 48.
+// A box with fewer than 8 candidates cannot close the search and is not scanned at all.  Same keys, same order relation,
+// bit-identical answers to knn_scan_rows_lane.
+constexpr int kFlatRows = 128;                  // >= rows of all passes of a query together (9 + 25 + 81 at cell = r_max / 4)
+constexpr int kFlatPasses = 3;                 // cell = r_max / 4: radii cell, 2 cell, r
+struct FlatLds { int rbeg[kFlatRows]; int rcnt[kFlatRows];            // [begin, length) of every row of every pass
+                 int beg[kFlatRows]; int cnt[kFlatRows]; int off[kFlatRows + 1]; };   // non-empty rows of the current pass
+
+// [begin, length) of row (cz, cy) of the box of radius `re` around q, TRIMMED to the sphere: a row whose (y, z) interval
+// lies farther than re from q holds no candidate, and along x only the chord of the sphere matters -- a cube of the
+// query radius holds ~2x the candidates of its inscribed sphere, and the slowest query of a launch sets its duration.
+// Conservative: the box inflation of box_of plus a margin on the cell intervals; boundary cells are unbounded (points
+// beyond the grid's extent are clamped into them).
+__device__ __forceinline__ void flat_row_range(const GridMeta& m, const int* __restrict__ cell_start, const CellBox& bx, int row,
+                                               int ny_b, float qx, float qy, float qz, float re, int& beg, int& cnt) {
+  const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
+  const float rr = re * 1.0001f + 1e-6f, eps = 1e-4f * m.cell;
+  float dy = 0.f, dz = 0.f;
+  {
+    const float lo = m.oy + (float)cy * m.cell, hi = lo + m.cell;
+    if (qy < lo && cy > 0) dy = lo - qy; else if (qy > hi && cy < m.ny - 1) dy = qy - hi;
+    const float lz = m.oz + (float)cz * m.cell, hz = lz + m.cell;
+    if (qz < lz && cz > 0) dz = lz - qz; else if (qz > hz && cz < m.nz - 1) dz = qz - hz;
+    dy = fmaxf(dy - eps, 0.f); dz = fmaxf(dz - eps, 0.f);
+  }
+  const float w2 = rr * rr - dy * dy - dz * dz;
+  beg = 0; cnt = 0;
+  if (!(w2 >= 0.f)) return;
+  const float w = sqrtf(w2) * 1.0001f + eps;
+  const int x0 = max(bx.lo[0], cell_coord(qx - w, m.ox, m.inv_cell, m.nx)), x1 = min(bx.hi[0], cell_coord(qx + w, m.ox, m.inv_cell, m.nx));
+  if (x1 < x0) return;
+  const int rowbase = (cz * m.ny + cy) * m.nx;
+  beg = cell_start[rowbase + x0];
+  cnt = cell_start[rowbase + x1 + 1] - beg;
+}
+
+// one pass over the rows [row0, row0 + nrows) of the table that wave_knn_flat has filled
+__device__ __forceinline__ void knn_scan_flat(const float4* __restrict__ spos, float qx, float qy, float qz, u64& mine, u64& thr,
+                                              unsigned long long& cand, FlatLds& L, int row0, int nrows, bool need_full) {
+  const int lane = threadIdx.x & 63;
+  // compact the non-empty rows into the pass table: position = number of non-empty rows before this one
+  int n_tab = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = lane + 64 * h;
+    const int b = row < nrows ? L.rbeg[row0 + row] : 0, c = row < nrows ? L.rcnt[row0 + row] : 0;
+    const u64 ne = __ballot(c > 0);
+    if (c > 0) { const int k = n_tab + __popcll(ne & ((1ull << lane) - 1ull)); L.beg[k] = b; L.cnt[k] = c; }
+    n_tab += __popcll(ne);
+  }
+  wave_lds_sync();
+  // exclusive prefix sums of the table's lengths (<= 128 entries: two per lane, wave scan)
+  int c0 = lane < n_tab ? L.cnt[lane] : 0, c1 = lane + 64 < n_tab ? L.cnt[lane + 64] : 0;
+  int x0 = c0, x1 = c1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int y0 = __shfl_up(x0, o), y1 = __shfl_up(x1, o); if (lane >= o) { x0 += y0; x1 += y1; } }
+  const int tot0 = __shfl(x0, 63);
+  const int T = tot0 + __shfl(x1, 63);
+  if (lane < n_tab) L.off[lane] = x0 - c0;
+  if (lane + 64 < n_tab) L.off[lane + 64] = tot0 + x1 - c1;
+  if (lane == 0) L.off[n_tab] = T;
+  wave_lds_sync();
+  cand += (unsigned long long)T;
+  if (T == 0 || (!need_full && T < K)) return;           // fewer than 8 candidates cannot close the search at this radius
+  // ---- this lane's slice of the concatenated list
+  const int q = (T + 63) >> 6;
+  const int j0 = lane * q;
+  int tr = 0;                                    // table row that holds candidate j0: last tr with off[tr] <= j0
+  {
+    int lo = 0, hi = n_tab - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] <= j0) lo = mid; else hi = mid - 1; }
+    tr = lo;
+  }
+  int cur = 0, row_end = 0;
+  if (j0 < T) { cur = L.beg[tr] + (j0 - L.off[tr]); row_end = L.beg[tr] + L.cnt[tr]; }
+  int left = min(q, max(T - j0, 0));
+  // ---- eight records per lane in flight (repeated for passes of more than 512 candidates)
+  constexpr int U = 8;
+  for (int it = 0; it < q; it += U) {
+    float4 c[U];
+    bool v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = left > 0;
+      c[u] = v[u] ? spos[cur] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v[u]) {
+        --left; ++cur;
+        if (cur == row_end && left > 0) { ++tr; cur = L.beg[tr]; row_end = cur + L.cnt[tr]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned idx = __float_as_uint(c[u].w);
+      const float d2 = dist2(c[u].x, c[u].y, c[u].z, qx, qy, qz);
+      const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
+      u64 mask = __ballot(v[u] && key < thr);
+      while (mask) {
+        lane_list_insert(mine, thr, readlane64(key, __builtin_ctzll(mask)));
+        mask &= mask - 1;
+        if (mask) mask &= __ballot(v[u] && key < thr);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* __restrict__ spos,
+                                              const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
+                                              float r2, u64& mine, unsigned long long& cand, const int* __restrict__ coarse,
+                                              int& passes, FlatLds& L) {
+  const int lane = threadIdx.x & 63;
+  passes = 0;
+  // the radii of the expanding search (one cell, doubling, the last one = r) and their boxes: known before any load.
+  // (Fully unrolled with compile-time indices: the per-pass records stay in registers.)
+  float re[kFlatPasses];
+  CellBox bx[kFlatPasses];
+  int nyb[kFlatPasses], base[kFlatPasses + 1];
+  int np = 0;
+  base[0] = 0;
+  {
+    float rho = m.cell;
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < kFlatPasses; ++k) {
+      const bool last = rho >= r;
+      re[k] = last ? r : rho;
+      box_of(m, qx, qy, qz, re[k], bx[k]);
+      nyb[k] = bx[k].hi[1] - bx[k].lo[1] + 1;
+      const int rows = done ? 0 : (bx[k].hi[2] - bx[k].lo[2] + 1) * nyb[k];
+      base[k + 1] = base[k] + rows;
+      if (!done) np = k + 1;
+      done = done || last;
+      rho *= 2.0f;
+    }
+    if (!done || base[kFlatPasses] > kFlatRows) {   // (never with cell = r_max / 4) -- the row walk of k_knn_rays
+      wave_knn_lane(m, spos, cell_start, qx, qy, qz, r, r2, mine, cand, coarse, passes);
+      return;
+    }
+  }
+  // ONE trip for the row ranges of ALL passes (two rows per lane) and, concurrently, the coarse occupancy test
+  int rb[2], rc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int gr = lane + 64 * h;
+    rb[h] = 0; rc[h] = 0;
+#pragma unroll
+    for (int k = 0; k < kFlatPasses; ++k)
+      if (gr >= base[k] && gr < base[k + 1]) flat_row_range(m, cell_start, bx[k], gr - base[k], nyb[k], qx, qy, qz, re[k], rb[h], rc[h]);
+  }
+  const bool empty = coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r);
+  if (empty) { mine = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull; return; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { const int gr = lane + 64 * h; if (gr < base[kFlatPasses]) { L.rbeg[gr] = rb[h]; L.rcnt[gr] = rc[h]; } }
+  wave_lds_sync();
+  bool closed = false;
+#pragma unroll
+  for (int k = 0; k < kFlatPasses; ++k) {
+    if (k < np && !closed) {
+      const bool last = k == np - 1;
+      const float t2 = last ? r2 : __fmul_rn(re[k], re[k]);
+      const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
+      mine = sentinel;
+      u64 thr = sentinel;
+      knn_scan_flat(spos, qx, qy, qz, mine, thr, cand, L, base[k], base[k + 1] - base[k], last);
+      ++passes;
+      closed = last || thr != sentinel;
+    }
+  }
+}
+
+// ray mode, small launches: one wave per SAMPLE with the flat enumeration; outputs as k_knn_rays
+__global__ __launch_bounds__(256) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+                                                       const int* __restrict__ cell_start,
+                                                       const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                       const float* __restrict__ depth, const float* __restrict__ z_vals,
+                                                       const float* __restrict__ r_query,
+                                                       float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
+                                                       int* __restrict__ I_out, int* __restrict__ cnt_out,
+                                                       unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse,
+                                                       int trace) {
+  __shared__ FlatLds lds[4];
+  const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (p >= n_rays * S) return;
+  const unsigned long long t0 = trace ? clock64() : 0ull;
+  const int ray = p / S, si = p - ray * S;
+  const int lane = threadIdx.x & 63;
+  const GridMeta m = *meta;
+  const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
+  float r, r2;
+  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  float qx, qy, qz;
+  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+               rays_d[ray * 3 + 2], zq, qx, qy, qz);
+  u64 mine;
+  unsigned long long n_cand = 0;
+  int n_pass = 0;
+  wave_knn_flat(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass, lds[(threadIdx.x >> 6) & 3]);
+  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
+  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
+  if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
+  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
+  if (trace && lane == 0) {
+    const unsigned long long cyc = clock64() - t0;
+    atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
+    atomicAdd(&g_knn_trace.sum_cand, n_cand); atomicMax(&g_knn_trace.max_cand, n_cand);
+    atomicAdd(&g_knn_trace.sum_pass, (unsigned long long)n_pass);
+    atomicAdd(&g_knn_trace.hist_cyc[log2_bucket(cyc)], 1ull); atomicAdd(&g_knn_trace.hist_cand[log2_bucket(n_cand + 1)], 1ull);
+    atomicAdd(&g_knn_trace.hist_pass[min(n_pass, 3)], 1ull);
+  }
+}
+
 // ray mode: one wave per SAMPLE (5 per ray); I_out [R*5][8] int32, cnt_out [R*5]
 __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                   const int* __restrict__ cell_start,
@@ -861,16 +1080,28 @@ static inline float r2_of(float r) { return (float)((double)r * (double)r); }   
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s, int max_blocks) {
   if (n_rays <= 0) return PSL_OK;
-  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0; }
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0; }
   // 0 = by launch size: from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the
   // shared candidate scan of one wavefront per ray (2); below that one wavefront per sample (1).  3 = four wavefronts
   // per sample sharing the rows of every pass: measured no faster than (1) on the tracker's 200-ray launches, before
   // and after both got the lane-distributed list (68 vs 67 us, then 67 vs 63 us; profiles/r02_knn_small_ab.txt) --
   // those launches are not bound by the serial row walk of a wavefront -- so it stays an option (PSL_KNN_SMALL=3),
   // covered by the exactness tests.
+  // 4 = one wavefront per sample with the FLAT candidate enumeration (two dependent memory trips per pass): the default
+  // below 1 024 rays since round 3
   static int small_ver = -1;
-  if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] == '3') ? 3 : 1; }
+  if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; if (small_ver == 2) small_ver = 4; }
   const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : small_ver);
+  if (ver == 4) {
+    static int trace4 = -1;
+    if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
+    hipLaunchKernelGGL(k_knn_rays_flat, dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
+                       (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
+    PSL_LAUNCH_CHECK();
+    return PSL_OK;
+  }
   if (ver == 3) {
     hipLaunchKernelGGL(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -474,63 +474,68 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
 // row of a launch sets its duration.
 __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_rows, int n_groups,
                                                        float b1, float b2, float eps, AdamLazy lz) {
-  int blk = blockIdx.x;
-  if (blk >= nb_rows * n_groups) { adam_par_segment(par, blk - nb_rows * n_groups, b1, b2, eps); return; }
-  const bool is_col = blk >= nb_rows;
-  if (is_col) blk -= nb_rows;
+  int blk0 = blockIdx.x;
+  if (blk0 >= nb_rows * n_groups) { adam_par_segment(par, blk0 - nb_rows * n_groups, b1, b2, eps); return; }
+  const bool is_col = blk0 >= nb_rows;
+  if (is_col) blk0 -= nb_rows;
   const AdamRowsSeg& sg = is_col ? col : geo;
   const int n_work = lz.list ? *lz.count : sg.n_rows;
-  if ((long long)blk * 8 >= n_work) return;             // the whole workgroup lies beyond the work list
-  const int e = threadIdx.x & 31;
-  const long long ridx = (long long)blk * 8 + (threadIdx.x >> 5);
-  int row = -1;
-  if (ridx < n_work) row = lz.list ? lz.list[ridx] : (int)ridx;
-  bool has_g = false, work = false;
-  int u = -1;
-  if (row >= 0) {
-    has_g = sg.touched[row] != 0;
-    u = sg.upto[row];
-    work = has_g || (u >= 0 && u <= lz.it);
-  }
-  if (!__syncthreads_or(work ? 1 : 0)) return;
   // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
   // made each step a full memory round trip)
   __shared__ float2 stab[kAdamTabLds];
   const int nt = lz.it - lz.base + 1;
-  for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
-    const float4 v = lz.tab[lz.base + t];
-    stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+  if ((long long)blk0 * 8 < n_work) {
+    for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
+      const float4 v = lz.tab[lz.base + t];
+      stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+    }
   }
   __syncthreads();
-  if (!work) return;
-  if (u < 0) u = lz.it;                                 // first gradient of this row: the missed steps were +0
   auto consts = [&](int t) -> float2 {
     const int k = t - lz.base;
     if (k >= 0 && k < kAdamTabLds) return stab[k];
     const float4 v = lz.tab[t];
     return is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
   };
-  float* pptr = sg.feats + (size_t)sg.rows[row] * C + e;
-  const size_t k = (size_t)row * C + e;
-  float* gp = reinterpret_cast<float*>(sg.g) + k;
-  float* mp = reinterpret_cast<float*>(sg.m) + k;
-  float* vp = reinterpret_cast<float*>(sg.v) + k;
-  float pp = *pptr, mm = *mp, vv = *vp;
-  float gg = 0.f;
-  if (has_g) { gg = *gp; *gp = 0.f; }
-  for (int t = u; t < lz.it; ++t) {                     // replay of the steps without a gradient
-    const float2 ab = consts(t);
-    adam_replay(pp, mm, vv, ab.x, __builtin_amdgcn_rcpf(ab.y), b1, b2, eps);
+  const int e = threadIdx.x & 31;
+  unsigned long long done = 0;
+  // the grid is a fixed number of workgroups per group: each walks the work list with a stride (a grid sized to the
+  // list's CAPACITY -- 10^4 workgroups per group, most of them past its length -- cost more to dispatch than to run)
+  for (long long blk = blk0; blk * 8 < n_work; blk += nb_rows) {
+    const long long ridx = blk * 8 + (threadIdx.x >> 5);
+    int row = -1;
+    if (ridx < n_work) row = lz.list ? lz.list[ridx] : (int)ridx;
+    bool has_g = false, work = false;
+    int u = -1;
+    if (row >= 0) {
+      has_g = sg.touched[row] != 0;
+      u = sg.upto[row];
+      work = has_g || (u >= 0 && u <= lz.it);
+    }
+    if (!work) continue;
+    if (u < 0) u = lz.it;                                 // first gradient of this row: the missed steps were +0
+    float* pptr = sg.feats + (size_t)sg.rows[row] * C + e;
+    const size_t k = (size_t)row * C + e;
+    float* gp = reinterpret_cast<float*>(sg.g) + k;
+    float* mp = reinterpret_cast<float*>(sg.m) + k;
+    float* vp = reinterpret_cast<float*>(sg.v) + k;
+    float pp = *pptr, mm = *mp, vv = *vp;
+    float gg = 0.f;
+    if (has_g) { gg = *gp; *gp = 0.f; }
+    for (int t = u; t < lz.it; ++t) {                     // replay of the steps without a gradient
+      const float2 ab = consts(t);
+      adam_replay(pp, mm, vv, ab.x, __builtin_amdgcn_rcpf(ab.y), b1, b2, eps);
+    }
+    const float2 ab = consts(lz.it);
+    adam_update(pp, gg, mm, vv, ab.x, ab.y, b1, b2, eps);
+    *pptr = pp; *mp = mm; *vp = vv;
+    // the 32 lanes of a row sit in one wavefront and have all read touched/upto above
+    if (e == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; ++done; }
   }
-  const float2 ab = consts(lz.it);
-  adam_update(pp, gg, mm, vv, ab.x, ab.y, b1, b2, eps);
-  *pptr = pp; *mp = mm; *vp = vv;
-  // the 32 lanes of a row sit in one wavefront and have all read touched/upto above
-  if (e == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; }
-  if (lz.rows_done) {                                   // one atomic per wavefront, spread over 256 cache lines
-    const unsigned long long act = __ballot(e == 0);
-    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)))
-      atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), (unsigned long long)__popcll(act));
+  if (lz.rows_done) {                                     // one atomic per wavefront, spread over 256 cache lines
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) done += __shfl_xor(done, o);
+    if ((threadIdx.x & 63) == 0 && done) atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), done);
   }
 }
 
@@ -562,7 +567,8 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   if (lazy.tab) {
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
     const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, geo.n_rows) : geo.n_rows;
-    const int nb_rows = (int)((rows + 7) / 8), n_groups = col.n_rows > 0 ? 2 : 1;
+    // a fixed grid of at most 2 048 workgroups per group (8 rows each per trip) walks the list with a stride
+    const int nb_rows = (int)std::min<long long>((rows + 7) / 8, 2048), n_groups = col.n_rows > 0 ? 2 : 1;
     if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
     hipLaunchKernelGGL(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
                        0.9f, 0.999f, 1e-8f, lazy);

@@ -760,9 +760,9 @@ int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
-// colour-stage decode as separate F_theta / trunk kernels: 0 = fused tile kernels, 1 = split from 2 048 samples per launch
-// on (default), 2 = split always
-int g_decode_split = env_flag("PSL_DECODE_SPLIT", 1);
+// colour-stage decode as separate F_theta / trunk kernels: 0 = fused tile kernels (default: measured faster),
+// 1 = split from 2 048 samples per launch on, 2 = split always
+int g_decode_split = env_flag("PSL_DECODE_SPLIT", 0);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI

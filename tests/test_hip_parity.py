@@ -136,7 +136,7 @@ def test_ray_knn_sparse_cloud_matches_oracle(dev):
     cnt_o = O.neighbor_count(Do, rq)
     assert 0.02 < float((cnt_o == 0).float().mean()) and float((cnt_o == 8).float().mean()) < 0.9
     try:
-        for ver in (0, 1, 2, 3):    # by launch size / one wavefront per sample / one per ray / four per sample
+        for ver in (0, 1, 2, 3, 4):    # by launch size / one wavefront per sample / one per ray / four per sample / flat
             _lib.check(L.psl_debug_option(b"knn", ver))
             ws.zero_()
             _lib.check(L.psl_render_fwd(npc.handle, C.byref(a), _lib.stream_ptr()))
@@ -196,9 +196,10 @@ def _run_case(case, dev, grads):
     return fx, cfg, dec, (ro, rd, geo, col, ef), out
 
 
-# colour-stage launches of >= 2 048 samples run as separate F_theta / trunk kernels (psl_decode_fwd2.hip "split forward");
-# the fixtures are smaller, so the rel-pos cases are run a second time with the split forced ("decode_split" = 2)
-SPLIT_CASES = [(c, 1) for c in RENDER_CASES] + [(c, 2) for c in RENDER_CASES if "replica_color" in c or "holes" in c]
+# the colour-stage decode also exists as separate F_theta / trunk kernels (psl_decode_fwd2.hip "split forward"; off by
+# default, PSL_DECODE_SPLIT=1 enables it from 2 048 samples per launch): the rel-pos cases are run a second time with the
+# split forced ("decode_split" = 2)
+SPLIT_CASES = [(c, 0) for c in RENDER_CASES] + [(c, 2) for c in RENDER_CASES if "replica_color" in c or "holes" in c]
 
 
 class _forced_split:
@@ -211,7 +212,7 @@ class _forced_split:
 
     def __exit__(self, *a):
         from point_slam_amd import _lib
-        _lib.check(_lib.lib().psl_debug_option(b"decode_split", 1))
+        _lib.check(_lib.lib().psl_debug_option(b"decode_split", 0))
 
 
 @pytest.mark.parametrize("case,split", SPLIT_CASES)
