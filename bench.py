@@ -129,7 +129,7 @@ def kernel_profile(slam):
 
 
 MFMA_CLASSES = ("decode_fwd", "decode_bwd", "dw_gemm", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
-                "decode_bwd_track")
+                "decode_bwd_track", "geo_iter")
 
 
 def pmc_traffic(mix):

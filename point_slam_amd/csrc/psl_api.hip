@@ -229,6 +229,17 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
   PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
+  {
+    // scratch of the fused loops, sized once for the capacity of this context (nothing is allocated inside psl_map_iters
+    // unless a call exceeds these defaults: 8 192 iterations, 16 384 rays per iteration)
+    const size_t ns = np, lcap = std::min<size_t>(2 * (size_t)16384 * S * K, ns);
+    const size_t need = (3 * ns + kStageTabIters + lcap) * sizeof(int) + 2 * ns;
+    PSL_HIP(hipMalloc(&c->touched, need)); c->touched_cap = need;
+    PSL_HIP(hipMalloc(&c->adam_tab, sizeof(float4) * (kStageTabIters + 64))); c->adam_tab_cap = kStageTabIters + 64;
+    PSL_HIP(hipMalloc(&c->loss_acc, sizeof(double) * 4 * kStageTabIters)); c->loss_acc_cap = (int)kStageTabIters;
+    PSL_HIP(hipHostMalloc((void**)&c->h_stage, 4 * kStageSlot, hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) PSL_HIP(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+  }
   PSL_HIP(hipMalloc(&c->d_small, sizeof(float) * 64)); psl::poison(c->d_small, sizeof(float) * 64);
   PSL_HIP(hipMalloc(&c->d_expo, sizeof(float) * 64 * (12 + 128 + 12))); psl::poison(c->d_expo, sizeof(float) * 64 * (12 + 128 + 12));
   dbg_range("pos", c->pos, sizeof(float4) * np); dbg_range("spos", c->spos, sizeof(float4) * np);
@@ -254,6 +265,8 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
   (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (int i = 0; i < 4; ++i) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
   if (c->stream2) {
     (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2);
     (void)hipEventDestroy(c->ev_knn_ready[0]); (void)hipEventDestroy(c->ev_knn_ready[1]); (void)hipEventDestroy(c->ev_knn_free);
@@ -320,6 +333,24 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
 }
 }  // namespace psl
 
+namespace psl {
+int launch_geo_iter(psl_ctx* ctx, const DecodeArgs& a, const GeoIterRays& gr, float* g_geo, const int* row_map,
+                    const AdamWorklist* wl, hipStream_t s);
+// one geometry-stage mapper iteration (psl_decode_geo.hip): needs the neighbour lists answered ahead (psl_map_iters)
+int geo_iter_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, const int* active, double* loss_acc,
+                  const AdamWorklist* wl, hipStream_t s, bool repack) {
+  int rc = check_render_args(ctx, a, "psl_map_iters(geometry iteration)");
+  if (rc) return rc;
+  if (!ctx->pre_I || !g || !g->g_geo_feats) { set_error("geo_iter_impl: neighbour lists / gradient buffer missing"); return PSL_ERR_STATE; }
+  DecodeArgs d;
+  fill_decode_args(ctx, a, d);
+  if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
+  GeoIterRays gr{active, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, loss_acc, ctx->d_small, a->n_rays};
+  ProfScope ps(ctx, PROF_GEO_ITER, s, (fwd_flops_per_sample(d.flags) + bwd_flops_per_sample(d.flags)) * d.P);
+  return launch_geo_iter(ctx, d, gr, g->g_geo_feats, g->feat_row_map, wl, s);
+}
+}  // namespace psl
+
 extern "C" int psl_render_fwd(psl_ctx* ctx, const psl_render_args* a, void* stream) {
   return render_fwd_impl(ctx, a, (hipStream_t)stream, true);
 }
@@ -335,11 +366,11 @@ extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
 
 static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
                                          "adam", "misc", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
-                                         "decode_bwd_track", "knn_side_stream", "knn_prefetch"};
+                                         "decode_bwd_track", "knn_side_stream", "knn_prefetch", "geo_iter"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_decode_split; int knn_trace_dump(); }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_decode_split, g_geo_fused; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
@@ -349,6 +380,7 @@ extern "C" int psl_debug_option(const char* name, int value) {
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_overlap")) { psl::g_knn_overlap = value; return PSL_OK; }
   if (!strcmp(name, "decode_split")) { psl::g_decode_split = value; return PSL_OK; }
+  if (!strcmp(name, "geo_fused")) { psl::g_geo_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_trace_dump")) return psl::knn_trace_dump();
   set_error("psl_debug_option: unknown option %s", name);
   return PSL_ERR_ARG;

@@ -102,6 +102,7 @@ enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BW
                 PROF_ADAM, PROF_MISC, PROF_DECODE_FWD_GEO, PROF_DECODE_BWD_GEO, PROF_DECODE_FWD_TRK, PROF_DECODE_BWD_TRK,
                 PROF_KNN_SIDE,   // the mapper's k-NN block prefetch while it runs on the side stream (off the critical path)
                 PROF_KNN_PREFETCH,   // ... and on the main stream (first block of a call): the per-ray kernel, 10^4..10^5 rays per launch
+                PROF_GEO_ITER,       // geometry-stage mapper iteration in one launch (decode fwd + compositing + loss + decode bwd)
                 PROF_N };
 inline int prof_decode_slot(int flags, bool bwd) {
   if (!(flags & PSL_STAGE_COLOR)) return bwd ? PROF_DECODE_BWD_GEO : PROF_DECODE_FWD_GEO;
@@ -109,6 +110,7 @@ inline int prof_decode_slot(int flags, bool bwd) {
   return bwd ? PROF_DECODE_BWD : PROF_DECODE_FWD;
 }
 constexpr int PROF_RING = 4096;
+constexpr size_t kStageFrames = 64 * 96, kStageTabIters = 8192, kStageSlot = kStageFrames + kStageTabIters * 16;   // bytes
 
 }  // namespace psl
 
@@ -148,6 +150,9 @@ struct psl_ctx {
   hipEvent_t ev_knn_ready[2] = {nullptr, nullptr}, ev_knn_free = nullptr;
   bool dw_defer_reduce = false;   // psl_map_iters: launch_dw leaves the chunk reduction to the Adam launch (dw_ra)
   psl::DwReduceArgs dw_ra{};
+  // pinned host staging of psl_map_iters' per-call tables (frame descriptors, Adam constants): four slots, one event each,
+  // so that the asynchronous uploads never read memory that has gone out of scope and the call needs no stream sync
+  char* h_stage = nullptr; hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr}; int stage_next = 0;
   float4* adam_tab = nullptr; size_t adam_tab_cap = 0;            // per-iteration (lr/bc1, sqrt(bc2)) of the two row groups
   unsigned long long* adam_rows = nullptr;                        // feature rows stepped by the lazy Adam since the last profile read
   unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read

@@ -32,6 +32,17 @@ struct BlkTrace {
     o[0] = w0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - c0;
   }
 };
+// ray-level arguments of the one-launch geometry-stage iteration (psl_decode_geo.hip)
+struct GeoIterRays {
+  const int* active;            // [R] 1 = ray passed the depth filters (common.py:173-179, Mapper.py:507-514)
+  float coef;                   // sigmoid coefficient of the mapper (Mapper.py:45)
+  float *depth, *var, *rgb;     // [R], [R], [R][3] render outputs (rgb = 0 in this stage)
+  unsigned char* valid;         // [R]
+  double* loss_acc;             // [4]: sum |d_gt - d|, (colour: unused), #rays in the mask
+  float* zero64;                // accumulators of a later colour-stage backward (cleared here as the ray kernel does)
+  int n_rays;
+};
+
 int blk_trace_begin(DecodeArgs& a, int grid, hipStream_t s);                                  // psl_api.hip
 int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_tiles, int threads);
 #define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)

@@ -1,0 +1,68 @@
+// Small device helpers shared by the register-chained decode kernels (psl_decode_fwd2.hip, psl_decode_geo.hip).
+#pragma once
+#include "psl_decode.h"
+#include "psl_frag.h"
+
+namespace psl {
+
+__device__ __forceinline__ f32x4 ldfrag(const float* __restrict__ WF, int frag, int lane) {
+  return *reinterpret_cast<const f32x4*>(WF + (size_t)frag * FRAG + lane * 4);
+}
+__device__ __forceinline__ f32x4 ldbias(const float* __restrict__ WF, int layer_bias_off, int nt, int g) {
+  return *reinterpret_cast<const f32x4*>(WF + layer_bias_off + nt * 16 + 4 * g);
+}
+// four k-steps: acc += A-fragment (4 floats) x B registers (4 floats)
+__device__ __forceinline__ void mma4(f32x4& acc, const f32x4& a, const f32x4& b) {
+  acc = mfma16(a[0], b[0], acc);
+  acc = mfma16(a[1], b[1], acc);
+  acc = mfma16(a[2], b[2], acc);
+  acc = mfma16(a[3], b[3], acc);
+}
+// nothing is scheduled across this point: pins the hand-written order "request the fragments of step s + D, then issue
+// the MFMAs of step s" (left alone, the scheduler hoists every data-independent weight load to the top and spills)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// sum over the 8 consecutive lanes that hold the 8 neighbours of one sample, as three DPP moves (full-rate VALU; the
+// __shfl_xor form goes through ds_bpermute: ~100 cycles of LDS latency per step, 24 steps per wave here)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group8_sum(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_mov<0x141>(v);    // row_half_mirror: lane i <-> 7 - i inside each group of 8 (both quads hold their own sum)
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry role
+// The geometry decoder of one tile as a flat list of "steps" (one k-group = 4 k-steps for both 16-column output tiles):
+// fragment indices, which registers feed the B operand, which accumulator pair receives.  The list is walked fully
+// unrolled with the weight fragments of step s + GEO_AHEAD requested before the MFMAs of step s (the weights do not
+// depend on the data, so the prefetch runs across layer boundaries).
+struct GStep { int f0, f1, bsel, dst, layer_end; };   // bsel: 0..5 embedding groups, 6..7 hidden, 8..9 interpolated feature
+struct GSteps { GStep s[40]; int n; };
+constexpr GSteps make_geo_steps() {
+  GSteps g{};
+  int n = 0;
+  const int FLs[5] = {FL_G0, FL_G1, FL_G2, FL_G3, FL_G4};
+  const int FLf[5] = {FL_GF0, FL_GF1, FL_GF2, FL_GF3, FL_GF4};
+  for (int i = 0; i < 5; ++i) {
+    const int L = FLs[i], nq = kFLayers[L].ngroups, first = ffirst(L);
+    for (int q = 0; q < nq; ++q) {
+      int bsel = 0;
+      if (i == 0) bsel = q;
+      else if (i == 3) bsel = q < 6 ? q : 6 + (q - 6);
+      else bsel = 6 + q;
+      g.s[n++] = GStep{first + q, first + nq + q, bsel, 0, 0};
+    }
+    const int ff = ffirst(FLf[i]);
+    for (int q = 0; q < 2; ++q) g.s[n++] = GStep{ff + q, ff + 2 + q, 8 + q, 1, q == 1 ? i + 1 : 0};
+  }
+  for (int q = 0; q < 2; ++q) g.s[n++] = GStep{ffirst(FL_GOUT) + q, -1, 6 + q, 2, 0};
+  g.n = n;
+  return g;
+}
+constexpr GSteps kGeo = make_geo_steps();
+
+
+}  // namespace psl

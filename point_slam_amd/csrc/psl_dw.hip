@@ -237,7 +237,9 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
       const DwJob& J = d.job[j];
       total += (double)J.rows * J.n_tiles * J.k_tiles * (J.aq * J.bq) / 4.0;
     }
-    double per_item = std::max(total / 1000.0, 64.0 * 16 / 4);      // MFMAs per item (>= 64 rows of a full tile)
+    static int n_items_target = -1;   // PSL_DW_ITEMS: wavefronts the work is cut into (default 1 000 ~ one per SIMD)
+    if (n_items_target < 0) { const char* e = getenv("PSL_DW_ITEMS"); n_items_target = e ? atoi(e) : 1000; if (n_items_target < 64) n_items_target = 1000; }
+    double per_item = std::max(total / (double)n_items_target, 64.0 * 16 / 4);      // MFMAs per item (>= 64 rows of a full tile)
     if (chunk_rows > 0) per_item = chunk_rows * 16 / 4.0;           // PSL_DW_CHUNK: rows per chunk of a FULL tile
     int base = 0;
     for (int j = 0; j < nj; ++j) {

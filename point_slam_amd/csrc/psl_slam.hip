@@ -12,6 +12,8 @@ namespace psl {
 
 int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool repack);
 int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s);
+int geo_iter_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, const int* active, double* loss_acc,
+                  const AdamWorklist* wl, hipStream_t s, bool repack);
 
 // quad2rotation (src/common.py:225-248), same operation order
 __device__ __forceinline__ void quat_to_rot(const float* q, float R[3][3]) {
@@ -763,6 +765,8 @@ int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 // colour-stage decode as separate F_theta / trunk kernels: 0 = fused tile kernels (default: measured faster),
 // 1 = split from 2 048 samples per launch on, 2 = split always
 int g_decode_split = env_flag("PSL_DECODE_SPLIT", 0);
+// geometry-stage mapper iterations as ONE launch (psl_decode_geo.hip) instead of decode fwd / ray kernel / decode bwd
+int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -963,7 +967,15 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
                                                c->dw_defer_reduce = false; } } pre_guard{ctx};
   ctx->fused_ray = true;
   ctx->dw_defer_reduce = g_dw_fused != 0;   // the chunk partials of the dW kernel are summed inside the Adam launch
-  std::vector<float4> tab_host;
+  // host staging of this call's tables: a pinned slot whose previous upload (four calls ago) has certainly been consumed
+  const bool staged = ctx->h_stage && (size_t)m->n_iters <= kStageTabIters && sizeof(FrameDev) * (size_t)m->n_frames <= kStageFrames;
+  char* slot = nullptr;
+  if (staged) {
+    const int si = ctx->stage_next; ctx->stage_next = (si + 1) & 3;
+    PSL_HIP(hipEventSynchronize(ctx->ev_stage[si]));     // returns at once unless the host is > 3 mapped frames ahead
+    slot = ctx->h_stage + (size_t)si * kStageSlot;
+  }
+  std::vector<float4> tab_vec;
   if (m->n_sel > 0) {
     // lazy Adam of the feature rows (k_map_adam_lazy): upto_geo | upto_col | stamp | count[n_iters] | list | touched_geo |
     // touched_col
@@ -987,7 +999,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       PSL_HIP(hipMalloc(&ctx->adam_tab, sizeof(float4) * ((size_t)m->n_iters + 64))); ctx->adam_tab_cap = (size_t)m->n_iters + 64;
       dbg_range("adam_tab", ctx->adam_tab, sizeof(float4) * ctx->adam_tab_cap);
     }
-    tab_host.resize(m->n_iters);
+    float4* tab_host = staged ? (float4*)(slot + kStageFrames) : (tab_vec.resize(m->n_iters), tab_vec.data());
     for (int it = 0; it < m->n_iters; ++it) {   // the constants launch_map_adam would compute for iteration `it`
       const bool cs = it > m->n_geo_iters;
       float4 t = make_float4(0.f, 1.f, 0.f, 1.f);
@@ -995,7 +1007,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       if (cs) adam_consts(m->step0_col + (it - m->n_geo_iters), m->lr_col, 0.9f, 0.999f, t.z, t.w);
       tab_host[it] = t;
     }
-    PSL_HIP(hipMemcpyAsync(ctx->adam_tab, tab_host.data(), sizeof(float4) * m->n_iters, hipMemcpyHostToDevice, s));
+    PSL_HIP(hipMemcpyAsync(ctx->adam_tab, tab_host, sizeof(float4) * m->n_iters, hipMemcpyHostToDevice, s));
   }
   if (ctx->loss_acc_cap < m->n_iters) {
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
@@ -1024,13 +1036,15 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     if (m->frames[f].r_query) dbg_range("map.r_query", m->frames[f].r_query, sizeof(float) * (size_t)m->cam.H * m->cam.W);
   }
   {
-    std::vector<FrameDev> fh(m->n_frames);
+    std::vector<FrameDev> fvec;
+    FrameDev* fh = staged ? (FrameDev*)slot : (fvec.resize(m->n_frames), fvec.data());
     for (int f = 0; f < m->n_frames; ++f) {
       fh[f].depth = m->frames[f].depth; fh[f].color = m->frames[f].color; fh[f].r_query = m->frames[f].r_query;
       memcpy(fh[f].c2w, m->frames[f].c2w, sizeof(float) * 12);
     }
-    PSL_HIP(hipMemcpyAsync(fdev, fh.data(), sizeof(FrameDev) * m->n_frames, hipMemcpyHostToDevice, s));
-    PSL_HIP(hipStreamSynchronize(s));   // fh goes out of scope; once per mapped frame
+    PSL_HIP(hipMemcpyAsync(fdev, fh, sizeof(FrameDev) * m->n_frames, hipMemcpyHostToDevice, s));
+    if (staged) PSL_HIP(hipEventRecord(ctx->ev_stage[(ctx->stage_next + 3) & 3], s));   // both uploads of this slot are enqueued
+    else PSL_HIP(hipStreamSynchronize(s));   // oversized call: the tables live on this stack frame
   }
   psl_render_args ra{};
   memset(&ra, 0, sizeof(ra));
@@ -1103,8 +1117,6 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     ra.fallback_col = m->fallback + (size_t)it * 64 + 32;
     // the forward weights only change after the decoder was stepped (colour stage with train_decoder)
     const bool repack = it == 0;   // afterwards the fused Adam kernel keeps the forward-layout copy in step
-    int rc = render_fwd_impl(ctx, &ra, s, repack);
-    if (rc) return rc;
     // lazy Adam: rows the next iteration reads must be up to date; its lists exist unless a prefetch block ends here
     const bool lazy = ctx->adam_upto != nullptr && g_lazy_adam != 0;
     const bool dense = !lazy || it + 1 == m->n_iters || (it + 1) % kblock == 0;
@@ -1112,6 +1124,16 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     if (lazy && !dense)   // distinct rows of this iteration's and the next iteration's neighbour lists
       wl = AdamWorklist{ctx->pre_I, ctx->pre_I + (size_t)n * S * K, n * S * K / 4, m->row_map, ctx->adam_need, it + 1,
                         ctx->adam_list, ctx->adam_count + it};
+    int rc;
+    const bool geo_one_launch = !color_stage && g_geo_fused != 0;
+    if (geo_one_launch) {
+      // stage 'geometry': decode forward, compositing, loss, compositing backward and decode backward of whole ray triples
+      // per wavefront, ONE launch (+ the work list of this iteration's Adam as extra workgroups)
+      rc = geo_iter_impl(ctx, &ra, &rg, b.active, ctx->loss_acc + 4 * (size_t)it, &wl, s, repack);
+      if (rc) return rc;
+    } else {
+    rc = render_fwd_impl(ctx, &ra, s, repack);
+    if (rc) return rc;
     { // compositing + mapper loss + compositing backward in one launch (+ the work list of this iteration's Adam)
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
       const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
@@ -1124,6 +1146,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
     if (rc) return rc;
+    }
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
     // decoder only once they have received a gradient (colour stage) -- torch skips params whose .grad is None.
     const float lr_geo = color_stage ? m->lr_geo_color_stage : m->lr_geo_geo_stage;

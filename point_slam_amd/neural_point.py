@@ -87,7 +87,7 @@ class HipNeuralPointCloud(object):
 
     def __reduce__(self):
         # the reference shares its cloud between the tracker and mapper PROCESSES through a BaseManager proxy
-        # (src/Point_SLAM.py:256-281); a native context (device buffers, grid index) belongs to one process
+        # (src/Point_SLAM.py:93-97,189-207); a native context (device buffers, grid index) belongs to one process
         raise TypeError("HipNeuralPointCloud cannot be pickled or sent to another process: run tracker and mapper in one "
                         "process per GPU (INTEGRATION.md section 2)")
 

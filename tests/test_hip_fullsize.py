@@ -231,3 +231,65 @@ def test_loss_parity_vs_oracle_at_1m_points(world, oracle_world, kind, n_pix):
         if kind == "map_color":
             assert rep["g_col_rel_l2"] < 1e-3 and rep["g_col_cos"] > 0.99999
             assert rep["g_params_rel_l2"] < 1e-3 and rep["g_params_cos"] > 0.99999
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: synthetic 1280x960 stream, 2 M seeded neural points (the grid index works with <= 2^22 cells:
+# untested at that density before round 3)
+@pytest.fixture(scope="module")
+def world_cfg5():
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.config import default_config
+    from point_slam_amd.slam import Frame, HipSLAM
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    cam = syn.intrinsics(1280, 960)
+    torch.manual_seed(1219)
+    s = HipSLAM(cfg, cam, device="cuda:0", max_points=2_400_000, engine="native")
+    pts = syn.seed_cloud(cam, 2_000_000, n_views=64, seed=1219)
+    s.seed_points(pts)
+    c2w = syn.pose(200.0, dev)
+    depth, color = syn.render_frame(cam, c2w)
+    r_add, r_q = syn.dynamic_radii(color, cfg)
+    fr = Frame(0, depth, color, r_add, r_q, c2w)
+    return dict(cfg=cfg, cam=cam, slam=s, pts=pts, frame=fr, dev=dev)
+
+
+def test_cfg5_knn_exact_at_2m_points(world_cfg5):
+    """Free-query and ray-mode k-NN (every kernel variant) at 2 M points / 1280x960: bit-exact against the oracle."""
+    from oracle import pointslam_oracle as O
+    w = world_cfg5
+    assert w["slam"].npc.pts_num() == 2_000_000
+    ro, rd, gd, gc, rq = _rays(w, 1200, 21)
+    z = O.z_samples(gd.cpu(), 0.98, 1.02, 5)
+    q = O.sample_points(ro.cpu(), rd.cpu(), z)
+    r = rq.cpu().repeat_interleave(5)
+    D, I, cnt = w["slam"].npc.find_neighbors_faiss(q.to(w["dev"]), step="query", dynamic_radius=r.to(w["dev"]))
+    Do, Io = O.knn_exact(w["pts"], q, 8)
+    inr = Do <= (r * r)[:, None]
+    Io_m = torch.where(inr, Io, torch.full_like(Io, -1))
+    assert torch.equal(I.cpu(), Io_m) and torch.equal(cnt.cpu(), O.neighbor_count(Do, r))
+    report(test="cfg5_knn", points=2_000_000, queries=int(q.shape[0]), mean_cnt=float(cnt.float().mean()))
+
+
+def test_cfg5_render_split_invariance_and_loss_parity(world_cfg5):
+    """2 M points, 1280x960: the render of 6 000 rays equals the same rays in three launches, and one tracker / one
+    colour-stage mapper iteration agree with the oracle to BASELINE's 1e-4 at the loss level."""
+    from tests import parity_probe as PP
+    w = world_cfg5
+    ro, rd, gd, gc, rq = _rays(w, 6000, 22)
+    d, v, c, valid = _render(w, ro, rd, gd, rq)
+    dd, cc = [], []
+    for a, b in [(0, 2500), (2500, 4000), (4000, 6000)]:
+        o = _render(w, ro[a:b].contiguous(), rd[a:b].contiguous(), gd[a:b].contiguous(), rq[a:b].contiguous())
+        dd.append(o[0]); cc.append(o[2])
+    e_d, e_c = float((d - torch.cat(dd)).abs().max()), float((c - torch.cat(cc)).abs().max())
+    assert e_d < 1e-5 and e_c < 2e-5 and float(valid.float().mean()) > 0.5
+    st = PP.oracle_state(w["slam"])
+    reps = [PP.probe(w["slam"], w["cfg"], w["cam"], w["frame"], kind, n, seed=300 + n, state=st)
+            for kind, n in (("tracker", 200), ("map_color", 1000))]
+    for rep in reps:
+        report(test="cfg5_loss_parity", **rep)
+        assert rep["points"] == 2_000_000 and rep["mask_mismatch"] == 0 and rep["valid_mismatch"] == 0
+        assert rep["loss_rel"] <= 1e-4 and rep["geo_loss_rel"] <= 1e-4 and rep["col_loss_rel"] <= 1e-4
+    report(test="cfg5_split", depth=e_d, rgb=e_c, valid_frac=float(valid.float().mean()))

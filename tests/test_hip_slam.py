@@ -273,7 +273,7 @@ def _map_switch_runs(n_it, variants, dev, frozen_decoder=False):
     cfg["mapping"]["fix_color_decoder"] = bool(frozen_decoder)
     L = _lib.lib()
     res, draws = {}, None
-    keys = (b"lazy_adam", b"dw_fused", b"knn_overlap")
+    keys = (b"lazy_adam", b"dw_fused", b"knn_overlap", b"geo_fused")
     try:
         for name, opts in variants.items():
             for k in keys:
@@ -308,7 +308,7 @@ def _switch_metrics(r, ref):
 def test_map_native_scheduling_switches_agree():
     """The scheduling devices of psl_map_iters -- lazy Adam replay (work lists, dense catch-up at block ends), the dW chunk
     reduction inside the Adam launch, the k-NN prefetch of the next block on the side stream (throttled, a wavefront walks
-    several rays) -- change WHEN things are computed, not what.  Runs differ by the order of the float atomics of the
+    several rays), the one-launch geometry-stage iteration (psl_decode_geo.hip) -- change WHEN things are computed, not what.  Runs differ by the order of the float atomics of the
     feature scatter, and Adam amplifies that noise (rows with tiny gradients move ~lr per step in a direction the noise
     decides):
       * 24 iterations (replay gaps up to ~20 steps, decoder training, noise still small): every switch within 3x the
@@ -321,7 +321,8 @@ def test_map_native_scheduling_switches_agree():
     dev = torch.device("cuda:0")
     keys = ("loss_rel_max", "loss_rel_mean", "geo_mean", "col_mean", "geo_frac_gt_1e3", "col_frac_gt_1e3")
     all_variants = {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0},
-                    "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0}}
+                    "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0},
+                    "geometry_stage_in_three_launches": {b"geo_fused": 0}}
     for n_it, variants, frozen in ((24, all_variants, False), (150, all_variants, True)):
         res = _map_switch_runs(n_it, variants, dev, frozen_decoder=frozen)
         ref = res["all_on"]
