@@ -38,6 +38,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   const int p = min(p0 + min(rl, GI_TILE - 1), a.P - 1);
   const float* __restrict__ M = a.master;
   f32x4 W0[kGeo.n], W1[kGeo.n];
+  PSL_STAMP(0);
   const SampleGeom sg = sample_geom(a, p);
   // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171)
   int nb[K];
@@ -58,6 +59,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
 #pragma unroll
   for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
   const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150)
+  PSL_STAMP(1);
   f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -76,6 +78,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
     for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
   }
   sched_fence();
+  PSL_STAMP(2);
 #pragma unroll
   for (int st = 0; st < GEO_AHEAD; ++st) {
     W0[st] = ldfrag(WF, kGeo.s[st].f0, lane);
@@ -93,6 +96,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
       const float v = fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
       eg[q][r] = (16 * q + 4 * g + r < EG) ? v : 0.f;
     }
+  PSL_STAMP(3);
   // ---- five blocks: h = relu(W_i h + b_i) + (Wc_i c + bc_i); the embedding is re-attached after block 2
   f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   f32x4 acc[2], u[2], oo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -137,6 +141,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   }
   // occupancy logit of sample rl (lanes g == 0 hold it); raw[~point_mask, -1] = -100 (Renderer.py:189-190)
   const float occ = has ? (oo[0][0] + oo[1][0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
+  PSL_STAMP(4);
 
   // ---------------------------------------------------------------- compositing + loss + compositing backward
   // Every lane evaluates its OWN ray (the five samples sit in lanes 5 j .. 5 j + 4 of lane group 0) and keeps the
@@ -202,6 +207,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
     if (lcnt != 0.0) atomicAdd(&gr.loss_acc[2], lcnt);
   }
 
+  PSL_STAMP(5);
   // ---------------------------------------------------------------- geometry decoder backward (psl_decode_bwd2.hip geo role)
   f32x4 G[2], dcg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -236,6 +242,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
     }
   }
   sched_fence();
+  PSL_STAMP(6);
   // ---- scatter w_k * dC into the geometry feature rows
   const bool hasl = live && has;
 #pragma unroll
@@ -252,6 +259,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
       }
     }
   }
+  PSL_STAMP(7);
 }
 
 // work list of the lazy Adam (psl_ray.hip: adam_worklist_role) for 64-thread workgroups
@@ -307,11 +315,25 @@ int launch_geo_iter(psl_ctx* ctx, const DecodeArgs& a_in, const GeoIterRays& gr,
   if (wl) w = *wl;
   const int n_tiles = (gr.n_rays + 2) / 3;
   const int n_wl = (w.I_a && w.n4 > 0) ? std::min(((w.I_b ? 2 : 1) * w.n4 + 63) / 64, 512) : 0;
+  static unsigned long long* dbg = nullptr;
+  static int dbg_on = -1;
+  if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+  if (dbg_on) {
+    if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long)));
+    PSL_HIP(hipMemsetAsync(dbg, 0, 64 * sizeof(unsigned long long), s));
+    a.dbg = dbg;
+  }
   { int rc = blk_trace_begin(a, n_tiles + n_wl, s); if (rc) return rc; }
   hipLaunchKernelGGL(k_geo_iter, dim3(n_tiles + n_wl), dim3(64), 0, s, a, (const float*)ctx->wf, (const float*)ctx->wb, gr, g_geo,
                      row_map, ctx->touched_geo, w, n_tiles, n_wl);
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, "geo_iter", n_tiles + n_wl, n_tiles, 64); if (rc) return rc; }
+  if (dbg_on) {
+    unsigned long long h[8];
+    PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[psl geo_iter P=%d] nbr+weights %llu gather %llu frag-prefetch+sin %llu layers %llu | composite %llu | bwd layers %llu scatter %llu | total %llu\n",
+            a.P, h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6], h[7] - h[0]);
+  }
   return PSL_OK;
 }
 

@@ -5,6 +5,7 @@
 // depth = sum(w z)/W, var = sum(w (z-depth)^2).  S = 5 samples fit in registers: one lane per ray.
 #include "psl_common.h"
 #include "psl_device.h"
+#include "psl_adam.h"
 
 namespace psl {
 
@@ -328,31 +329,6 @@ int launch_ray_grad(const float4* dp, const float4* dp2, const float* z, const f
 }
 
 // ------------------------------------------------------------------------ Adam
-// torch.optim.Adam (defaults, no weight decay / amsgrad):
-//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-// Dense over every element each step (the reference steps all frustum-selected rows, Mapper.py:394-402).
-// Written in the operation order of torch's single-tensor path (lerp_, mul_/addcmul_, sqrt/div/add_, addcdiv_).
-__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr_bc1, float sqrt_bc2,
-                                            float b1, float b2, float eps) {
-  m = m + (1.0f - b1) * (g - m);
-  v = v * b2 + ((1.0f - b2) * g) * g;
-  float denom = sqrtf(v) / sqrt_bc2 + eps;
-  p = p + ((-lr_bc1) * m) / denom;
-}
-
-// A replayed step of the lazy Adam: the gradient is zero.  m and v are the expressions of adam_update with g = 0, bit for
-// bit.  The parameter increment -lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps) uses the hardware reciprocal and square root
-// (1 ulp each) instead of the correctly rounded quotient and root: the replay loop is a serial chain per row, and the
-// IEEE sequences made one step cost ~1 us on a lone wavefront.  The increment is ~1e-3 of the step size itself
-// ~1e-3 |p|; two ulp of it are ~1e-13 |p|, far below the rounding of the sum p + increment.
-__device__ __forceinline__ void adam_replay(float& p, float& m, float& v, float lr_bc1, float inv_sqrt_bc2, float b1,
-                                            float b2, float eps) {
-  m = m + (1.0f - b1) * (0.f - m);
-  v = v * b2;
-  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_sqrt_bc2, eps);
-  p = fmaf((-lr_bc1) * m, __builtin_amdgcn_rcpf(denom), p);
-}
-
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long long n, float lr_bc1, float sqrt_bc2,
                                               float b1, float b2, float eps, int zero_grad) {
@@ -460,83 +436,14 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
   }
 }
 
-// Feature rows, lazily.  torch.optim.Adam steps every selected row in every iteration, also the ones without a gradient
-// (m decays, p keeps moving): ~10^5 rows x 2 groups x 7 accesses of 128 B per iteration, 30-50 us of pure HBM time,
-// although an iteration reads and writes only the ~2x10^4 rows next to its samples.  A row's update depends on nothing
-// but its own (p, g, m, v) and the step's constants, so the steps a row missed are replayed later IN REGISTERS, in order
-// (m and v bit-identical to the dense sweep, p to ~1e-13 relative: adam_replay).  A row is brought up to date when
-//  (a) this iteration's neighbour lists name it (it may have received a gradient: `touched`), or
-//  (b) the next iteration's lists name it (the forward will read it) -- both sets come from the prefetched lists as a
-//      de-duplicated work list (k_adam_worklist), or
-//  (c) dense pass (list == null): the next lists are not known yet (end of a k-NN prefetch block) or the call ends.
-// upto[row] = number of this call's iterations already applied; -1 = never had a gradient (m = v = 0, every missed
-// step is exactly +0).  32 lanes per row, one channel each: the replay is a serial chain per channel and the slowest
-// row of a launch sets its duration.
 __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_rows, int n_groups,
                                                        float b1, float b2, float eps, AdamLazy lz) {
   int blk0 = blockIdx.x;
   if (blk0 >= nb_rows * n_groups) { adam_par_segment(par, blk0 - nb_rows * n_groups, b1, b2, eps); return; }
+  __shared__ float2 stab[kAdamTabLds];
   const bool is_col = blk0 >= nb_rows;
   if (is_col) blk0 -= nb_rows;
-  const AdamRowsSeg& sg = is_col ? col : geo;
-  const int n_work = lz.list ? *lz.count : sg.n_rows;
-  // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
-  // made each step a full memory round trip)
-  __shared__ float2 stab[kAdamTabLds];
-  const int nt = lz.it - lz.base + 1;
-  if ((long long)blk0 * 8 < n_work) {
-    for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
-      const float4 v = lz.tab[lz.base + t];
-      stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-    }
-  }
-  __syncthreads();
-  auto consts = [&](int t) -> float2 {
-    const int k = t - lz.base;
-    if (k >= 0 && k < kAdamTabLds) return stab[k];
-    const float4 v = lz.tab[t];
-    return is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-  };
-  const int e = threadIdx.x & 31;
-  unsigned long long done = 0;
-  // the grid is a fixed number of workgroups per group: each walks the work list with a stride (a grid sized to the
-  // list's CAPACITY -- 10^4 workgroups per group, most of them past its length -- cost more to dispatch than to run)
-  for (long long blk = blk0; blk * 8 < n_work; blk += nb_rows) {
-    const long long ridx = blk * 8 + (threadIdx.x >> 5);
-    int row = -1;
-    if (ridx < n_work) row = lz.list ? lz.list[ridx] : (int)ridx;
-    bool has_g = false, work = false;
-    int u = -1;
-    if (row >= 0) {
-      has_g = sg.touched[row] != 0;
-      u = sg.upto[row];
-      work = has_g || (u >= 0 && u <= lz.it);
-    }
-    if (!work) continue;
-    if (u < 0) u = lz.it;                                 // first gradient of this row: the missed steps were +0
-    float* pptr = sg.feats + (size_t)sg.rows[row] * C + e;
-    const size_t k = (size_t)row * C + e;
-    float* gp = reinterpret_cast<float*>(sg.g) + k;
-    float* mp = reinterpret_cast<float*>(sg.m) + k;
-    float* vp = reinterpret_cast<float*>(sg.v) + k;
-    float pp = *pptr, mm = *mp, vv = *vp;
-    float gg = 0.f;
-    if (has_g) { gg = *gp; *gp = 0.f; }
-    for (int t = u; t < lz.it; ++t) {                     // replay of the steps without a gradient
-      const float2 ab = consts(t);
-      adam_replay(pp, mm, vv, ab.x, __builtin_amdgcn_rcpf(ab.y), b1, b2, eps);
-    }
-    const float2 ab = consts(lz.it);
-    adam_update(pp, gg, mm, vv, ab.x, ab.y, b1, b2, eps);
-    *pptr = pp; *mp = mm; *vp = vv;
-    // the 32 lanes of a row sit in one wavefront and have all read touched/upto above
-    if (e == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; ++done; }
-  }
-  if (lz.rows_done) {                                     // one atomic per wavefront, spread over 256 cache lines
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) done += __shfl_xor(done, o);
-    if ((threadIdx.x & 63) == 0 && done) atomicAdd(lz.rows_done + 8 * (blockIdx.x & 255), done);
-  }
+  adam_lazy_rows_block(is_col ? col : geo, is_col, blk0, nb_rows, b1, b2, eps, lz, stab);
 }
 
 }  // namespace psl
@@ -558,17 +465,21 @@ void psl::adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, flo
 }
 
 namespace psl {
+int adam_lazy_row_blocks(const AdamLazy& lazy, int n_rows) {
+  // a fixed grid of at most 2 048 workgroups per group (8 rows each per trip) walks the list with a stride
+  const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, n_rows) : n_rows;
+  return (int)std::min<long long>((rows + 7) / 8, 2048);
+}
+
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par, AdamLazy lazy) {
+                    float lr_par, hipStream_t s, int step_par, AdamLazy lazy, bool rows_done_elsewhere) {
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
   const int nb_par = par.n <= 0 ? 0 : (par.slabs ? (par.n + 31) / 32 : (par.n + 255) / 256);
   if (lazy.tab) {
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
-    const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, geo.n_rows) : geo.n_rows;
-    // a fixed grid of at most 2 048 workgroups per group (8 rows each per trip) walks the list with a stride
-    const int nb_rows = (int)std::min<long long>((rows + 7) / 8, 2048), n_groups = col.n_rows > 0 ? 2 : 1;
+    const int nb_rows = rows_done_elsewhere ? 0 : adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
     if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
     hipLaunchKernelGGL(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
                        0.9f, 0.999f, 1e-8f, lazy);
