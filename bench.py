@@ -266,7 +266,14 @@ def cpu_baseline(cfg, cam, n_points):
     t_col = timed(n_c, mp["pixels"], False, "color")
     r = mp["geo_iter_ratio"]
     per_frame = tr["iters"] * t_track + mp["iters"] / mp["every_frame"] * (r * t_geo + (1.0 - r) * t_col)
-    return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=n_thr, kind="port",
+    calib = None
+    try:      # the imported reference against this port, per iteration, measured in the build container (oracle/calibrate_cpu_baseline.py)
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_calibration.json")))
+        calib = dict(reference_over_port_per_frame=cj["reference_over_port_per_frame"], threads=cj["threads"],
+                     file="profiles/r03_cpu_calibration.json")
+    except Exception:
+        pass
+    return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=n_thr, kind="port", calibration_vs_imported_reference=calib,
                 sample=f"kind=port because /root/reference does not exist on the GPU box (the imported reference can only "
                        f"run in the build container, which has no GPU to compare with); "
                        f"oracle (cKDTree exact 8-NN + torch fp32 + autograd + Adam), N={n_points}: {n_t} tracking iters "

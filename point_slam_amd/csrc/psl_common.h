@@ -149,7 +149,6 @@ struct psl_ctx {
   hipStream_t stream2 = nullptr;                 // low-priority stream of the mapper's k-NN block prefetch
   hipEvent_t ev_knn_ready[2] = {nullptr, nullptr}, ev_knn_free = nullptr;
   bool dw_defer_reduce = false;   // psl_map_iters: launch_dw leaves the chunk reduction to the Adam launch (dw_ra)
-  const void* dw_rows = nullptr;  // psl_map_iters: DwRowsRole* -- the dW launch also steps the feature rows (lazy Adam)
   psl::DwReduceArgs dw_ra{};
   // pinned host staging of psl_map_iters' per-call tables (frame descriptors, Adam constants): four slots, one event each,
   // so that the asynchronous uploads never read memory that has gone out of scope and the call needs no stream sync
@@ -243,10 +242,7 @@ struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2;
                     // (what k_dw_reduce would have written), taken inside the Adam launch
                     const float* slabs; const float* g_brel; DwReduceArgs ra; };
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, nullptr, 0, 0, nullptr, 0},
-                    bool rows_done_elsewhere = false);
-// the feature-row part of an iteration's lazy Adam, run by extra workgroups of the dW kernel (psl_dw.hip)
-struct DwRowsRole { AdamRowsSeg geo, col; AdamLazy lz; int nb_rows; };
+                    float lr_par, hipStream_t s, int step_par = -1, AdamLazy lazy = AdamLazy{nullptr, nullptr, nullptr, 0, 0, nullptr, 0});
 int adam_lazy_row_blocks(const AdamLazy& lazy, int n_rows);
 void adam_consts(int step, float lr, float b1, float b2, float& lr_bc1, float& sqrt_bc2);
 // work list of the lazy Adam, built by extra workgroups of k_map_ray_fused (see adam_worklist_role)

@@ -32,6 +32,35 @@ struct BlkTrace {
     o[0] = w0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - c0;
   }
 };
+// work list of the lazy Adam (as adam_worklist_role, psl_ray.hip), one int4 of neighbour indices per lane; wave-level appends
+__device__ __forceinline__ void worklist_role_wave(const AdamWorklist& wl, int i) {
+  const int lane = threadIdx.x & 63;
+  int4 v = make_int4(-1, -1, -1, -1);
+  if (i < wl.n4) v = reinterpret_cast<const int4*>(wl.I_a)[i];
+  else if (wl.I_b && i < 2 * wl.n4) v = reinterpret_cast<const int4*>(wl.I_b)[i - wl.n4];
+  const int ent[4] = {v.x, v.y, v.z, v.w};
+  int r[4];
+  bool fresh[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) r[c] = (ent[c] >= 0) ? wl.row_map[ent[c]] : -1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) fresh[c] = (r[c] >= 0) ? (atomicExch(&wl.stamp_arr[r[c]], wl.stamp) != wl.stamp) : false;
+  unsigned long long mask[4];
+  int tot = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { mask[c] = __ballot(fresh[c]); tot += __popcll(mask[c]); }
+  if (tot == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(wl.count, tot);
+  base = __shfl(base, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (fresh[c]) wl.list[base + __popcll(mask[c] & ((1ull << lane) - 1ull))] = r[c];
+    base += __popcll(mask[c]);
+  }
+}
+
+
 // ray-level arguments of the one-launch geometry-stage iteration (psl_decode_geo.hip)
 struct GeoIterRays {
   const int* active;            // [R] 1 = ray passed the depth filters (common.py:173-179, Mapper.py:507-514)

@@ -65,4 +65,51 @@ constexpr GSteps make_geo_steps() {
 constexpr GSteps kGeo = make_geo_steps();
 
 
+// ------------------------------------------------------------------------------------------------ coalesced gradient scatter
+// The backward adds  w_k * dC[sample][32]  (interpolation) or dX[pair][32] (F_theta) to feature-gradient rows chosen by the
+// neighbour lists.  Straight from the accumulator layout -- lane (sample, g) holds channels 16 jt + 4 g + r -- one atomic
+// instruction touches 16 different rows with four scattered dwords each, and the eight instructions of a neighbour slot
+// return to the same 16 lines eight times: phase stamps put 40 % of the one-launch geometry iteration and 15-30 % of the
+// colour backward into this scatter.  Transposed through a per-wave LDS tile instead, an instruction covers TWO WHOLE ROWS
+// (lanes = 2 x 32 consecutive channels, two 128-byte lines): an eighth of the line operations at the L2 atomic units, the
+// same products, the same (unordered) sums.
+struct ScatterLds { float dc[TILE * C]; float w[TILE * K]; int row[TILE * K]; };      // 3 KB per wavefront
+__device__ __forceinline__ void scatter_interp_rows(ScatterLds& L, float* __restrict__ g_feat, unsigned char* __restrict__ touched,
+                                                    const f32x4 (&dc)[2], const float (&w)[K], const int (&dst)[K]) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  *reinterpret_cast<f32x4*>(L.dc + rl * C + 4 * g) = dc[0];
+  *reinterpret_cast<f32x4*>(L.dc + rl * C + 16 + 4 * g) = dc[1];
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { L.w[rl * K + k] = w[k]; L.row[rl * K + k] = dst[k]; }
+  }
+  wave_lds_sync();
+  const int ch = lane & 31, half = lane >> 5;
+#pragma unroll 8
+  for (int pi = 0; pi < TILE * K; pi += 2) {
+    const int pair = pi + half;
+    const int row = L.row[pair];
+    if (row >= 0) {
+      atomic_add_f32(&g_feat[(size_t)row * C + ch], L.w[pair] * L.dc[(pair >> 3) * C + ch]);
+      if (touched && ch == 0) touched[row] = 1;
+    }
+  }
+}
+// per-pair rows: lane (pair rl, g) holds dX[pair][16 jt + 4 g + r]; dst = gradient row of the lane's pair (-1: none)
+__device__ __forceinline__ void scatter_pair_rows(float* tile /*[16][32] per-wave LDS*/, float* __restrict__ g_feat, const f32x4 (&dx)[2],
+                                                  int dst) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  *reinterpret_cast<f32x4*>(tile + rl * C + 4 * g) = dx[0];
+  *reinterpret_cast<f32x4*>(tile + rl * C + 16 + 4 * g) = dx[1];
+  wave_lds_sync();
+  const int ch = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int pi = 0; pi < TILE; pi += 2) {
+    const int pair = pi + half;
+    const int row = __shfl(dst, pair);                  // lanes 0..15 (g = 0) hold the 16 pairs' rows
+    if (row >= 0) atomic_add_f32(&g_feat[(size_t)row * C + ch], tile[pair * C + ch]);
+  }
+  wave_lds_sync();
+}
+
 }  // namespace psl

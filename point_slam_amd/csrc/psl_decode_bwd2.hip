@@ -19,6 +19,7 @@
 #include <type_traits>
 #include "psl_decode.h"
 #include "psl_frag.h"
+#include "psl_decode2.h"
 
 namespace psl {
 
@@ -71,12 +72,13 @@ struct Bwd2Lds {
                        total = oDE + 16 * LD_E2,           // ~6.3 K floats = 25 KB
                        oWn = (total + 3) / 4 * 4, total_nbr = oWn + kNbrFragsB * FRAG;   // 73 KB
 };
-static_assert(8 * 16 * LD_X2 <= 2 * 8 * FRAG, "sXe fits the dz buffers");
+static_assert(8 * TILE * C <= 2 * 8 * FRAG && 16 * LD_X2 <= TILE * C, "the per-wave scatter / rel-pos tiles fit the dz buffers");
 
 // ------------------------------------------------------------------------------------------------ geometry role
 // One wavefront per tile.  d_occ flows for masked samples too (straight-through of the -100 write, Renderer.py:189-190).
 template <bool PTSG>
-__device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0) {
+__device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0,
+                                             ScatterLds& sl) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
   const bool live = p0 + rl < a.P;
@@ -148,23 +150,22 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
     }
   }
   sched_fence_b();
-  // ---- scatter w_k * dC into the geometry feature rows; dL/dw_k for the pose gradient
+  // ---- scatter w_k * dC into the geometry feature rows (coalesced: psl_decode2.h); dL/dw_k for the pose gradient
   float gw[K];
+  if (featg) {
+    int dst[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = nb[k];
+      dst[k] = (i >= 0 && has && w[k] != 0.f) ? (o.row_map ? o.row_map[i] : i) : -1;
+    }
+    scatter_interp_rows(sl, o.g_geo, o.t_geo, dcg, w, dst);
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     gw[k] = 0.f;
     const int i = nb[k];
     if (i >= 0 && has) {
-      if (featg && w[k] != 0.f) {
-        const int row = o.row_map ? o.row_map[i] : i;
-        if (row >= 0) {
-#pragma unroll
-          for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_geo[(size_t)row * C + jt * 16 + 4 * g + r], w[k] * dcg[jt][r]);
-          if (o.t_geo && g == 0) o.t_geo[row] = 1;
-        }
-      }
       if constexpr (PTSG) {
         const float* frow = a.geo_feats + (size_t)i * C + 4 * g;
         const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow), f1 = *reinterpret_cast<const f32x4*>(frow + 16);
@@ -322,6 +323,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       return *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g);
     };
     f32x4 ynext = ld_y(4);
+    // fc_c fragments of the NEXT layer in flight during the current one: dL/dc is the first product of a layer and its
+    // weights were the one load whose L2 latency stood exposed at every layer start (phase stamps: "pre" 3-5 k cycles)
+    f32x4 wcn[2] = {ldfragb(WB, bfirst(BL_CF4) + 0 * 8 + nt, lane), ldfragb(WB, bfirst(BL_CF4) + 1 * 8 + nt, lane)};
     auto layer = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
       constexpr int BLs[5] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4};
@@ -334,8 +338,11 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
         for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, fb + nt * 8 + q, lane);
       }
-      wc[0] = ldfragb(WB, bfirst(BLf[i]) + 0 * 8 + nt, lane);
-      wc[1] = ldfragb(WB, bfirst(BLf[i]) + 1 * 8 + nt, lane);
+      wc[0] = wcn[0]; wc[1] = wcn[1];
+      if (i > 0) {
+        wcn[0] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 0 * 8 + nt, lane);
+        wcn[1] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 1 * 8 + nt, lane);
+      }
       const f32x4 y = ynext;
       if (i > 0) ynext = ld_y(i > 0 ? i - 1 : 0);
       sched_fence_b();
@@ -513,6 +520,17 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
       for (int it = 0; it < 4; ++it) dx[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       const bool need_rel = parg || PTSG;
+      // sin / cos of the wave's 160 (pair, frequency) entries as the forward saved them: requested before the dX product
+      // (three dependent global loads used to sit between the MFMAs and the rel-pos contraction)
+      float psn[3], pcs[3];
+      if (need_rel && a.ws.n_x) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int e = lane + 64 * u, r2 = min(e, 16 * ERF - 1) / ERF, f = min(e, 16 * ERF - 1) - r2 * ERF;
+          const float* xr = a.ws.n_x + ((size_t)p0 * K + 16 * wave + r2) * NX;
+          psn[u] = xr[f]; pcs[u] = xr[ERF + f];
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         sched_fence_b();
@@ -531,19 +549,15 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         }
       }
       PSL_STAMP(21);
-      // feature part -> scattered into the colour feature rows straight from the accumulators
-      if (featg && dst >= 0) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], dx[jt][r]);
-      }
+      // feature part -> the colour feature rows, two whole rows per atomic instruction (psl_decode2.h); the wave's 2 KiB slice
+      // of the (dead) dz buffers is the transpose tile, the rel-pos tile below reuses it
+      if (featg) { const f32x4 dxf[2] = {dx[0], dx[1]}; scatter_pair_rows(sXe + wave * TILE * C, o.g_col, dxf, dst); }
       // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y].  Step 1: dL/dy for the 160 (row, frequency)
       // pairs of this wave, in place in its LDS tile.  Step 2: the two small contractions over them --
       // dB_rel[a][f] = sum_rows dy[row][f] rel[row][a] (30 lanes) and dp[s][a] -= sum_{rows of s, f} dy[row][f] B[a][f]
       // (6 lanes) -- so that a wave ends in 30 (+6) LDS atomics instead of 480 (+480).
       if (need_rel) {
-        float* xw = sXe + wave * 16 * LD_X2;
+        float* xw = sXe + wave * TILE * C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           xw[rl * LD_X2 + 4 * g + r] = dx[2][r];
@@ -551,14 +565,16 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
         }
         wave_lds_sync();
         const float* Brel = M + MO(PI_C_BREL);
-        for (int e = lane; e < 16 * ERF; e += 64) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int e = lane + 64 * u;
+          if (e >= 16 * ERF) break;
           const int r2 = e / ERF, f = e - r2 * ERF;
           const int row2 = 16 * wave + r2, s2 = row2 >> 3;
           const bool lv = (p0 + s2) < a.P && sI[row2] >= 0;
           float sn, cs;
           if (a.ws.n_x) {     // the forward pass saved [sin | cos] in the first 20 columns of F_theta's input
-            const float* xr = a.ws.n_x + ((size_t)p0 * K + row2) * NX;
-            sn = xr[f]; cs = xr[ERF + f];
+            sn = psn[u]; cs = pcs[u];
           } else {
             fast_sincosf(fourier_phase(sRel[row2 * 3], sRel[row2 * 3 + 1], sRel[row2 * 3 + 2], Brel, ERF, f), sn, cs);
           }
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(WG, 4) void k_trunk_bwd(DecodeArgs a, Bwd2Out o, co
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   if ((int)blockIdx.x >= color_tiles) {       // geometry role: one tile per wave
     const int tile = ((int)blockIdx.x - color_tiles) * 8 + wave;
-    if (tile < tiles) geo_tile_bwd<false>(a, o, WB, tile * TILE);
+    if (tile < tiles) geo_tile_bwd<false>(a, o, WB, tile * TILE, reinterpret_cast<ScatterLds*>(smem)[wave]);
     bt.done(a);
     return;
   }
@@ -710,6 +726,9 @@ __global__ __launch_bounds__(WG, 4) void k_trunk_bwd(DecodeArgs a, Bwd2Out o, co
       return *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g);
     };
     f32x4 ynext = ld_y(4);
+    // fc_c fragments of the NEXT layer in flight during the current one: dL/dc is the first product of a layer and its
+    // weights were the one load whose L2 latency stood exposed at every layer start (phase stamps: "pre" 3-5 k cycles)
+    f32x4 wcn[2] = {ldfragb(WB, bfirst(BL_CF4) + 0 * 8 + nt, lane), ldfragb(WB, bfirst(BL_CF4) + 1 * 8 + nt, lane)};
     auto layer = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
       constexpr int BLs[5] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4};
@@ -721,8 +740,11 @@ __global__ __launch_bounds__(WG, 4) void k_trunk_bwd(DecodeArgs a, Bwd2Out o, co
 #pragma unroll
         for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, fb + nt * 8 + q, lane);
       }
-      wc[0] = ldfragb(WB, bfirst(BLf[i]) + 0 * 8 + nt, lane);
-      wc[1] = ldfragb(WB, bfirst(BLf[i]) + 1 * 8 + nt, lane);
+      wc[0] = wcn[0]; wc[1] = wcn[1];
+      if (i > 0) {
+        wcn[0] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 0 * 8 + nt, lane);
+        wcn[1] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 1 * 8 + nt, lane);
+      }
       const f32x4 y = ynext;
       if (i > 0) ynext = ld_y(i > 0 ? i - 1 : 0);
       sched_fence_b();
@@ -940,7 +962,7 @@ __global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_d
     color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE);
   } else {
     if (threadIdx.x >= 64) return;
-    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE);
+    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem));
   }
   bt.done(a);
 }
@@ -990,8 +1012,8 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
     if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
     else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
   } else {
-    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
-    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), 0, s, a, o, WB, 0);
+    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
+    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
   }
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }

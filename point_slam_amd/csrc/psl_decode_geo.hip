@@ -29,7 +29,7 @@ constexpr int GI_TILE = 15;     // samples per wavefront: three rays
 
 __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* __restrict__ WF, const float* __restrict__ WB,
                                               const GeoIterRays& gr, float* g_geo, const int* __restrict__ row_map,
-                                              unsigned char* t_geo, int tile) {
+                                              unsigned char* t_geo, int tile, ScatterLds& sl) {
   constexpr int GEO_AHEAD = 4;
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p0 = tile * GI_TILE;
@@ -142,6 +142,10 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   // occupancy logit of sample rl (lanes g == 0 hold it); raw[~point_mask, -1] = -100 (Renderer.py:189-190)
   const float occ = has ? (oo[0][0] + oo[1][0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
   PSL_STAMP(4);
+  // the backward's first layer of fragments flies during the compositing
+  f32x4 bwf[4], bwb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { bwf[e] = ldfragb_g(WB, bfirst(BL_GF4) + e, lane); bwb[e] = ldfragb_g(WB, bfirst(BL_G4) + e, lane); }
 
   // ---------------------------------------------------------------- compositing + loss + compositing backward
   // Every lane evaluates its OWN ray (the five samples sit in lanes 5 j .. 5 j + 4 of lane group 0) and keeps the
@@ -214,80 +218,54 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) G[nt][r] = docc * M[MO(PI_G_OUT) + nt * 16 + 4 * g + r];
+  // (the eight fragments of layer i - 1 are requested before the MFMAs of layer i: a layer's weights used to be fetched
+  //  where they were needed, ~3.5 k cycles of exposed L2 latency per layer on a lone wavefront)
 #pragma unroll
   for (int i = 4; i >= 0; --i) {
     constexpr int BLs[5] = {BL_G0, BL_G1, BL_G2, BL_G3, BL_G4};
     constexpr int BLf[5] = {BL_GF0, BL_GF1, BL_GF2, BL_GF3, BL_GF4};
+    sched_fence();
+    f32x4 wfc[4], wbc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wfc[e] = bwf[e]; wbc[e] = bwb[e]; }
+    if (i > 0) {
+      const int ffn = bfirst(BLf[i > 0 ? i - 1 : 0]), fbn = bfirst(BLs[i > 0 ? i - 1 : 0]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bwf[e] = ldfragb_g(WB, ffn + e, lane); if (i > 1) bwb[e] = ldfragb_g(WB, fbn + e, lane); }
+    }
     sched_fence();
     f32x4 dz[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dz[nt][r] = ((ym[i] >> (4 * nt + r)) & 1u) ? G[nt][r] : 0.f;      // ReLU
-    // dL/dc += Wc_i^T G   (fc_c.i.weight [32][32])
-    const int ff = bfirst(BLf[i]);
+    // dL/dc += Wc_i^T G   (fc_c.i.weight [32][32]); fragment (it, q) of a layer sits at first + 2 it + q
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) mma4(dcg[it], ldfragb_g(WB, ff + it * 2 + q, lane), G[q]);
+      for (int it = 0; it < 2; ++it) mma4(dcg[it], wfc[it * 2 + q], G[q]);
     // dL/d(input of layer i) = W_i^T dz
     if (i > 0) {
-      const int fb = bfirst(BLs[i]);
       f32x4 Gn[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int it = 0; it < 2; ++it) mma4(Gn[it], ldfragb_g(WB, fb + it * 2 + q, lane), dz[q]);   // hidden tiles come first
+        for (int it = 0; it < 2; ++it) mma4(Gn[it], wbc[it * 2 + q], dz[q]);   // hidden tiles come first
       G[0] = Gn[0]; G[1] = Gn[1];
     }
   }
   sched_fence();
   PSL_STAMP(6);
-  // ---- scatter w_k * dC into the geometry feature rows
+  // ---- scatter w_k * dC into the geometry feature rows (coalesced: psl_decode2.h)
   const bool hasl = live && has;
+  int dst[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int i = nb[k];
-    if (i >= 0 && hasl && w[k] != 0.f) {
-      const int row = row_map ? row_map[i] : i;
-      if (row >= 0) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomic_add_f32(&g_geo[(size_t)row * C + jt * 16 + 4 * g + r], w[k] * dcg[jt][r]);
-        if (t_geo && g == 0) t_geo[row] = 1;
-      }
-    }
+    dst[k] = (i >= 0 && hasl && w[k] != 0.f) ? (row_map ? row_map[i] : i) : -1;
   }
+  scatter_interp_rows(sl, g_geo, t_geo, dcg, w, dst);
   PSL_STAMP(7);
-}
-
-// work list of the lazy Adam (psl_ray.hip: adam_worklist_role) for 64-thread workgroups
-__device__ __forceinline__ void geo_iter_worklist(const AdamWorklist& wl, int i) {
-  const int lane = threadIdx.x & 63;
-  int4 v = make_int4(-1, -1, -1, -1);
-  if (i < wl.n4) v = reinterpret_cast<const int4*>(wl.I_a)[i];
-  else if (wl.I_b && i < 2 * wl.n4) v = reinterpret_cast<const int4*>(wl.I_b)[i - wl.n4];
-  const int ent[4] = {v.x, v.y, v.z, v.w};
-  int r[4];
-  bool fresh[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) r[c] = (ent[c] >= 0) ? wl.row_map[ent[c]] : -1;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) fresh[c] = (r[c] >= 0) ? (atomicExch(&wl.stamp_arr[r[c]], wl.stamp) != wl.stamp) : false;
-  unsigned long long mask[4];
-  int tot = 0;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { mask[c] = __ballot(fresh[c]); tot += __popcll(mask[c]); }
-  if (tot == 0) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(wl.count, tot);
-  base = __shfl(base, 0);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (fresh[c]) wl.list[base + __popcll(mask[c] & ((1ull << lane) - 1ull))] = r[c];
-    base += __popcll(mask[c]);
-  }
 }
 
 // grid: [0, n_tiles) one wavefront per ray triple, then the work-list role (four list entries per thread, 8 waves' worth of
@@ -295,14 +273,15 @@ __device__ __forceinline__ void geo_iter_worklist(const AdamWorklist& wl, int i)
 __global__ __launch_bounds__(64, 2) void k_geo_iter(DecodeArgs a, const float* __restrict__ WF, const float* __restrict__ WB,
                                                     GeoIterRays gr, float* g_geo, const int* __restrict__ row_map,
                                                     unsigned char* t_geo, AdamWorklist wl, int n_tiles, int n_wl_blocks) {
+  __shared__ ScatterLds sl;
   BlkTrace bt(a);
   if ((int)blockIdx.x < n_tiles) {
     if (blockIdx.x == 0 && gr.zero64) gr.zero64[threadIdx.x] = 0.f;
-    geo_iter_tile(a, WF, WB, gr, g_geo, row_map, t_geo, (int)blockIdx.x);
+    geo_iter_tile(a, WF, WB, gr, g_geo, row_map, t_geo, (int)blockIdx.x, sl);
   } else {
     const int total = (wl.I_b ? 2 : 1) * wl.n4;
     for (int i = ((int)blockIdx.x - n_tiles) * 64 + (int)threadIdx.x; i - (int)threadIdx.x < total; i += n_wl_blocks * 64)
-      geo_iter_worklist(wl, i);
+      worklist_role_wave(wl, i);
   }
   bt.done(a);
 }

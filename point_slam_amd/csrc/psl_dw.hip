@@ -6,7 +6,6 @@
 #include <cstdlib>
 #include <algorithm>
 #include "psl_decode.h"
-#include "psl_adam.h"
 
 namespace psl {
 
@@ -149,18 +148,7 @@ __device__ __forceinline__ void dw_tile(const DwJob& J, int item, int chunk, flo
   }
 }
 
-// grid: [0, dw_blocks) the GEMM items, four per workgroup; then -- psl_map_iters, colour stage -- the feature-row part of this
-// iteration's lazy Adam (rr.nb_rows workgroups per feature set): the rows need the scattered gradients of the backward that
-// has just finished, not the parameter gradients computed here, so they are stepped on the SIMDs the GEMM leaves idle
-__global__ __launch_bounds__(256) void k_dw(DwArgs d, DwRowsRole rr, int dw_blocks) {
-  if ((int)blockIdx.x >= dw_blocks) {
-    __shared__ float2 stab[kAdamTabLds];
-    int blk0 = (int)blockIdx.x - dw_blocks;
-    const bool is_col = blk0 >= rr.nb_rows;
-    if (is_col) blk0 -= rr.nb_rows;
-    adam_lazy_rows_block(is_col ? rr.col : rr.geo, is_col, blk0, rr.nb_rows, 0.9f, 0.999f, 1e-8f, rr.lz, stab);
-    return;
-  }
+__global__ __launch_bounds__(256) void k_dw(DwArgs d) {
   const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (wid >= d.n_items) return;
   int item = wid;
@@ -286,11 +274,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   }
   const int base = finish();
   d.n_jobs = nj; d.n_items = base; d.slabs = ctx->dw_slabs;
-  DwRowsRole rr{};
-  int row_blocks = 0;
-  if (ctx->dw_rows) { rr = *(const DwRowsRole*)ctx->dw_rows; row_blocks = 2 * rr.nb_rows; }
-  const int dw_blocks = (base + 3) / 4;
-  hipLaunchKernelGGL(k_dw, dim3((unsigned)(dw_blocks + row_blocks)), dim3(256), 0, s, d, rr, dw_blocks);
+  hipLaunchKernelGGL(k_dw, dim3((unsigned)((base + 3) / 4)), dim3(256), 0, s, d);
   PSL_LAUNCH_CHECK();
   ctx->dw_ra = ra;
   if (ctx->dw_defer_reduce) return PSL_OK;   // psl_map_iters: the Adam launch sums the chunk partials itself

@@ -472,14 +472,14 @@ int adam_lazy_row_blocks(const AdamLazy& lazy, int n_rows) {
 }
 
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
-                    float lr_par, hipStream_t s, int step_par, AdamLazy lazy, bool rows_done_elsewhere) {
+                    float lr_par, hipStream_t s, int step_par, AdamLazy lazy) {
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
   const int nb_par = par.n <= 0 ? 0 : (par.slabs ? (par.n + 31) / 32 : (par.n + 255) / 256);
   if (lazy.tab) {
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
-    const int nb_rows = rows_done_elsewhere ? 0 : adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
+    const int nb_rows = adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
     if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
     hipLaunchKernelGGL(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
                        0.9f, 0.999f, 1e-8f, lazy);

@@ -767,8 +767,6 @@ int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 int g_decode_split = env_flag("PSL_DECODE_SPLIT", 0);
 // geometry-stage mapper iterations as ONE launch (psl_decode_geo.hip) instead of decode fwd / ray kernel / decode bwd
 int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
-// colour stage: the feature rows of the lazy Adam are stepped by extra workgroups of the dW launch
-int g_rows_in_dw = env_flag("PSL_ROWS_IN_DW", 1);
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -1127,7 +1125,6 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       wl = AdamWorklist{ctx->pre_I, ctx->pre_I + (size_t)n * S * K, n * S * K / 4, m->row_map, ctx->adam_need, it + 1,
                         ctx->adam_list, ctx->adam_count + it};
     int rc;
-    bool rows_in_dw = false;
     const bool geo_one_launch = !color_stage && g_geo_fused != 0;
     if (geo_one_launch) {
       // stage 'geometry': decode forward, compositing, loss, compositing backward and decode backward of whole ray triples
@@ -1147,24 +1144,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
                                 m->pix_per_frame, ex_g, s, &wl);
       if (rc) return rc;
     }
-    // colour stage with a training decoder: the dW launch inside render_bwd_impl also steps the feature rows
-    DwRowsRole rows_role{};
-    rows_in_dw = lazy && color_stage && m->train_decoder && g_rows_in_dw != 0;
-    if (rows_in_dw) {
-      AdamRowsSeg& sg = rows_role.geo; AdamRowsSeg& sc = rows_role.col;
-      sg.feats = (float*)m->geo_feats; sg.rows = m->sel_rows; sg.g = (float4*)m->g_geo; sg.m = (float4*)m->adam_geo;
-      sg.v = (float4*)(m->adam_geo + (size_t)m->n_sel * C); sg.n_rows = m->n_sel; sg.touched = ctx->touched_geo;
-      sg.upto = ctx->adam_upto;
-      sc.feats = (float*)m->col_feats; sc.rows = m->sel_rows; sc.g = (float4*)m->g_col; sc.m = (float4*)m->adam_col;
-      sc.v = (float4*)(m->adam_col + (size_t)m->n_sel * C); sc.n_rows = m->n_sel; sc.touched = ctx->touched_col;
-      sc.upto = ctx->adam_upto + m->n_sel;
-      rows_role.lz = AdamLazy{ctx->adam_tab, dense ? nullptr : ctx->adam_list, ctx->adam_count + it, ctx->adam_list_cap, it,
-                              ctx->adam_rows, it - it % kblock};
-      rows_role.nb_rows = adam_lazy_row_blocks(rows_role.lz, m->n_sel);
-      ctx->dw_rows = &rows_role;
-    }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
-    ctx->dw_rows = nullptr;
     if (rc) return rc;
     }
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour
@@ -1196,7 +1176,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       AdamLazy lz{lazy ? ctx->adam_tab : nullptr, (lazy && !dense) ? ctx->adam_list : nullptr,
                   lazy ? ctx->adam_count + it : nullptr, ctx->adam_list_cap, it, ctx->adam_rows, it - it % kblock};
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
-                           st + m->step0_params, lz, rows_in_dw);
+                           st + m->step0_params, lz);
       if (rc) return rc;
       if (ex && color_stage) {   // mlp_exposure is part of color_decoder.parameters() (decoders_lr); latent lr 0.001
         hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, m->n_frames, ex_g, ex_aff, ex_act,
