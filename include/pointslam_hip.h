@@ -110,6 +110,17 @@ int psl_knn(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scal
 int psl_dedupe_count(psl_ctx* ctx, const float* q, const float* r_per_query, float r_scalar, int nq, int idx_limit,
                      int32_t* cnt_out, void* stream);
 
+/* The cross-rank half of the same admission test (point_slam_amd/dist.py, step 2): n_loc = block_first[n_blocks]
+ * locations of three points each (N_add = 3, src/neural_point.py:126-143; the middle point is the surface point and
+ * carries the radius) arrive in rank blocks, block b = locations [block_first[b], block_first[b+1]).  On entry keep[l] is 1
+ * for every location that passed the test against the base map; a location of block b loses its flag when one of the
+ * three points of a location of an EARLIER block that is still kept lies strictly inside its radius.  Blocks are
+ * processed in order on `stream` (block 0 is admitted as it stands), so every rank derives the same flags.
+ * pts / radius: device pointers to the first point's xyz and radius, strides in floats between consecutive points.
+ * block_first: HOST array of n_blocks + 1 ascending offsets. */
+int psl_dedupe_blocks(psl_ctx* ctx, const float* pts, int pts_stride, const float* radius, int radius_stride,
+                      const int32_t* block_first, int n_blocks, uint8_t* keep, void* stream);
+
 /* NeuralPointCloud.sample_near_pcl marching test (src/neural_point.py:232-249): hits[ray][step] = 1 when the point
  * rays_o + rays_d * z_steps[row][step] has >= 1 neural point strictly inside `radius` (cfg radius_query).
  * z_steps is [n_rows][n_steps]; row = step_row[ray], or 0 when step_row is NULL (render_img marches each of its
@@ -354,7 +365,10 @@ int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world, const flo
 int psl_sync(psl_ctx* ctx, void* stream);
 /* Kernel-class timing with HIP events recorded on the launch stream (for bench.py's roofline):
  * enable, run, then read per class: total ms, launch count, algorithmic work (FLOP for the MFMA-bound
- * classes decode_fwd/decode_bwd/dw_gemm, bytes for the HBM-bound ones). psl_profile_read synchronises. */
+ * classes decode_fwd/decode_bwd/dw_gemm, bytes for the HBM-bound ones). psl_profile_read synchronises.
+ * on = 0: off; 1: every launch is bracketed; n > 1: one launch in n of each class, the classes staggered (a marker is a
+ * barrier packet: bracketing every launch of a five-launch iteration perturbs what it measures); the totals
+ * psl_profile_read returns are then mean-of-the-bracketed x launches. */
 int psl_profile_enable(psl_ctx* ctx, int on);
 /* candidates (16-byte sorted-position records) the ray k-NN examined since the previous call: the k-NN's roofline is
  * 16 B x candidates / kernel time against the L2 bandwidth (its traffic is index-dependent).

@@ -406,14 +406,15 @@ extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
   ctx->prof_on = on;
   if (on) {
     memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work));
+    memset(ctx->prof_seen, 0, sizeof(ctx->prof_seen));
     PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
   }
   return PSL_OK;
 }
 
-// Per kernel class since psl_profile_enable(1): total device time (ms) of the recorded launches, launch count and the
-// algorithmic work (FLOP or bytes) attributed to them.  Synchronises the device.  When a class was launched more than
-// PROF_RING times only the last PROF_RING durations are available: ms is scaled to the full count.
+// Per kernel class since psl_profile_enable(n): total device time (ms), launch count and the algorithmic work (FLOP or
+// bytes) of ALL launches of the class.  Synchronises the device.  The time is the mean of the bracketed launches (one in
+// n; at most the last PROF_RING of them) times the launch count.
 extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, double* work_out, int cap) {
   if (!ctx || !ms_out || !count_out || !work_out) return PSL_ERR_ARG;
   PSL_HIP(hipDeviceSynchronize());
@@ -427,8 +428,8 @@ extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, do
       if (hipEventElapsedTime(&ms, ctx->ev[((size_t)i * PROF_RING + k) * 2], ctx->ev[((size_t)i * PROF_RING + k) * 2 + 1]) == hipSuccess)
         tot += ms;
     }
-    ms_out[i] = have > 0 ? tot * ((double)cnt / have) : 0.0;
-    count_out[i] = cnt;
+    ms_out[i] = have > 0 ? tot * ((double)ctx->prof_seen[i] / have) : 0.0;
+    count_out[i] = ctx->prof_seen[i];
     work_out[i] = ctx->prof_work[i];
   }
   if (n > (int)PROF_ADAM) {   // feature rows the lazy Adam stepped: 5 streams x 4 B x 32 channels each

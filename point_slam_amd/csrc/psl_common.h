@@ -171,7 +171,8 @@ struct psl_ctx {
   // profiling: a ring of HIP event pairs per kernel class, recorded on the launch stream
   int prof_on;
   hipEvent_t* ev;                    // [PROF_N][PROF_RING][2]
-  int prof_count[psl::PROF_N];       // launches recorded since enable (may exceed the ring)
+  int prof_count[psl::PROF_N];       // launches bracketed with events since enable (may exceed the ring)
+  int prof_seen[psl::PROF_N];        // launches since enable (prof_on = n > 1 brackets one in n, staggered by class)
   double prof_work[psl::PROF_N];     // algorithmic work (FLOP for MFMA classes, bytes for HBM classes) of those launches
   double prof_work_ring[psl::PROF_N];
 };
@@ -208,16 +209,23 @@ bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every lau
 void dbg_range(const char* name, const void* p, size_t bytes);
 
 struct ProfScope {  // brackets a kernel class with HIP events on the launch stream when profiling is on
-  psl_ctx* c; int slot; hipStream_t s; int k;
-  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0) : c(c_), slot(slot_), s(s_), k(0) {
+  // prof_on = n > 1: one launch in n of a class is bracketed, classes staggered, so that a bracketed launch runs between
+  // unbracketed neighbours (every marker is a barrier packet: bracketing all five launches of an iteration costs 44 %
+  // of the frame time and charges the markers of the neighbours to the short kernels)
+  psl_ctx* c; int slot; hipStream_t s; int k; bool on;
+  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0) : c(c_), slot(slot_), s(s_), k(0), on(false) {
     if (c && c->prof_on) {
-      k = c->prof_count[slot] % PROF_RING;
-      (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2], s);
+      const int n = c->prof_seen[slot]++;
       c->prof_work[slot] += work;
+      on = c->prof_on == 1 || (n + slot) % c->prof_on == 0;
+      if (on) {
+        k = c->prof_count[slot] % PROF_RING;
+        (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2], s);
+      }
     }
   }
   ~ProfScope() {
-    if (c && c->prof_on) {
+    if (on) {
       (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2 + 1], s);
       c->prof_count[slot]++;
     }

@@ -1297,6 +1297,52 @@ extern "C" int psl_dedupe_count(psl_ctx* ctx, const float* q, const float* r_per
   return PSL_OK;
 }
 
+// psl_dedupe_blocks: the cross-rank half of the merge's admission test.  Locations arrive in rank blocks; block b's
+// locations are tested against the points (three per location) of the locations of the blocks before it that are still
+// kept.  One launch per block, in block order, so the keep flags a block reads are final; one wavefront per location,
+// lanes stride over the earlier locations.  (dx*dx + dy*dy) + dz*dz unfused, as the grid search evaluates it.
+__global__ __launch_bounds__(256) void k_dedupe_block(const float* __restrict__ pts, int pts_stride, const float* __restrict__ rad,
+                                                      int rad_stride, int first, int last, unsigned char* __restrict__ keep) {
+  const int l = first + __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  if (l >= last || !keep[l]) return;
+  const int lane = threadIdx.x & 63;
+  const float* qp = pts + (size_t)(3 * l + 1) * pts_stride;       // the surface point is the middle one of the triplet
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const float r = rad[(size_t)(3 * l + 1) * rad_stride], r2 = __fmul_rn(r, r);
+  bool hit = false;
+  for (int j0 = 0; j0 < first && !hit; j0 += 64) {
+    const int j = j0 + lane;
+    bool h = false;
+    if (j < first && keep[j]) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float* p = pts + (size_t)(3 * j + t) * pts_stride;
+        const float dx = __fsub_rn(qx, p[0]), dy = __fsub_rn(qy, p[1]), dz = __fsub_rn(qz, p[2]);
+        h |= __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)) < r2;
+      }
+    }
+    hit = __any(h);
+  }
+  if (hit && lane == 0) keep[l] = 0;
+}
+
+extern "C" int psl_dedupe_blocks(psl_ctx* ctx, const float* pts, int pts_stride, const float* radius, int radius_stride,
+                                 const int32_t* block_first, int n_blocks, uint8_t* keep, void* stream) {
+  if (!ctx || !pts || !radius || !block_first || !keep || n_blocks < 0 || pts_stride < 3 || radius_stride < 1) {
+    set_error("psl_dedupe_blocks: bad argument"); return PSL_ERR_ARG;
+  }
+  for (int b = 0; b < n_blocks; ++b)
+    if (block_first[b] < 0 || block_first[b + 1] < block_first[b]) { set_error("psl_dedupe_blocks: block offsets must ascend"); return PSL_ERR_ARG; }
+  for (int b = 1; b < n_blocks; ++b) {
+    const int first = block_first[b], last = block_first[b + 1];
+    if (last == first || first == 0) continue;
+    hipLaunchKernelGGL(k_dedupe_block, dim3((last - first + 3) / 4), dim3(256), 0, (hipStream_t)stream, pts, pts_stride, radius,
+                       radius_stride, first, last, keep);
+  }
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
 extern "C" int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float* rays_d, int n_rays,
                                  const float* z_steps, const int32_t* step_row, int n_steps, float radius,
                                  uint8_t* hits, void* stream) {

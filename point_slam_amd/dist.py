@@ -111,21 +111,6 @@ def make_transport(npc, group=None, kind: Optional[str] = None):
 
 
 # ------------------------------------------------------------------------------------------------------- new points
-def _sqdist_any_within(loc: torch.Tensor, r: torch.Tensor, pts: torch.Tensor, chunk: int = 1 << 24) -> torch.Tensor:
-    """True where some point of `pts` lies strictly inside radius r_i of loc_i; (dx*dx + dy*dy) + dz*dz in fp32, unfused
-    (every torch op is its own kernel), the arithmetic of the grid search."""
-    out = torch.zeros(loc.shape[0], dtype=torch.bool, device=loc.device)
-    if loc.shape[0] == 0 or pts.shape[0] == 0:
-        return out
-    step = max(1, chunk // max(pts.shape[0], 1))
-    r2 = r * r
-    for s in range(0, loc.shape[0], step):
-        d = loc[s:s + step, None, :] - pts[None, :, :]
-        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
-        out[s:s + step] = (d2 < r2[s:s + step, None]).any(1)
-    return out
-
-
 def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transport=None) -> List[int]:
     """Exchange the points `npc` gained since it had n_base points and rebuild the replica in global rank order
     (steps 1-2 of the module docstring).  Returns the number of points every rank CONTRIBUTED; the number admitted
@@ -153,24 +138,14 @@ def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transpor
         rad = allrec[:, 67].reshape(-1, 3)[:, 1].contiguous()
         first = next(k for k, c in enumerate(counts) if c > 0)    # the first non-empty block is admitted whole
         lo = offs[first + 1] // 3
-        keep_loc = torch.ones(loc.shape[0], dtype=torch.bool, device=dev)
+        keep_loc = torch.ones(loc.shape[0], dtype=torch.uint8, device=dev)
         if lo < loc.shape[0] and n_base > 0:
             # vs the BASE map: one launch on the index as it stands (it still covers this rank's own tail; indices
             # >= n_base are ignored) -- no rebuild before the test
-            keep_loc[lo:] = npc.count_within(loc[lo:], rad[lo:], n_base) == 0
-        kept_pts = allrec[offs[first]:offs[first + 1], :3]
-        for k in range(first + 1, len(counts)):
-            if counts[k] == 0:
-                continue
-            a, b = offs[k] // 3, offs[k + 1] // 3
-            cand = keep_loc[a:b].clone()
-            if bool(cand.any()) and kept_pts.shape[0]:
-                idx = torch.nonzero(cand).flatten()
-                hit = _sqdist_any_within(loc[a:b][idx], rad[a:b][idx], kept_pts)
-                cand[idx[hit]] = False
-            keep_loc[a:b] = cand
-            blk = allrec[offs[k]:offs[k + 1], :3]
-            kept_pts = torch.cat([kept_pts, blk[cand[:, None].expand(-1, 3).reshape(-1)]], 0)
+            keep_loc[lo:] = (npc.count_within(loc[lo:], rad[lo:], n_base) == 0).to(torch.uint8)
+        # vs the blocks before it, in rank order (one launch per block, flags final when the next block reads them)
+        npc.dedupe_blocks(allrec, 0, 67, [o // 3 for o in offs], keep_loc)
+        keep_loc = keep_loc.bool()
         keep = keep_loc[:, None].expand(-1, 3).reshape(-1)
     kept = allrec[keep]
     npc.truncate(n_base)
@@ -227,7 +202,7 @@ class FrameParallelSync:
         if self._rows:
             rows, snap = torch.cat(self._rows), torch.cat(self._vals)
             delta = torch.cat([geo[rows], col[rows]], 1) - snap
-            ch = (delta != 0).any(1)
+            ch = torch.nonzero((delta != 0).any(1)).flatten()        # the one host sync of this half
             rows_c, delta_c, snap_c = rows[ch], delta[ch], snap[ch]
         else:
             rows_c = torch.zeros(0, dtype=torch.int64, device=dev)
@@ -240,22 +215,21 @@ class FrameParallelSync:
         if sum(counts):
             ids = allrec[:, 0].contiguous().view(torch.int32).long()
             uniq, inv = torch.unique(ids, return_inverse=True)       # sorted: the same order on every rank
-            tot = torch.zeros(uniq.shape[0], 64, device=dev)
-            cnt = torch.zeros(uniq.shape[0], device=dev)
+            allrec[:, 0] = 1.0                                       # column 0 now counts the contributors of a row
+            tot = torch.zeros(uniq.shape[0], REC_ROW, device=dev)
             off, mine = 0, None
             rank = dist.get_rank(self.group)
             for k, c in enumerate(counts):                           # rank order; ids are unique inside a block: plain adds
                 if c:
                     sl = inv[off:off + c]
-                    tot.index_add_(0, sl, allrec[off:off + c, 1:])
-                    cnt.index_add_(0, sl, torch.ones(c, device=dev))
+                    tot.index_add_(0, sl, allrec[off:off + c])
                     if k == rank:
                         mine = sl
                 off += c
             base = torch.cat([geo[uniq], col[uniq]], 1)              # rows this rank did not change still hold the snapshot
             if mine is not None:
                 base[mine] = snap_c
-            new = base + tot / cnt[:, None]
+            new = base + tot[:, 1:] / tot[:, :1]
             geo[uniq] = new[:, :32]
             col[uniq] = new[:, 32:]
         if self._rows:

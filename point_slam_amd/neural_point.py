@@ -196,6 +196,19 @@ class HipNeuralPointCloud(object):
                                                _lib.ptr(cnt), _lib.stream_ptr()), "psl_dedupe_count")
         return cnt
 
+    def dedupe_blocks(self, rec, pos_col, rad_col, block_first, keep):
+        """Cross-rank half of the admission test (psl_dedupe_blocks): `rec` [3 L, W] fp32 holds one record per point (xyz
+        at columns pos_col.., radius at rad_col), locations in rank blocks block_first[b]..block_first[b+1]; `keep` uint8
+        [L] is updated in place: a location loses its flag when a point of a still-kept location of an earlier block lies
+        strictly inside its radius."""
+        assert rec.dtype == torch.float32 and rec.is_contiguous() and keep.dtype == torch.uint8 and keep.is_contiguous()
+        import ctypes as C
+        bf = (C.c_int32 * len(block_first))(*[int(b) for b in block_first])
+        w = rec.shape[1]
+        _lib.check(_lib.lib().psl_dedupe_blocks(self._h, rec.data_ptr() + 4 * pos_col, w, rec.data_ptr() + 4 * rad_col, w, bf,
+                                                len(block_first) - 1, _lib.ptr(keep), _lib.stream_ptr()), "psl_dedupe_blocks")
+        return keep
+
     # ---- state upload (checkpoint / multi-GPU merge) ------------------------------------
     def set_points(self, pos: torch.Tensor, geo_feats: torch.Tensor = None, col_feats: torch.Tensor = None):
         """Replace the cloud by `pos` [N,3] (device tensor) and rebuild the index."""

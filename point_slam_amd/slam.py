@@ -43,15 +43,20 @@ class Frame:
         self.exposure = exposure  # [8] exposure latent of a keyframe (model.encode_exposure)
         self.grad_mag = None      # [H,W] f64 colour-gradient magnitude, filled on demand
 
-    def view(self) -> _lib.psl_frame_view:
+    def view(self, pose: bool = True) -> _lib.psl_frame_view:
+        """pose=False: the tracker reads the pose from its camera tensor on the device (psl_frame_view.c2w is "mapping
+        only"); the device-to-host copy of c2w would stall the host on everything queued so far, once per frame."""
         v = _lib.psl_frame_view()
         v.depth = self.depth.data_ptr()
         v.color = self.color.data_ptr()
         v.r_query = self.r_query.data_ptr() if self.r_query is not None else None
-        if self.c2w is not None:
-            flat = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
+        if pose and self.c2w is not None:
+            key = (id(self.c2w), self.c2w._version)
+            if getattr(self, "_c2w_host_key", None) != key:      # one copy per pose, not one per mapping call
+                self._c2w_host = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
+                self._c2w_host_key = key
             for i in range(12):
-                v.c2w[i] = flat[i]
+                v.c2w[i] = self._c2w_host[i]
         return v
 
 
@@ -214,7 +219,7 @@ class HipSLAM:
         a.cam = self.cam_intr
         a.edge_h, a.edge_w, a.n_iters, a.n_pix = eh, ew, n_iters, n_pix
         a.pix_idx, a.fallback = idx.data_ptr(), fb.data_ptr()
-        a.frame = frame.view()
+        a.frame = frame.view(pose=False)
         a.cam_tensor, a.adam_state, a.step0 = cam_t.data_ptr(), adam.data_ptr(), 0
         a.lr_T = tr["lr"]
         a.lr_quat = tr["lr"] * 0.2 if tr["separate_LR"] else tr["lr"]

@@ -31,6 +31,20 @@ class FakeCloud:
         d2 = ((loc[:, None, :] - pos[None]) ** 2).sum(-1)
         return (d2 < (radius * radius)[:, None]).sum(1)
 
+    def dedupe_blocks(self, rec, pos_col, rad_col, block_first, keep):
+        """psl_dedupe_blocks restated with torch on the host: block b against the kept locations of the blocks before it."""
+        pts = rec[:, pos_col:pos_col + 3].reshape(-1, 3, 3)
+        rad = rec[:, rad_col].reshape(-1, 3)[:, 1]
+        for b in range(1, len(block_first) - 1):
+            a, e = block_first[b], block_first[b + 1]
+            prev = pts[:a][keep[:a].bool()].reshape(-1, 3)
+            if e == a or prev.shape[0] == 0:
+                continue
+            d = pts[a:e, 1, None, :] - prev[None]
+            d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+            keep[a:e] &= (~(d2 < (rad[a:e] * rad[a:e])[:, None]).any(1)).to(torch.uint8)
+        return keep
+
     def truncate(self, n):
         if n != self.pos.shape[0]:
             self.index_ok = False

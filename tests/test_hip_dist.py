@@ -172,3 +172,35 @@ def test_native_rccl_transport_single_rank():
     assert n_empty == 0 and counts_e == [0]
     assert c == [300] and admitted == 300
     assert stats["rows_noted"] == 2 and stats["rows_sent"] == 1 and stats["rows_received"] == 1
+
+
+def test_dedupe_blocks_matches_brute_force():
+    """psl_dedupe_blocks against the host restatement the gloo test uses (tests/test_dist_gloo.py FakeCloud.dedupe_blocks):
+    ragged blocks with an empty one in the middle, locations packed so that about half collide; flags identical."""
+    from point_slam_amd.neural_point import HipNeuralPointCloud
+    from tests.helpers import base_cfg
+    from tests.test_dist_gloo import FakeCloud
+    dev = torch.device("cuda:0")
+    cfg = base_cfg()
+    cfg["mapping"] = dict(cfg["mapping"], device="cuda:0")
+    npc = HipNeuralPointCloud(cfg, max_points=1000, device="cuda:0")
+    g = torch.Generator().manual_seed(77)
+    counts = [130, 0, 257, 64, 1, 300]
+    L = sum(counts)
+    centres = torch.rand(L, 3, generator=g) * 0.6
+    pts = (centres[:, None, :] + torch.tensor([-0.01, 0.0, 0.01])[None, :, None]).reshape(-1, 3)
+    rec = torch.zeros(3 * L, 68)
+    rec[:, :3] = pts
+    rec[:, 67] = 0.02 + 0.06 * torch.rand(3 * L, generator=g)
+    first = [0]
+    for c in counts:
+        first.append(first[-1] + c)
+    keep0 = (torch.rand(L, generator=g) > 0.1).to(torch.uint8)          # some already rejected by the base test
+    ref = FakeCloud(torch.zeros(0, 3), torch.zeros(0, 32), torch.zeros(0, 32)).dedupe_blocks(rec, 0, 67, first, keep0.clone())
+    got = npc.dedupe_blocks(rec.to(dev), 0, 67, first, keep0.clone().to(dev)).cpu()
+    assert torch.equal(got, ref)
+    assert torch.equal(got[:counts[0]], keep0[:counts[0]])              # the first block is admitted as it stands
+    dropped = int(keep0.sum() - got.sum())
+    assert 50 < dropped < L - 50, dropped
+    from tests.test_hip_parity import report
+    report(test="dedupe_blocks", locations=L, dropped=dropped)

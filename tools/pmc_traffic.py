@@ -7,7 +7,7 @@ on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) streaming
 the kernels whose reads are such streams (the weight-fragment and activation streams of the register-chained decode
 kernels, the dW GEMM, Adam); WRITE_SIZE is taken as reported (uncalibrated there).
 
-usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc_<tag>/write.csv out.json
+usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc_<tag>/write.csv out.json [commit]
 """
 import json
 import sys
@@ -21,11 +21,12 @@ CLASS_OF = [   # (substring of the (possibly left-truncated) mangled kernel name
     ("2ILb1ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_track"),
     ("2ILb0ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo"),
     ("2ILb1ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo_track"),
+    ("k_geo_iter", lambda g: True, "geo_iter"),
     ("k_dwE", lambda g: True, "dw_gemm"),
     ("AdamRowsSeg", lambda g: True, "adam"),
     ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn"),
 ]
-DOUBLE_FETCH = {"decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
+DOUBLE_FETCH = {"geo_iter", "decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
                 "dw_gemm", "adam"}
 
 
@@ -63,6 +64,8 @@ def main():
                         fetch_size_kib_raw=round(f_kib, 1), write_size_kib_raw=round(w_kib, 1),
                         fetch_doubled=cls in DOUBLE_FETCH,
                         source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_probe.py")
+    res["_meta"] = dict(commit=sys.argv[4] if len(sys.argv) > 4 else None, command="bash tools/pmc_run.sh <tag> (tools/pmc_probe.py)",
+                        passes=["--pmc FETCH_SIZE", "--pmc WRITE_SIZE"])
     json.dump(res, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(res, indent=1))
 
