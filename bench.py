@@ -46,8 +46,9 @@ def parse():
     ap.add_argument("--exchange-every", type=int, default=2, help="mapped frames between point all-gathers (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=5,
-                    help="HIP-event bracket on one launch in N of every kernel class (1 = every launch)")
+    ap.add_argument("--event-stride", type=int, default=1,
+                    help="kernel-class timing on one launch in N of every class (1 = every launch, what the rocprofv3 "
+                         "trace of the same command averages over)")
     return ap.parse_args()
 
 
@@ -367,11 +368,11 @@ def main():
 
     # (1) the timed region proper: EXACTLY `steps` frames, no instrumentation -> `value`
     dt = timed(args.warmup)
-    # (2) the same `steps` frames of work again with HIP-event pairs on the launch stream around one launch in
-    #     --event-stride of every kernel class (classes staggered) -> `roofline`.  Kept apart from (1), and sampled,
-    #     because every marker is a barrier packet: with all five launches of an iteration bracketed the frame took 44 %
-    #     longer and the short kernels were charged their neighbours' markers (Adam 32 us by events vs 18 us in the
-    #     rocprofv3 trace).  The profiled wall time is reported as profiled_ms_per_step.
+    # (2) the same `steps` frames of work again with a HIP start/stop event pair on every kernel launch of the hot
+    #     classes (hipExtLaunchKernelGGL stamps the pair with the dispatch's own begin/end -- the timestamps rocprofv3
+    #     reports) -> `roofline`.  Kept apart from (1): event-carrying launches cost ~30 % of wall time here (marker
+    #     pairs -- hipEventRecord before/after -- cost 44 % and charged short kernels their neighbours' markers: Adam read
+    #     32 us against 18 us in the rocprofv3 trace).  The profiled wall time is reported as profiled_ms_per_step.
     prof, dt_prof = {}, None
     if not args.no_kernel_timing:
         _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, max(1, args.event_stride)))
@@ -438,8 +439,8 @@ def main():
                        "render_loss_rel_err_vs_reference": None},
             "roofline": roof,
             "profiled_ms_per_step": round(dt_prof / args.steps * 1e3, 3) if dt_prof else None,
-            "event_sampling": (f"HIP-event pair on 1 launch in {max(1, args.event_stride)} of each kernel class, classes staggered; "
-                               "class totals = mean of the bracketed launches x launches") if dt_prof else None,
+            "event_timing": (f"hipExtLaunchKernelGGL start/stop events on 1 launch in {max(1, args.event_stride)} of each kernel "
+                             "class; class totals = mean of the timed launches x launches") if dt_prof else None,
             "split": split,
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in per.items()},

@@ -8,6 +8,7 @@
 #include "psl_frag.h"
 
 namespace psl {
+thread_local ProfArm g_prof_arm = {nullptr, nullptr, false};
 
 static thread_local char g_err[512] = "";
 
@@ -124,7 +125,6 @@ RenderWs carve_ws(float* base, int n_rays, int flags) {
     if (color) {
       w.c_y = take(Pp * 5 * HC);
       w.d_out3 = take(Pp * 4);
-      w.dcc = take(Pp * C);
       if (relpos) {
         w.n_h1 = take(Pp * K * HC);
         if (flags & PSL_PTS_GRAD) w.n_out = take(Pp * K * C);     // only dL/dw -> dL/dp needs F_theta's outputs
@@ -292,13 +292,13 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
   fill_decode_args(ctx, a, d);
   if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
   if (!ctx->pre_I)
-  { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P);   // lower bound: query + 8 neighbour positions
+  { ProfScope ps(ctx, PROF_KNN, s, 108.0 * d.P, true);   // lower bound: query + 8 neighbour positions
     rc = knn_rays(ctx, a->rays_o, a->rays_d, a->gt_depth, a->z_vals, a->r_query, a->n_rays, d.ws.I, d.ws.cnt, s);
     if (rc) return rc; }
-  { ProfScope ps(ctx, prof_decode_slot(d.flags, false), s, fwd_flops_per_sample(d.flags) * d.P);
+  { ProfScope ps(ctx, prof_decode_slot(d.flags, false), s, fwd_flops_per_sample(d.flags) * d.P, true);
     rc = launch_decode_fwd2(ctx, d, s); if (rc) return rc; }
   if (!ctx->fused_ray)     // psl_map_iters composites, takes the loss and back-propagates it in one kernel of its own
-  { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays);
+  { ProfScope ps(ctx, PROF_COMPOSITE, s, 124.0 * a->n_rays, true);
     rc = launch_composite_fwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, d.ws.cnt, d.min_nn,
                               a->n_rays, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, d.ws.cw,
                               d.ws.ray_aux, s);
@@ -317,7 +317,7 @@ int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_gra
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
   if (!ctx->fused_ray)
-  { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays);
+  { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays, true);
     rc = launch_composite_bwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
                               g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, ctx->d_small, s);
     if (rc) return rc; }
@@ -346,7 +346,7 @@ int geo_iter_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads
   fill_decode_args(ctx, a, d);
   if (repack) { ProfScope ps(ctx, PROF_MISC, s); rc = repack_frags(ctx, a->params, s); if (rc) return rc; }
   GeoIterRays gr{active, a->sigmoid_coef, a->depth, a->var, a->rgb, a->valid_ray, loss_acc, ctx->d_small, a->n_rays};
-  ProfScope ps(ctx, PROF_GEO_ITER, s, (fwd_flops_per_sample(d.flags) + bwd_flops_per_sample(d.flags)) * d.P);
+  ProfScope ps(ctx, PROF_GEO_ITER, s, (fwd_flops_per_sample(d.flags) + bwd_flops_per_sample(d.flags)) * d.P, true);
   return launch_geo_iter(ctx, d, gr, g->g_geo_feats, g->feat_row_map, wl, s);
 }
 }  // namespace psl
@@ -370,7 +370,7 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_decode_split, g_geo_fused; int knn_trace_dump(); }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
@@ -379,7 +379,6 @@ extern "C" int psl_debug_option(const char* name, int value) {
   if (!strcmp(name, "track_fused")) { psl::g_track_fused = value; return PSL_OK; }
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_overlap")) { psl::g_knn_overlap = value; return PSL_OK; }
-  if (!strcmp(name, "decode_split")) { psl::g_decode_split = value; return PSL_OK; }
   if (!strcmp(name, "geo_fused")) { psl::g_geo_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_trace_dump")) return psl::knn_trace_dump();
   set_error("psl_debug_option: unknown option %s", name);

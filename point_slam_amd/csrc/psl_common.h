@@ -3,6 +3,7 @@
 #pragma once
 #include <cstdio>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/pointslam_hip.h"
 
@@ -208,29 +209,52 @@ bool debug_sync();   // PSL_DEBUG_SYNC=1: synchronise the device after every lau
 // PSL_DEBUG_ADDRS=1: log (name, [begin, end)) of device buffers to stderr, to match a GPU memory-fault address
 void dbg_range(const char* name, const void* p, size_t bytes);
 
-struct ProfScope {  // brackets a kernel class with HIP events on the launch stream when profiling is on
-  // prof_on = n > 1: one launch in n of a class is bracketed, classes staggered, so that a bracketed launch runs between
-  // unbracketed neighbours (every marker is a barrier packet: bracketing all five launches of an iteration costs 44 %
-  // of the frame time and charges the markers of the neighbours to the short kernels)
-  psl_ctx* c; int slot; hipStream_t s; int k; bool on;
-  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0) : c(c_), slot(slot_), s(s_), k(0), on(false) {
+// Timing of a kernel class (bench.py's roofline).  Two modes:
+//  * ext (single-kernel scopes, all the hot classes): the scope ARMS an event pair and the one PSL_KLAUNCH inside it hands
+//    the pair to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end -- the timestamps
+//    rocprofv3 reports, no barrier packet in the stream.  Marker pairs (hipEventRecord before / after) were measured to
+//    cost ~24 us of stream time per pair and to read 51 us for a 50 us kernel but 35 us for the 18 us Adam launch.
+//  * markers (scopes of several launches: repack, set-up): hipEventRecord on the launch stream before and after.
+// prof_on = n > 1: one launch in n of a class is timed, classes staggered.
+struct ProfArm { hipEvent_t start, stop; bool armed; };
+extern thread_local ProfArm g_prof_arm;
+struct ProfScope {
+  psl_ctx* c; int slot; hipStream_t s; int k; bool on, ext;
+  ProfScope(psl_ctx* c_, int slot_, hipStream_t s_, double work = 0.0, bool ext_ = false)
+      : c(c_), slot(slot_), s(s_), k(0), on(false), ext(ext_) {
     if (c && c->prof_on) {
       const int n = c->prof_seen[slot]++;
       c->prof_work[slot] += work;
       on = c->prof_on == 1 || (n + slot) % c->prof_on == 0;
       if (on) {
         k = c->prof_count[slot] % PROF_RING;
-        (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2], s);
+        hipEvent_t e0 = c->ev[((size_t)slot * PROF_RING + k) * 2], e1 = c->ev[((size_t)slot * PROF_RING + k) * 2 + 1];
+        if (ext) g_prof_arm = ProfArm{e0, e1, true};
+        else (void)hipEventRecord(e0, s);
       }
     }
   }
   ~ProfScope() {
-    if (on) {
+    if (!on) return;
+    if (ext) {
+      if (!g_prof_arm.armed) c->prof_count[slot]++;   // the launch took the pair
+      g_prof_arm.armed = false;                       // (no launch in the scope: the sample is dropped)
+    } else {
       (void)hipEventRecord(c->ev[((size_t)slot * PROF_RING + k) * 2 + 1], s);
       c->prof_count[slot]++;
     }
   }
 };
+// kernel launch that takes the armed event pair of the enclosing ext ProfScope, if there is one
+#define PSL_KLAUNCH(kern, grid, block, lds, stream, ...)                                                          \
+  do {                                                                                                            \
+    if (psl::g_prof_arm.armed) {                                                                                  \
+      psl::g_prof_arm.armed = false;                                                                              \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, psl::g_prof_arm.start, psl::g_prof_arm.stop, 0, __VA_ARGS__); \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                            \
+    }                                                                                                             \
+  } while (0)
 
 // ---- internal launchers (defined in the .hip files) -------------------------
 int grid_build(psl_ctx* ctx, hipStream_t s);
@@ -293,7 +317,6 @@ struct RenderWs {
   float* d_out3;     // [Ppad][4]
   float* dp;         // [Ppad][4]
   float* dp2;        // [Ppad][4]  geometry-branch share of dL/dp (register-chained backward: written by another workgroup)
-  float* dcc;        // [Ppad][32] dL/d(interpolated colour feature), masked: trunk backward -> F_theta backward (split kernels)
   int64_t total;
 };
 RenderWs carve_ws(float* base, int n_rays, int flags);

@@ -651,308 +651,6 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   }
 }
 
-// ------------------------------------------------------------------------------------------------ split backward
-// The mapper's colour-stage backward as two kernels (see the split forward in psl_decode_fwd2.hip for the why):
-//   kernel 1  k_trunk_bwd  : d(logits), the five trunk layers and the K-split dL/dc reduction of one 16-sample tile per
-//                            512-thread workgroup -> dcc[sample][32] (masked), plus the geometry role, EIGHT tiles per
-//                            workgroup (every wave works);
-//   kernel 2  k_ftheta_bwd : F_theta's backward, one WAVEFRONT per row tile of 16 (sample, neighbour) pairs, four per
-//                            workgroup: 75 % of the fused kernel's time, now in 2 500 equal units over all SIMDs.
-// Mapper instantiation only (no pose gradients); the tracker's launches (1 000 samples) keep the fused kernel.
-__global__ __launch_bounds__(WG, 4) void k_trunk_bwd(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles, int tiles) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  BlkTrace bt(a);
-  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  if ((int)blockIdx.x >= color_tiles) {       // geometry role: one tile per wave
-    const int tile = ((int)blockIdx.x - color_tiles) * 8 + wave;
-    if (tile < tiles) geo_tile_bwd<false>(a, o, WB, tile * TILE, reinterpret_cast<ScatterLds*>(smem)[wave]);
-    bt.done(a);
-    return;
-  }
-  using L = Bwd2Lds;
-  int* sHas = (int*)(smem + L::oHas);       // [16]
-  float* sDO = smem + L::oDO;               // [16][4] dL/d colour logits (pre-affine)
-  float* sAffP = smem + L::oAffP;           // [16][12] per-sample dL/d affine
-  float* sDccP = smem + L::oDccP;           // [8][2][64][4] per-wave partial tiles
-  float* sDZ = smem + L::oDZ;               // [2][8][64][4] dz tile, fragment order, double buffered
-  const bool parg = (a.flags & PSL_PARAM_GRAD) != 0;
-  const float* __restrict__ M = a.master;
-  const int p0 = (int)blockIdx.x * TILE;
-  if (t < TILE) {
-    const int p = min(p0 + t, a.P - 1);
-    sHas[t] = (p0 + t < a.P && a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
-  } else if (t >= 64 && t < 64 + TILE) {
-    // ---- d(logits): sigmoid and exposure-affine backward (decoder.py:432-448), one thread per sample
-    const int s = t - 64;
-    const int p = p0 + s;
-    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-    float ag[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) ag[j] = 0.f;
-    if (p < a.P) {
-      const float4 dr = reinterpret_cast<const float4*>(a.ws.d_raw)[p];
-      const float4 rw = reinterpret_cast<const float4*>(a.ws.raw)[p];
-      d0 = dr.x; d1 = dr.y; d2 = dr.z;
-      if (!(a.flags & PSL_NO_SIGMOID)) { d0 *= rw.x * (1.f - rw.x); d1 *= rw.y * (1.f - rw.y); d2 *= rw.z * (1.f - rw.z); }
-      if (a.flags & PSL_HAS_AFFINE) {
-        const float* A = a.affine;
-        const float o0 = a.ws.out3[(size_t)p * 4], o1 = a.ws.out3[(size_t)p * 4 + 1], o2 = a.ws.out3[(size_t)p * 4 + 2];
-        ag[0] = o0 * d0; ag[1] = o0 * d1; ag[2] = o0 * d2; ag[3] = o1 * d0; ag[4] = o1 * d1; ag[5] = o1 * d2;
-        ag[6] = o2 * d0; ag[7] = o2 * d1; ag[8] = o2 * d2; ag[9] = d0; ag[10] = d1; ag[11] = d2;
-        const float e0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
-        const float e1 = A[3] * d0 + A[4] * d1 + A[5] * d2;
-        const float e2 = A[6] * d0 + A[7] * d1 + A[8] * d2;
-        d0 = e0; d1 = e1; d2 = e2;
-      }
-      if (a.ws.d_out3) reinterpret_cast<float4*>(a.ws.d_out3)[p] = make_float4(d0, d1, d2, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 12; ++j) sAffP[s * 12 + j] = ag[j];
-    sDO[s * 4] = d0; sDO[s * 4 + 1] = d1; sDO[s * 4 + 2] = d2; sDO[s * 4 + 3] = 0.f;
-  }
-  lds_barrier();
-  {
-    const int nt = wave;
-    f32x4 G;
-    {
-      const float d0 = sDO[rl * 4], d1 = sDO[rl * 4 + 1], d2 = sDO[rl * 4 + 2];
-      const float* wo = M + MO(PI_C_OUT) + nt * 16 + 4 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) G[r] = d0 * wo[r] + d1 * wo[HC + r] + d2 * wo[2 * HC + r];
-    }
-    f32x4 dccp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    auto ld_y = [&](int i) {
-      return *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g);
-    };
-    f32x4 ynext = ld_y(4);
-    // fc_c fragments of the NEXT layer in flight during the current one: dL/dc is the first product of a layer and its
-    // weights were the one load whose L2 latency stood exposed at every layer start (phase stamps: "pre" 3-5 k cycles)
-    f32x4 wcn[2] = {ldfragb(WB, bfirst(BL_CF4) + 0 * 8 + nt, lane), ldfragb(WB, bfirst(BL_CF4) + 1 * 8 + nt, lane)};
-    auto layer = [&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      constexpr int BLs[5] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4};
-      constexpr int BLf[5] = {BL_CF0, BL_CF1, BL_CF2, BL_CF3, BL_CF4};
-      sched_fence_b();
-      f32x4 wq[8], wc[2];
-      const int fb = bfirst(BLs[i]);
-      if (i > 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, fb + nt * 8 + q, lane);
-      }
-      wc[0] = wcn[0]; wc[1] = wcn[1];
-      if (i > 0) {
-        wcn[0] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 0 * 8 + nt, lane);
-        wcn[1] = ldfragb(WB, bfirst(BLf[i > 0 ? i - 1 : 0]) + 1 * 8 + nt, lane);
-      }
-      const f32x4 y = ynext;
-      if (i > 0) ynext = ld_y(i > 0 ? i - 1 : 0);
-      sched_fence_b();
-      f32x4 dz;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dz[r] = G[r] * softplus100_grad_from_out(y[r]);
-      if (parg) {
-        const size_t o_ = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
-        *reinterpret_cast<f32x4*>(a.ws.c_dz + o_) = dz;
-        *reinterpret_cast<f32x4*>(a.ws.c_g + o_) = G;
-      }
-      float* buf = sDZ + (i & 1) * 8 * FRAG;
-      *reinterpret_cast<f32x4*>(buf + nt * FRAG + lane * 4) = dz;
-      mma4b(dccp[0], wc[0], G);
-      mma4b(dccp[1], wc[1], G);
-      lds_barrier();
-      if (i > 0) {
-        f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
-        f32x4 z0 = *reinterpret_cast<const f32x4*>(buf + lane * 4), z1 = *reinterpret_cast<const f32x4*>(buf + FRAG + lane * 4);
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          sched_fence_b();
-          const f32x4 c0 = z0, c1 = z1;
-          if (q < 6) {
-            z0 = *reinterpret_cast<const f32x4*>(buf + (q + 2) * FRAG + lane * 4);
-            z1 = *reinterpret_cast<const f32x4*>(buf + (q + 3) * FRAG + lane * 4);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { ga = mfma16(wq[q][r], c0[r], ga); gb = mfma16(wq[q + 1][r], c1[r], gb); }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) G[r] = ga[r] + gb[r];
-      }
-    };
-    layer(std::integral_constant<int, 4>{});
-    layer(std::integral_constant<int, 3>{});
-    layer(std::integral_constant<int, 2>{});
-    layer(std::integral_constant<int, 1>{});
-    layer(std::integral_constant<int, 0>{});
-    *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 0) * FRAG + lane * 4) = dccp[0];
-    *reinterpret_cast<f32x4*>(sDccP + (wave * 2 + 1) * FRAG + lane * 4) = dccp[1];
-  }
-  lds_barrier();
-  {   // 512 threads, 512 elements [it][lane][r]: sum over the waves, mask samples without neighbours -> dcc[sample][32]
-    const int e = t;
-    float v = 0.f;
-#pragma unroll
-    for (int w8 = 0; w8 < 8; ++w8) v += sDccP[w8 * 2 * FRAG + e];
-    const int it = e >> 8, ln = (e >> 2) & 63, r = e & 3;
-    const int s = ln & 15, gg = ln >> 4;
-    a.ws.dcc[(size_t)(p0 + s) * C + it * 16 + 4 * gg + r] = sHas[s] ? v : 0.f;
-  }
-  if ((a.flags & PSL_HAS_AFFINE) && t < 12 && o.g_affine) {
-    float v = 0.f;
-#pragma unroll
-    for (int s = 0; s < TILE; ++s) v += sAffP[s * 12 + t];
-    atomic_add_f32(&o.g_affine[t], v);
-  }
-  bt.done(a);
-}
-
-// F_theta backward of the 16 pairs row0 .. row0 + 15: d_nf = w dC (decoder.py:380-385), dH1 = W2^T d_nf, dz1 = dH1 *
-// softplus'(h1), dX1 = W1^T dz1; the feature part is scattered into the colour feature rows, the rel-pos part contracted
-// into dL/dB_rel (when the colour decoder trains).
-template <bool PARG>
-__global__ __launch_bounds__(256, 4) void k_ftheta_bwd(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int n_rt) {
-  __shared__ float sXe[4 * 16 * LD_X2];     // rel-pos part of dX1, per wave [16][22]
-  __shared__ float sRelW[4 * 16 * 3];       // rel positions of a wave's 16 pairs
-  __shared__ float sDB[32];                 // dL/dB_rel of this workgroup (30 used)
-  __shared__ __attribute__((aligned(16))) float sWn[kNbrFragsB * FRAG];   // linear2^T, linear1^T fragments
-  BlkTrace bt(a);
-  { NbrStageB<256> stage; stage.load(WB); stage.store(sWn); }
-  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
-  const float* __restrict__ M = a.master;
-  if (PARG && t < 32) sDB[t] = 0.f;
-  __syncthreads();
-  const int rt = (int)blockIdx.x * 4 + wave;
-  if (rt < n_rt) {
-    const int row = rt * 16 + rl;
-    const int ps = row >> 3;
-    const bool live = ps < a.P;
-    const int p = min(ps, a.P - 1);
-    const int i = a.ws.I[(size_t)p * K + (row & 7)];
-    const float wgt = a.ws.w[(size_t)row];
-    const bool has = live && a.ws.cnt[p] >= a.min_nn;
-    const size_t grow = (size_t)row;
-    f32x4 dc[2];     // dL/dc_col of this row's sample (already masked by the trunk kernel), channels 16 jt + 4 g + r
-    dc[0] = *reinterpret_cast<const f32x4*>(a.ws.dcc + (size_t)ps * C + 4 * g);
-    dc[1] = *reinterpret_cast<const f32x4*>(a.ws.dcc + (size_t)ps * C + 16 + 4 * g);
-    int dst = -1;
-    if (i >= 0 && has && wgt != 0.f) dst = o.row_map ? o.row_map[i] : i;
-    if (featg && dst >= 0 && o.t_col && g == 0) o.t_col[dst] = 1;
-    if (PARG && g == 0) {
-      const SampleGeom sg = sample_geom(a, p);
-      const float4 q = a.pos[max(i, 0)];
-      sRelW[(wave * 16 + rl) * 3 + 0] = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f;
-      sRelW[(wave * 16 + rl) * 3 + 1] = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
-      sRelW[(wave * 16 + rl) * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
-    }
-    f32x4 dnf[2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dnf[jt][r] = wgt * dc[jt][r];
-      if (PARG) *reinterpret_cast<f32x4*>(a.ws.n_dnf + grow * C + jt * 16 + 4 * g) = dnf[jt];
-    }
-    f32x4 dh[8], h1v[8];
-    constexpr int b2 = bfirst(BL_N2);
-    constexpr int b1 = bfirst(BL_N1);
-    f32x4 wn[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + j * 2 + 0, lane);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      h1v[it] = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow * HC + it * 16 + 4 * g);
-    }
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {       // st = 2 * half + q
-      sched_fence_b();
-      const int half = st >> 1, q = st & 1;
-      f32x4 wc4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wc4[j] = wn[j];
-      if (st < 3) {
-        const int h2 = (st + 1) >> 1, q2 = (st + 1) & 1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + (4 * h2 + j) * 2 + q2, lane);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b1 + j * 8 + 0, lane);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dh[4 * half + j] = mfma16(wc4[j][r], dnf[q][r], dh[4 * half + j]);
-    }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dh[it][r] = live ? dh[it][r] * softplus100_grad_from_out(h1v[it][r]) : 0.f;
-      if (PARG) *reinterpret_cast<f32x4*>(a.ws.n_dz1 + grow * HC + it * 16 + 4 * g) = dh[it];
-    }
-    f32x4 dx[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) dx[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      sched_fence_b();
-      f32x4 wf4[4];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) wf4[it] = wn[it];
-      if (q < 7) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) wn[it] = ldsfragb(sWn, b1 + it * 8 + q + 1, lane);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dx[0] = mfma16(wf4[0][r], dh[q][r], dx[0]);
-        dx[1] = mfma16(wf4[1][r], dh[q][r], dx[1]);
-        if (PARG) { dx[2] = mfma16(wf4[2][r], dh[q][r], dx[2]); dx[3] = mfma16(wf4[3][r], dh[q][r], dx[3]); }
-      }
-    }
-    if (featg && dst >= 0) {
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], dx[jt][r]);
-    }
-    if (PARG) {
-      // rel-pos embedding part: y_f = 2pi rel . B[:,f]; e = [sin y, cos y] -> dL/dy in place, then the contraction
-      // dB_rel[ax][f] = sum_rows dy[row][f] rel[row][ax] (30 lanes)
-      float* xw = sXe + wave * 16 * LD_X2;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xw[rl * LD_X2 + 4 * g + r] = dx[2][r];
-        if (g == 0) xw[rl * LD_X2 + 16 + r] = dx[3][r];
-      }
-      wave_lds_sync();
-      for (int e = lane; e < 16 * ERF; e += 64) {
-        const int r2 = e / ERF, f = e - r2 * ERF;
-        const int row2 = rt * 16 + r2, s2 = row2 >> 3;
-        const int p2 = min(s2, a.P - 1);
-        const bool lv = s2 < a.P && a.ws.I[(size_t)p2 * K + (row2 & 7)] >= 0;
-        const float* xr = a.ws.n_x + (size_t)row2 * NX;     // the forward saved [sin | cos] in the first 20 columns
-        const float sn = xr[f], cs = xr[ERF + f];
-        const float dy2 = TWO_PI * (xw[r2 * LD_X2 + f] * cs - xw[r2 * LD_X2 + ERF + f] * sn);
-        xw[r2 * LD_X2 + f] = lv ? dy2 : 0.f;
-      }
-      wave_lds_sync();
-      if (lane < 3 * ERF) {
-        const int ax = lane / ERF, f = lane - ax * ERF;
-        float v = 0.f;
-#pragma unroll
-        for (int r2 = 0; r2 < 16; ++r2) v += xw[r2 * LD_X2 + f] * sRelW[(wave * 16 + r2) * 3 + ax];
-        atomic_add_f32(&sDB[ax * ERF + f], v);
-      }
-    }
-  }
-  if (PARG) {
-    __syncthreads();
-    if (t < 3 * ERF && o.g_brel) atomic_add_f32(&o.g_brel[t], sDB[t]);
-  }
-  bt.done(a);
-}
-
 // grid as in the forward: [0, color_tiles) colour role, then one geometry-role WAVEFRONT per tile in a workgroup of its own
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
@@ -979,7 +677,7 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   const bool ptsg = a.flags & PSL_PTS_GRAD;
   const size_t lds = sizeof(float) * ((a.flags & 0x10000) ? Bwd2Lds::total_nbr : Bwd2Lds::total);
   const size_t lds_max = sizeof(float) * Bwd2Lds::total_nbr;
-  static bool attr_set = false, attr_set2 = false;
+  static bool attr_set = false;
   if (!attr_set) {
     PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     PSL_HIP(hipFuncSetAttribute((const void*)k_decode_bwd2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -989,31 +687,13 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   static int dbg_on = -1;
   if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
   if (dbg_on && a.dbg) PSL_HIP(hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), s));
-  extern int g_decode_split;
-  if (color && !ptsg && (a.flags & 0x10000) && g_decode_split != 0 && (a.P >= 2048 || g_decode_split == 2)) {
-    if (!attr_set2) {
-      PSL_HIP(hipFuncSetAttribute((const void*)k_trunk_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-      attr_set2 = true;
-    }
-    const int g_blocks = (tiles + 7) / 8, n_rt = a.ws.Ppad / 2, f_blocks = (n_rt + 3) / 4;
-    { int rc = blk_trace_begin(a, tiles + g_blocks, s); if (rc) return rc; }
-    hipLaunchKernelGGL(k_trunk_bwd, dim3(tiles + g_blocks), dim3(WG), sizeof(float) * Bwd2Lds::total, s, a, o, WB, tiles, tiles);
-    PSL_LAUNCH_CHECK();
-    { int rc = blk_trace_end(a, "trunk_bwd", tiles + g_blocks, tiles, WG); if (rc) return rc; }
-    { int rc = blk_trace_begin(a, f_blocks, s); if (rc) return rc; }
-    if (a.flags & PSL_PARAM_GRAD) hipLaunchKernelGGL(k_ftheta_bwd<true>, dim3(f_blocks), dim3(256), 0, s, a, o, WB, n_rt);
-    else hipLaunchKernelGGL(k_ftheta_bwd<false>, dim3(f_blocks), dim3(256), 0, s, a, o, WB, n_rt);
-    PSL_LAUNCH_CHECK();
-    { int rc = blk_trace_end(a, "ftheta_bwd", f_blocks, f_blocks, 256); if (rc) return rc; }
-    return PSL_OK;
-  }
   { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color) {
-    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
-    else hipLaunchKernelGGL((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
+    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
   } else {
-    if (ptsg) hipLaunchKernelGGL((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
-    else hipLaunchKernelGGL((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
+    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
   }
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
@@ -1050,7 +730,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
   DecodeArgs a2 = a;
   if (dbg_on) { if (!dbg) PSL_HIP(hipMalloc(&dbg, 64 * sizeof(unsigned long long))); a2.dbg = dbg; }
   {
-    ProfScope ps(ctx, prof_decode_slot(a.flags, true), s, bwd_flops_per_sample(a.flags) * a.P);
+    ProfScope ps(ctx, prof_decode_slot(a.flags, true), s, bwd_flops_per_sample(a.flags) * a.P, true);
     int rc = launch_decode_bwd2(ctx, a2, g, small, s);
     if (rc) return rc;
   }
@@ -1058,7 +738,7 @@ int launch_decode_bwd(psl_ctx* ctx, const DecodeArgs& a, const psl_render_grads&
     PSL_HIP(hipMemcpyAsync(g.g_exposure_affine, small + 32, sizeof(float) * 12, hipMemcpyDeviceToDevice, s));
   if (a.flags & PSL_PARAM_GRAD) {
     if (color) {
-      ProfScope ps(ctx, PROF_DW, s, dw_flops_per_sample(a.flags) * a.P);
+      ProfScope ps(ctx, PROF_DW, s, dw_flops_per_sample(a.flags) * a.P, ctx->dw_defer_reduce != 0);
       int rc = launch_dw(ctx, a, g.g_params, small, s);
       if (rc) return rc;
     } else {

@@ -488,257 +488,6 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   }
 }
 
-// ------------------------------------------------------------------------------------------------ split forward
-// Colour-stage launches of >= kSplitMinSamples samples run as TWO kernels instead of the fused tile kernel above.
-// Per-workgroup traces of the fused kernel at 5 000 samples (profiles/r03_block_trace_fused.txt) show why: 313 tiles on
-// 256 CUs leave 57 CUs with two co-resident tiles (42-50 us against 32 us for a tile that has its CU to itself), and the
-// one-wave geometry workgroups -- dispatched as 512-thread workgroups whose other seven waves exit -- cannot start on a
-// CU that has fewer than eight free wave slots, so a third of them wait ~31 us for the colour tiles to finish.  F_theta
-// (55 % of the MFMA work, the per-(sample, neighbour) MLP) has no reason to be tied to a 16-sample tile:
-//   kernel 1  k_ftheta_fwd : one WAVEFRONT per row tile of 16 (sample, neighbour) pairs, four per workgroup -- 2 500 equal
-//                            units at 5 000 samples, spread evenly over the 1 024 SIMDs -- plus the geometry role, four
-//                            tiles per workgroup (every wave of a workgroup works).  No LDS, no barrier.
-//   kernel 2  k_trunk_fwd  : the colour trunk, one 512-thread workgroup per 16-sample tile as before, which now starts
-//                            from the interpolated colour features in `cc` (640 KB, L2-resident) and is half as long,
-//                            so that two tiles sharing a CU cost half as much.
-constexpr int kSplitMinSamples = 2048;
-
-// F_theta of the 16 pairs row0 .. row0 + 15 of the launch (pair row = 8 * sample + neighbour): neighbour weights
-// (decoder.py:362-368), rel-pos embedding + feature gather, linear1 / softplus / linear2 (decoder.py:371-379), weighted sum
-// over the 8 neighbours and the fallback for samples without neighbours (decoder.py:380-388) -> cc[sample][32].
-__device__ __forceinline__ void ftheta_fwd_rows(const DecodeArgs& a, const float* __restrict__ WF, const float* sWn, int row0) {
-  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
-  const float* __restrict__ M = a.master;
-  constexpr int f1 = ffirst(FL_N1);
-  f32x4 afn[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + j * 4 + 0, lane);
-  const int row = row0 + rl;                  // < 8 * Ppad: every per-pair buffer holds that many rows
-  const int ps = row >> 3;                    // sample slot (may lie in the padding behind the batch)
-  const int p = min(ps, a.P - 1);
-  const SampleGeom sg = sample_geom(a, p);
-  const int i = a.ws.I[(size_t)p * K + (row & 7)];
-  const float4 q = a.pos[max(i, 0)];
-  const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-  const float wraw = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
-  const float wgt = wraw / fmaxf(group8_sum(wraw), 1e-12f);      // same summation tree as the fused kernel's butterfly
-  if (g == 0) a.ws.w[(size_t)row] = wgt;
-  const float rx = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f, ry = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f,
-              rz = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
-  const bool has = a.ws.cnt[p] >= a.min_nn;
-  const size_t grow = (size_t)row;
-  f32x4 xf[2];
-  {
-    const float* frow = a.col_feats + (size_t)max(i, 0) * C + 4 * g;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(frow), v1 = *reinterpret_cast<const f32x4*>(frow + 16);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? v0[r] : 0.f; xf[1][r] = (i >= 0) ? v1[r] : 0.f; }
-  }
-  // F_theta input [sin(10) cos(10) | feat(32)] (decoder.py:371-378); this lane holds sin or cos of f = 2 s + (g >> 1)
-  const float* __restrict__ Brel = M + MO(PI_C_BREL);
-  f32x4 xe; float xe4 = 0.f;
-#pragma unroll
-  for (int ks = 0; ks < 5; ++ks) {
-    const int f = 2 * ks + (g >> 1);
-    float sn, cs;
-    fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
-    const float v = (g & 1) ? cs : sn;
-    if (ks < 4) xe[ks] = v; else xe4 = v;
-    if (a.ws.n_x) a.ws.n_x[grow * NX + (g & 1) * ERF + f] = v;
-  }
-  if (a.ws.n_x) {
-    *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 4 * g) = xf[0];
-    *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 16 + 4 * g) = xf[1];
-  }
-  f32x4 hid[8];
-#pragma unroll
-  for (int nt = 0; nt < 8; ++nt) hid[nt] = ldbias(WF, fbias(FL_N1), nt, g);
-  auto activate = [&](int nt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100_nb(hid[nt][r]);
-    if (a.ws.n_h1) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
-  };
-  constexpr int f2 = ffirst(FL_N2);
-  f32x4 a0n, a1n;
-#pragma unroll
-  for (int st = 0; st < 8; ++st) {
-    sched_fence();
-    const int half = st >> 2, qq = st & 3;
-    f32x4 af[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) af[j] = afn[j];
-    if (st < 7) {
-      const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + (4 * h2 + j) * 4 + q2, lane);
-    } else {
-      a0n = ldsfrag(sWn, f2 + 0, lane); a1n = ldsfrag(sWn, f2 + 8 + 0, lane);
-    }
-    if (qq < 3) {
-      const f32x4 b = (qq == 0) ? xf[0] : (qq == 1 ? xf[1] : xe);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][r], b[r], hid[4 * half + j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][0], xe4, hid[4 * half + j]);
-    }
-    if (half == 1) activate(qq);
-  }
-  f32x4 nf[2];
-  nf[0] = ldbias(WF, fbias(FL_N2), 0, g); nf[1] = ldbias(WF, fbias(FL_N2), 1, g);
-#pragma unroll
-  for (int qq = 0; qq < 8; ++qq) {
-    sched_fence();
-    const f32x4 a0 = a0n, a1 = a1n;
-    if (qq < 7) { a0n = ldsfrag(sWn, f2 + qq + 1, lane); a1n = ldsfrag(sWn, f2 + 8 + qq + 1, lane); }
-    if (qq < 4) activate(4 + qq);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[qq][r], nf[0]); nf[1] = mfma16(a1[r], hid[qq][r], nf[1]); }
-  }
-  sched_fence();
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    if (a.ws.n_out) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
-    f32x4 c;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = group8_sum(__fmul_rn(wgt, nf[nt][r]));   // sum_k w_k F_theta(.)  (decoder.py:380-385)
-    if ((rl & 7) == 0) {
-      const f32x4 fb = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
-#pragma unroll
-      for (int r = 0; r < 4; ++r) c[r] = has ? c[r] : fb[r];
-      *reinterpret_cast<f32x4*>(a.ws.cc + (size_t)ps * C + nt * 16 + 4 * g) = c;
-    }
-  }
-}
-
-// grid: [0, f_blocks) F_theta row tiles, four per workgroup; then the geometry role, four tiles per workgroup
-__global__ __launch_bounds__(256, 4) void k_ftheta_fwd(DecodeArgs a, const float* __restrict__ WF, int f_blocks, int n_rt, int tiles) {
-  __shared__ __attribute__((aligned(16))) float sWn[kNbrFrags * FRAG];
-  BlkTrace bt(a);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if ((int)blockIdx.x < f_blocks) {
-    { NbrStage<256> stage; stage.load(WF); stage.store(sWn); }
-    __syncthreads();
-    const int rt = (int)blockIdx.x * 4 + wave;
-    if (rt < n_rt) ftheta_fwd_rows(a, WF, sWn, rt * 16);
-  } else {
-    const int tile = ((int)blockIdx.x - f_blocks) * 4 + wave;
-    if (tile < tiles) geo_tile<2>(a, WF, tile * TILE, false, false);
-  }
-  bt.done(a);
-}
-
-// the colour trunk of one 16-sample tile from the interpolated colour features in a.ws.cc (decoder.py:390-449)
-__global__ __launch_bounds__(WG, 4) void k_trunk_fwd(DecodeArgs a, const float* __restrict__ WF) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  BlkTrace bt(a);
-  float* sH = smem;                         // [2][8][64][4] hidden tile, fragment order, double buffered
-  const int p0 = (int)blockIdx.x * TILE;
-  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const float* __restrict__ M = a.master;
-  const int nt = wave;
-  TrunkW tw;
-  load_trunk<0>(tw, WF, nt, lane, g);
-  const f32x4 ccb0 = *reinterpret_cast<const f32x4*>(a.ws.cc + (size_t)(p0 + rl) * C + 4 * g);
-  const f32x4 ccb1 = *reinterpret_cast<const f32x4*>(a.ws.cc + (size_t)(p0 + rl) * C + 16 + 4 * g);
-  const SampleGeom sg = sample_geom(a, min(p0 + rl, a.P - 1));
-  float sn[5], cs[5];
-#pragma unroll
-  for (int ks = 0; ks < 5; ++ks) {
-    const int f = 4 * ks + g;
-    fast_sincosf(fourier_phase(sg.x, sg.y, sg.z, a.Bcol, ECF, f), sn[ks], cs[ks]);
-    if (wave == 0 && a.ws.c_emb) {
-      a.ws.c_emb[(size_t)(p0 + rl) * EC + f] = sn[ks];
-      a.ws.c_emb[(size_t)(p0 + rl) * EC + ECF + f] = cs[ks];
-    }
-  }
-  const f32x4 esn = {sn[0], sn[1], sn[2], sn[3]}, ecs = {cs[0], cs[1], cs[2], cs[3]};
-  auto layer = [&](auto I_) {
-    constexpr int i = decltype(I_)::value;
-    const float* bufp = sH + ((i + 1) & 1) * 8 * FRAG;
-    f32x4 acc_a = tw.bias, acc_b = {0.f, 0.f, 0.f, 0.f}, u = tw.cbias;
-    f32x4 hq0, hq1;
-    if (i != 0) { hq0 = *reinterpret_cast<const f32x4*>(bufp + lane * 4); hq1 = *reinterpret_cast<const f32x4*>(bufp + FRAG + lane * 4); }
-    sched_fence();
-    mma4(u, tw.c[0], ccb0);
-    if (i == 0 || i == 3) {
-      mma4(acc_a, tw.w[0], esn);
-      mma4(acc_b, tw.w[2], ecs);
-      acc_a = mfma16(tw.w[1][0], sn[4], acc_a);
-      acc_b = mfma16(tw.w[3][0], cs[4], acc_b);
-    }
-    mma4(u, tw.c[1], ccb1);
-    if (i != 0) {
-      if (i == 3) {
-        sched_fence();
-        const int base = ffirst(FL_C3) + nt * 12;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tw.w[q] = ldfrag(WF, base + 8 + q, lane);
-      }
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        sched_fence();
-        const f32x4 h0 = hq0, h1 = hq1;
-        if (q < 6) {
-          hq0 = *reinterpret_cast<const f32x4*>(bufp + (q + 2) * FRAG + lane * 4);
-          hq1 = *reinterpret_cast<const f32x4*>(bufp + (q + 3) * FRAG + lane * 4);
-        }
-        const int s0 = (i == 3) ? (q < 4 ? 4 + q : q - 4) : q;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc_a = mfma16(tw.w[s0][r], h0[r], acc_a); acc_b = mfma16(tw.w[s0 + 1][r], h1[r], acc_b); }
-      }
-    }
-    sched_fence();
-    if constexpr (i < 4) load_trunk<(i < 4 ? i + 1 : 4)>(tw, WF, nt, lane, g);
-    sched_fence();
-    f32x4 y, hh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { y[r] = softplus100_nb(acc_a[r] + acc_b[r]); hh[r] = y[r] + u[r]; }
-    if (a.ws.c_y) {
-      const size_t o = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
-      *reinterpret_cast<f32x4*>(a.ws.c_y + o) = y;
-      if (a.ws.c_hin) *reinterpret_cast<f32x4*>(a.ws.c_hin + o) = hh;
-    }
-    *reinterpret_cast<f32x4*>(sH + (i & 1) * 8 * FRAG + nt * FRAG + lane * 4) = hh;
-    lds_barrier();
-  };
-  layer(std::integral_constant<int, 0>{});
-  layer(std::integral_constant<int, 1>{});
-  layer(std::integral_constant<int, 2>{});
-  layer(std::integral_constant<int, 3>{});
-  layer(std::integral_constant<int, 4>{});
-  if (wave == 0) {
-    const float* buf = sH;     // layer 4 wrote buffer 0
-    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
-    constexpr int fo = ffirst(FL_COUT);
-#pragma unroll
-    for (int q = 0; q < 8; q += 2) {
-      mma4(oa, ldfrag(WF, fo + q, lane), *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4));
-      mma4(ob, ldfrag(WF, fo + q + 1, lane), *reinterpret_cast<const f32x4*>(buf + (q + 1) * FRAG + lane * 4));
-    }
-    if (g == 0 && p0 + rl < a.P) {
-      const int p = p0 + rl;
-      float r0 = (oa[0] + ob[0]) + M[MO(PI_C_OUT + 1) + 0];
-      float r1 = (oa[1] + ob[1]) + M[MO(PI_C_OUT + 1) + 1];
-      float r2 = (oa[2] + ob[2]) + M[MO(PI_C_OUT + 1) + 2];
-      a.ws.out3[(size_t)p * 4 + 0] = r0; a.ws.out3[(size_t)p * 4 + 1] = r1; a.ws.out3[(size_t)p * 4 + 2] = r2;
-      if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
-        const float* A = a.affine;
-        const float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
-        const float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
-        const float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
-        r0 = q0; r1 = q1; r2 = q2;
-      }
-      if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
-      a.ws.raw[(size_t)p * 4 + 0] = r0; a.ws.raw[(size_t)p * 4 + 1] = r1; a.ws.raw[(size_t)p * 4 + 2] = r2;
-    }
-  }
-  bt.done(a);
-}
-
 // grid: [0, color_tiles) colour role (one tile per workgroup), then the geometry role: ONE WAVEFRONT per tile, each in a
 // workgroup of its own so that the tiles spread over all CUs (eight tiles in one workgroup would sit on one CU and share
 // its L1 port and its four SIMDs).  In the colour-stage launch the workgroup size is the colour role's 512: the seven
@@ -844,25 +593,11 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
     attr_set = true;
   }
   const bool color = a.flags & PSL_STAGE_COLOR;
-  extern int g_decode_split;
-  if (color && (a.flags & 0x10000) && g_decode_split != 0 && (a.P >= kSplitMinSamples || g_decode_split == 2)) {
-    // split forward: F_theta row tiles + geometry tiles, then the trunk tiles
-    const int n_rt = a.ws.Ppad / 2, f_blocks = (n_rt + 3) / 4, g_blocks = (tiles + 3) / 4;
-    { int rc = blk_trace_begin(a, f_blocks + g_blocks, s); if (rc) return rc; }
-    hipLaunchKernelGGL(k_ftheta_fwd, dim3(f_blocks + g_blocks), dim3(256), 0, s, a, (const float*)ctx->wf, f_blocks, n_rt, tiles);
-    PSL_LAUNCH_CHECK();
-    { int rc = blk_trace_end(a, "ftheta_fwd", f_blocks + g_blocks, f_blocks, 256); if (rc) return rc; }
-    { int rc = blk_trace_begin(a, tiles, s); if (rc) return rc; }
-    hipLaunchKernelGGL(k_trunk_fwd, dim3(tiles), dim3(WG), sizeof(float) * 2 * 8 * FRAG, s, a, (const float*)ctx->wf);
-    PSL_LAUNCH_CHECK();
-    { int rc = blk_trace_end(a, "trunk_fwd", tiles, tiles, WG); if (rc) return rc; }
-    return PSL_OK;
-  }
   { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color)
-    hipLaunchKernelGGL(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
+    PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
   else
-    hipLaunchKernelGGL(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
+    PSL_KLAUNCH(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, "fwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on) {

@@ -303,7 +303,7 @@ int launch_geo_iter(psl_ctx* ctx, const DecodeArgs& a_in, const GeoIterRays& gr,
     a.dbg = dbg;
   }
   { int rc = blk_trace_begin(a, n_tiles + n_wl, s); if (rc) return rc; }
-  hipLaunchKernelGGL(k_geo_iter, dim3(n_tiles + n_wl), dim3(64), 0, s, a, (const float*)ctx->wf, (const float*)ctx->wb, gr, g_geo,
+  PSL_KLAUNCH(k_geo_iter, dim3(n_tiles + n_wl), dim3(64), 0, s, a, (const float*)ctx->wf, (const float*)ctx->wb, gr, g_geo,
                      row_map, ctx->touched_geo, w, n_tiles, n_wl);
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, "geo_iter", n_tiles + n_wl, n_tiles, 64); if (rc) return rc; }

@@ -274,7 +274,7 @@ int launch_dw(psl_ctx* ctx, const DecodeArgs& a, float* g_params, const float* g
   }
   const int base = finish();
   d.n_jobs = nj; d.n_items = base; d.slabs = ctx->dw_slabs;
-  hipLaunchKernelGGL(k_dw, dim3((unsigned)((base + 3) / 4)), dim3(256), 0, s, d);
+  PSL_KLAUNCH(k_dw, dim3((unsigned)((base + 3) / 4)), dim3(256), 0, s, d);
   PSL_LAUNCH_CHECK();
   ctx->dw_ra = ra;
   if (ctx->dw_defer_reduce) return PSL_OK;   // psl_map_iters: the Adam launch sums the chunk partials itself

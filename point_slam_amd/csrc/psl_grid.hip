@@ -1095,7 +1095,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
-    hipLaunchKernelGGL(k_knn_rays_flat, dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+    PSL_KLAUNCH(k_knn_rays_flat, dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
                        (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
@@ -1103,7 +1103,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     return PSL_OK;
   }
   if (ver == 3) {
-    hipLaunchKernelGGL(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+    PSL_KLAUNCH(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
     PSL_LAUNCH_CHECK();
@@ -1112,7 +1112,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (ver >= 2) {
     int blocks = (n_rays + 3) / 4;
     if (max_blocks > 0) blocks = std::min(blocks, max_blocks);      // throttled: every wavefront walks several rays
-    hipLaunchKernelGGL(k_knn_rays2, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+    PSL_KLAUNCH(k_knn_rays2, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                        rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                        ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
     PSL_LAUNCH_CHECK();
@@ -1122,7 +1122,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   static int trace = -1;
   if (trace < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace = (e && e[0] == '1') ? 1 : 0; }
   // (the candidate counter costs one same-address atomic per query: only while the bench's class timers are on)
-  hipLaunchKernelGGL(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+  PSL_KLAUNCH(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
                      ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
                      (ctx->prof_on || trace) ? ctx->knn_cand : nullptr, ctx->coarse, trace);

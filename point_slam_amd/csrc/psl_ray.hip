@@ -292,7 +292,7 @@ int launch_map_ray_fused(const float4* raw, const int* cnt, const float* gt_dept
   if (wl) w = *wl;
   const int nb_ray = (n_rays + 255) / 256;
   const int nb_wl = (w.I_a && w.n4 > 0) ? ((w.I_b ? 2 : 1) * w.n4 + 255) / 256 : 0;
-  hipLaunchKernelGGL(k_map_ray_fused, dim3(nb_ray + nb_wl), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
+  PSL_KLAUNCH(k_map_ray_fused, dim3(nb_ray + nb_wl), dim3(256), 0, s, raw, cnt, gt_depth, gt_color, active,
                      near_s, far_s, min_nn, n_rays, coef, w_color, color_stage, depth, var, rgb, valid, d_raw, loss_acc,
                      zero64, frame_affine, pix_per_frame, g_frame_affine, w, nb_ray);
   PSL_LAUNCH_CHECK();
@@ -303,7 +303,7 @@ int launch_composite_fwd(const float4* raw, const float* z, const float* gt_dept
                          const int* cnt, int min_nn, int n_rays, float coef, float* depth, float* var, float* rgb,
                          unsigned char* valid, float* cw, float* ray_aux, hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
+  PSL_KLAUNCH(k_composite_fwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
                      cnt, min_nn, n_rays, coef, depth, var, rgb, valid, cw, ray_aux);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
@@ -313,7 +313,7 @@ int launch_composite_bwd(const float4* raw, const float* z, const float* gt_dept
                          const float* g_depth, const float* g_var, const float* g_rgb, float4* d_raw, float* zero64,
                          hipStream_t s) {
   if (n_rays <= 0) return PSL_OK;
-  hipLaunchKernelGGL(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
+  PSL_KLAUNCH(k_composite_bwd, dim3((n_rays + 255) / 256), dim3(256), 0, s, raw, z, gt_depth, near_s, far_s,
                      n_rays, coef, g_depth, g_var, g_rgb, d_raw, zero64);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
@@ -481,7 +481,7 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
     const int nb_rows = adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
     if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
-    hipLaunchKernelGGL(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
+    PSL_KLAUNCH(k_map_adam_lazy, dim3(nb_rows * n_groups + nb_par), dim3(256), 0, s, geo, col, par, nb_rows, n_groups,
                        0.9f, 0.999f, 1e-8f, lazy);
     PSL_LAUNCH_CHECK();
     return PSL_OK;
@@ -489,7 +489,7 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   const int nb_geo = (int)(((long long)geo.n_rows * (C / 4) + 255) / 256);
   const int nb_col = (int)(((long long)col.n_rows * (C / 4) + 255) / 256);
   if (nb_geo + nb_col + nb_par == 0) return PSL_OK;
-  hipLaunchKernelGGL(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
+  PSL_KLAUNCH(k_map_adam, dim3(nb_geo + nb_col + nb_par), dim3(256), 0, s, geo, col, par, nb_geo, nb_col, 0.9f,
                      0.999f, 1e-8f);
   PSL_LAUNCH_CHECK();
   return PSL_OK;

@@ -762,9 +762,6 @@ int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
-// colour-stage decode as separate F_theta / trunk kernels: 0 = fused tile kernels (default: measured faster),
-// 1 = split from 2 048 samples per launch on, 2 = split always
-int g_decode_split = env_flag("PSL_DECODE_SPLIT", 0);
 // geometry-stage mapper iterations as ONE launch (psl_decode_geo.hip) instead of decode fwd / ray kernel / decode bwd
 int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
 }  // namespace psl
@@ -875,7 +872,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     if (rc) return rc;
     float* lo = t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch;
     if (fused) {
-      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
+      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
       hipLaunchKernelGGL(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
                          ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, t->sigmoid_coef, t->w_color, t->handle_dynamic,
                          t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
@@ -1082,7 +1079,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
                          nb);
       hipLaunchKernelGGL(k_depth_inlier, dim3(nb), dim3(1024), 0, st, pbs[set].gd, pbs[set].active, n);
       PSL_LAUNCH_CHECK(); }
-    ProfScope ps(ctx, st == s ? PROF_KNN_PREFETCH : PROF_KNN_SIDE, st, 108.0 * nb * n * S);
+    ProfScope ps(ctx, st == s ? PROF_KNN_PREFETCH : PROF_KNN_SIDE, st, 108.0 * nb * n * S, true);
     // on the side stream the lookup is THROTTLED (g_knn_side_blocks workgroups, ~2 per CU): left alone its 10^4
     // workgroups fill every CU and the decode kernels of the main stream wait for slots (one of them measured at
     // 845 us instead of 52); it has a whole block of iterations (~8 ms) to finish
@@ -1135,7 +1132,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     rc = render_fwd_impl(ctx, &ra, s, repack);
     if (rc) return rc;
     { // compositing + mapper loss + compositing backward in one launch (+ the work list of this iteration's Adam)
-      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n);
+      ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
       const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
       rc = launch_map_ray_fused((const float4*)rw.raw, ctx->pre_cnt, b.gd, b.gc, b.active, ctx->cfg.near_end_surface,
                                 ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, n, m->sigmoid_coef, m->w_color,
@@ -1154,7 +1151,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // SURVEY.md §8d) over every selected row
     // (lazy path: the rows actually stepped are counted on the device and added by psl_profile_read)
     ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
-                                             ((color_stage && m->train_decoder) ? (double)ncol : 0.0)));
+                                             ((color_stage && m->train_decoder) ? (double)ncol : 0.0)), true);
     {
       AdamRowsSeg sg{}, sc{};
       AdamParSeg sp{};

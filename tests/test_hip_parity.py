@@ -196,28 +196,9 @@ def _run_case(case, dev, grads):
     return fx, cfg, dec, (ro, rd, geo, col, ef), out
 
 
-# the colour-stage decode also exists as separate F_theta / trunk kernels (psl_decode_fwd2.hip "split forward"; off by
-# default, PSL_DECODE_SPLIT=1 enables it from 2 048 samples per launch): the rel-pos cases are run a second time with the
-# split forced ("decode_split" = 2)
-SPLIT_CASES = [(c, 0) for c in RENDER_CASES] + [(c, 2) for c in RENDER_CASES if "replica_color" in c or "holes" in c]
-
-
-class _forced_split:
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        from point_slam_amd import _lib
-        _lib.check(_lib.lib().psl_debug_option(b"decode_split", self.mode))
-
-    def __exit__(self, *a):
-        from point_slam_amd import _lib
-        _lib.check(_lib.lib().psl_debug_option(b"decode_split", 0))
-
-
-@pytest.mark.parametrize("case,split", SPLIT_CASES)
-def test_render_forward_matches_reference(dev, case, split):
-    with torch.no_grad(), _forced_split(split):
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_render_forward_matches_reference(dev, case):
+    with torch.no_grad():
         fx, cfg, dec, _, (d, v, c, valid) = _run_case(case, dev, grads=False)
     d, v, c, valid = d.cpu(), v.cpu(), c.cpu(), valid.cpu()
     # loss-level quantities (what BASELINE.json bounds at 1e-4): mapper-style L1 sums against the sensor values
@@ -225,7 +206,7 @@ def test_render_forward_matches_reference(dev, case, split):
     m = fx["ref_valid"]
     Ld, Ld_ref = (gd - d)[m].abs().sum(), (gd - fx["ref_depth"])[m].abs().sum()
     Lc, Lc_ref = (gc - c)[m].abs().sum(), (gc - fx["ref_rgb"])[m].abs().sum()
-    rep = dict(test="render_fwd", case=case, split=split, depth_rel=relerr(d, fx["ref_depth"]),
+    rep = dict(test="render_fwd", case=case, depth_rel=relerr(d, fx["ref_depth"]),
                rgb_abs=float((c - fx["ref_rgb"]).abs().max()), var_rel=relerr(v, fx["ref_var"]),
                valid_eq=bool(torch.equal(valid, fx["ref_valid"])),
                depth_loss_rel=float((Ld - Ld_ref).abs() / Ld_ref.clamp_min(1e-12)),
@@ -240,14 +221,13 @@ def test_render_forward_matches_reference(dev, case, split):
 
 
 # ------------------------------------------------------------------------------ render backward
-@pytest.mark.parametrize("case,split", SPLIT_CASES)
-def test_render_backward_matches_reference(dev, case, split):
-    with _forced_split(split):
-        fx, cfg, dec, (ro, rd, geo, col, ef), (d, v, c, valid) = _run_case(case, dev, grads=True)
-        obj = (d * fx["w_d"].to(dev)).sum() + (c * fx["w_c"].to(dev)).sum() + (v * fx["w_v"].to(dev)).sum()
-        obj.backward()
-        torch.cuda.synchronize()
-    rep = dict(test="render_bwd", case=case, split=split)
+@pytest.mark.parametrize("case", RENDER_CASES)
+def test_render_backward_matches_reference(dev, case):
+    fx, cfg, dec, (ro, rd, geo, col, ef), (d, v, c, valid) = _run_case(case, dev, grads=True)
+    obj = (d * fx["w_d"].to(dev)).sum() + (c * fx["w_c"].to(dev)).sum() + (v * fx["w_v"].to(dev)).sum()
+    obj.backward()
+    torch.cuda.synchronize()
+    rep = dict(test="render_bwd", case=case)
     if fx["is_tracker"]:
         rep["g_rays_o"] = relerr(ro.grad.cpu(), fx["ref_g_rays_o"])
         rep["g_rays_d"] = relerr(rd.grad.cpu(), fx["ref_g_rays_d"])
