@@ -227,7 +227,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   { int rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
   PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
-  PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
+  PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * 2 * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * 2 * kAdamRowSlots));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   {
     // scratch of the fused loops, sized once for the capacity of this context (nothing is allocated inside psl_map_iters
@@ -249,7 +249,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   dbg_range("wf", c->wf, sizeof(float) * kFFloats);
   dbg_range("wb", c->wb, sizeof(float) * kBFloats); dbg_range("wf_index", c->wf_index, sizeof(int) * kColorFloats);
   dbg_range("wb_index", c->wb_index, sizeof(int) * kColorFloats); dbg_range("d_small", c->d_small, 256);
-  dbg_range("d_expo", c->d_expo, sizeof(float) * 64 * (12 + 128 + 12)); dbg_range("adam_rows", c->adam_rows, 8 * kAdamRowSlots);
+  dbg_range("d_expo", c->d_expo, sizeof(float) * 64 * (12 + 128 + 12)); dbg_range("adam_rows", c->adam_rows, 16 * kAdamRowSlots);
   *out = c;
   return PSL_OK;
 }
@@ -366,7 +366,7 @@ extern "C" int psl_sync(psl_ctx* ctx, void* stream) {
 
 static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "composite_bwd", "decode_bwd", "dw_gemm",
                                          "adam", "misc", "decode_fwd_geo", "decode_bwd_geo", "decode_fwd_track",
-                                         "decode_bwd_track", "knn_side_stream", "knn_prefetch", "geo_iter"};
+                                         "decode_bwd_track", "knn_side_stream", "knn_prefetch", "geo_iter", "adam_dense"};
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
@@ -406,7 +406,7 @@ extern "C" int psl_profile_enable(psl_ctx* ctx, int on) {
   if (on) {
     memset(ctx->prof_count, 0, sizeof(ctx->prof_count)); memset(ctx->prof_work, 0, sizeof(ctx->prof_work));
     memset(ctx->prof_seen, 0, sizeof(ctx->prof_seen));
-    PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long) * kAdamRowSlots));
+    PSL_HIP(hipMemset(ctx->adam_rows, 0, sizeof(unsigned long long) * 2 * kAdamRowSlots));
   }
   return PSL_OK;
 }
@@ -431,11 +431,15 @@ extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, do
     count_out[i] = ctx->prof_seen[i];
     work_out[i] = ctx->prof_work[i];
   }
-  if (n > (int)PROF_ADAM) {   // feature rows the lazy Adam stepped: 5 streams x 4 B x 32 channels each
+  // feature rows the lazy Adam stepped: 5 streams x 4 B x 32 channels each; work-list launches and the
+  // block-end catch-ups count into separate halves of adam_rows
+  for (int half = 0; half < 2; ++half) {
+    const int cls = half ? (int)PROF_ADAM_DENSE : (int)PROF_ADAM;
+    if (n <= cls) continue;
     unsigned long long rows = 0, slots[kAdamRowSlots];
-    PSL_HIP(hipMemcpy(slots, ctx->adam_rows, sizeof(slots), hipMemcpyDeviceToHost));
+    PSL_HIP(hipMemcpy(slots, ctx->adam_rows + (size_t)half * kAdamRowSlots, sizeof(slots), hipMemcpyDeviceToHost));
     for (int k = 0; k < kAdamRowSlots; k += 8) rows += slots[k];
-    work_out[PROF_ADAM] += 20.0 * C * (double)rows;
+    work_out[cls] += 20.0 * C * (double)rows;
   }
   return n;
 }

@@ -104,6 +104,7 @@ enum ProfSlot { PROF_KNN = 0, PROF_DECODE_FWD, PROF_COMPOSITE, PROF_COMPOSITE_BW
                 PROF_KNN_SIDE,   // the mapper's k-NN block prefetch while it runs on the side stream (off the critical path)
                 PROF_KNN_PREFETCH,   // ... and on the main stream (first block of a call): the per-ray kernel, 10^4..10^5 rays per launch
                 PROF_GEO_ITER,       // geometry-stage mapper iteration in one launch (decode fwd + compositing + loss + decode bwd)
+                PROF_ADAM_DENSE,     // the lazy Adam's block-end catch-up over every selected row (and the dense Adam when lazy is off)
                 PROF_N };
 inline int prof_decode_slot(int flags, bool bwd) {
   if (!(flags & PSL_STAGE_COLOR)) return bwd ? PROF_DECODE_BWD_GEO : PROF_DECODE_FWD_GEO;

@@ -764,6 +764,7 @@ int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 // geometry-stage mapper iterations as ONE launch (psl_decode_geo.hip) instead of decode fwd / ray kernel / decode bwd
 int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
+constexpr int kGeoIterMaxSamples = 10000;
 }  // namespace psl
 
 // ---------------------------------------------------------------------------------------------- C ABI
@@ -1122,7 +1123,9 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
       wl = AdamWorklist{ctx->pre_I, ctx->pre_I + (size_t)n * S * K, n * S * K / 4, m->row_map, ctx->adam_need, it + 1,
                         ctx->adam_list, ctx->adam_count + it};
     int rc;
-    const bool geo_one_launch = !color_stage && g_geo_fused != 0;
+    // one launch per geometry-stage iteration in the latency regime only: at 25 000 samples (Replica yaml) the one-wave
+    // tiles of k_geo_iter take 81 us against 35 + 8 + 21 us for the three throughput-shaped launches (PSL_GEO_FUSED=2 forces it)
+    const bool geo_one_launch = !color_stage && (g_geo_fused == 2 || (g_geo_fused == 1 && n * S <= kGeoIterMaxSamples));
     if (geo_one_launch) {
       // stage 'geometry': decode forward, compositing, loss, compositing backward and decode backward of whole ray triples
       // per wavefront, ONE launch (+ the work list of this iteration's Adam as extra workgroups)
@@ -1150,7 +1153,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     // dense Adam: 5 streams (p r/w, g r/w(zero), m r/w, v r/w ~ 7 accesses of 4 B; counted as 5 x 4 B per element as in
     // SURVEY.md §8d) over every selected row
     // (lazy path: the rows actually stepped are counted on the device and added by psl_profile_read)
-    ProfScope psa(ctx, PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
+    ProfScope psa(ctx, dense ? PROF_ADAM_DENSE : PROF_ADAM, s, 20.0 * ((lazy ? 0.0 : (double)m->n_sel * C * (color_stage ? 2 : 1)) +
                                              ((color_stage && m->train_decoder) ? (double)ncol : 0.0)), true);
     {
       AdamRowsSeg sg{}, sc{};
@@ -1171,7 +1174,7 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
         }
       }
       AdamLazy lz{lazy ? ctx->adam_tab : nullptr, (lazy && !dense) ? ctx->adam_list : nullptr,
-                  lazy ? ctx->adam_count + it : nullptr, ctx->adam_list_cap, it, ctx->adam_rows, it - it % kblock};
+                  lazy ? ctx->adam_count + it : nullptr, ctx->adam_list_cap, it, ctx->adam_rows + (dense ? kAdamRowSlots : 0), it - it % kblock};
       rc = launch_map_adam(sg, m->step0_geo + it + 1, lr_geo, sc, st, m->lr_col, sp, m->lr_decoder, s,
                            st + m->step0_params, lz);
       if (rc) return rc;

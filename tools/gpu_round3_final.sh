@@ -15,8 +15,8 @@ timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r03 -o r03 -- py
 python tools/rocpd_stats.py gpurun_out/prof_r03/r03_results.db --csv gpurun_out/r03_kernel_trace_stats.csv | head -20
 python tools/rocpd_timeline.py gpurun_out/prof_r03/r03_results.db 0.5 > gpurun_out/r03_timeline.txt
 rm -rf gpurun_out/prof_r03
-timeout 600 python tools/roofline_sweep.py 2>gpurun_out/r03_sweep.err | tail -1 > gpurun_out/r03_roofline_sweep.json
-timeout 300 python tools/knn_roofline.py 2>gpurun_out/r03_knn_roofline.err | tail -1 > gpurun_out/r03_knn_roofline.json
+timeout 600 python tools/roofline_sweep.py > gpurun_out/r03_sweep.log 2>&1; cp gpurun_out/roofline_sweep.json gpurun_out/r03_roofline_sweep.json
+timeout 300 python tools/knn_roofline.py > gpurun_out/r03_knn_roofline.log 2>&1; cp gpurun_out/knn_roofline.json gpurun_out/r03_knn_roofline.json
 for mix in replica tum scannet; do
   timeout 300 python bench.py --no-cpu-baseline --mix $mix 2>gpurun_out/r03_bench_$mix.err | tail -1 > gpurun_out/r03_bench_$mix.json
   echo "mix=$mix"; python tools/show_bench.py gpurun_out/r03_bench_$mix.json | grep -E "FPS"
