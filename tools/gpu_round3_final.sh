@@ -20,6 +20,9 @@ timeout 300 python tools/knn_roofline.py > gpurun_out/r03_knn_roofline.log 2>&1;
 for mix in replica tum scannet; do
   timeout 300 python bench.py --no-cpu-baseline --mix $mix 2>gpurun_out/r03_bench_$mix.err | tail -1 > gpurun_out/r03_bench_$mix.json
   echo "mix=$mix"; python tools/show_bench.py gpurun_out/r03_bench_$mix.json | grep -E "FPS"
+  # round 2 quoted these mixes on 6 steps after 2 warm-up frames: the same command for a like-for-like comparison
+  timeout 300 python bench.py --no-cpu-baseline --mix $mix --steps 6 --warmup 2 2>/dev/null | tail -1 > gpurun_out/r03_bench_${mix}_6steps.json
+  echo "mix=$mix, 6 steps"; python tools/show_bench.py gpurun_out/r03_bench_${mix}_6steps.json | grep -E "FPS"
 done
 timeout 400 python bench.py --no-cpu-baseline --points 2000000 --width 1280 --height 960 2>gpurun_out/r03_bench_cfg5.err | tail -1 > gpurun_out/r03_bench_cfg5.json
 echo cfg5; python tools/show_bench.py gpurun_out/r03_bench_cfg5.json | grep -E "FPS"
