@@ -226,7 +226,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
   PSL_HIP(hipMalloc(&c->wb_index, sizeof(int) * kColorFloats));
   { int rc = build_frag_index(c, nullptr); if (rc) return rc;
     PSL_HIP(hipStreamSynchronize(nullptr)); }
-  PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long))); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long)));
+  PSL_HIP(hipMalloc(&c->knn_cand, sizeof(unsigned long long) * 8 * kKnnCandSlots)); PSL_HIP(hipMemset(c->knn_cand, 0, sizeof(unsigned long long) * 8 * kKnnCandSlots));
   PSL_HIP(hipMalloc(&c->adam_rows, sizeof(unsigned long long) * 2 * kAdamRowSlots)); PSL_HIP(hipMemset(c->adam_rows, 0, sizeof(unsigned long long) * 2 * kAdamRowSlots));
   PSL_HIP(hipMalloc(&c->d_counter, sizeof(int) * 4)); psl::poison(c->d_counter, sizeof(int) * 4);
   {
@@ -388,10 +388,11 @@ extern "C" int psl_debug_option(const char* name, int value) {
 // candidates (16-byte position records) the ray k-NN has examined since the previous call; synchronises and resets
 extern "C" int64_t psl_knn_candidates(psl_ctx* ctx) {
   if (!ctx) return PSL_ERR_ARG;
-  unsigned long long v = 0;
+  unsigned long long v = 0, slots[8 * kKnnCandSlots];
   if (hipDeviceSynchronize() != hipSuccess) return PSL_ERR_HIP;
-  if (hipMemcpy(&v, ctx->knn_cand, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return PSL_ERR_HIP;
-  if (hipMemset(ctx->knn_cand, 0, sizeof(v)) != hipSuccess) return PSL_ERR_HIP;
+  if (hipMemcpy(slots, ctx->knn_cand, sizeof(slots), hipMemcpyDeviceToHost) != hipSuccess) return PSL_ERR_HIP;
+  if (hipMemset(ctx->knn_cand, 0, sizeof(slots)) != hipSuccess) return PSL_ERR_HIP;
+  for (int k = 0; k < 8 * kKnnCandSlots; k += 8) v += slots[k];
   return (int64_t)v;
 }
 

@@ -157,7 +157,7 @@ struct psl_ctx {
   char* h_stage = nullptr; hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr}; int stage_next = 0;
   float4* adam_tab = nullptr; size_t adam_tab_cap = 0;            // per-iteration (lr/bc1, sqrt(bc2)) of the two row groups
   unsigned long long* adam_rows = nullptr;                        // feature rows stepped by the lazy Adam since the last profile read
-  unsigned long long* knn_cand = nullptr;   // candidates examined by the ray k-NN since the last psl_knn_candidates() read
+  unsigned long long* knn_cand = nullptr;   // [kKnnCandSlots * 8] candidates examined by the ray k-NN since the last psl_knn_candidates() read
   int* d_counter;
   // multi-GPU exchange (psl_comm.hip): RCCL communicator (ncclComm_t), device counts [world + 1], staging buffer
   void* comm = nullptr; int comm_rank = 0, comm_world = 0; int* comm_counts = nullptr; float* comm_stage = nullptr; size_t comm_stage_cap = 0;
@@ -267,6 +267,7 @@ struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_row
 // Lazy, exact Adam of the mapper's feature rows (see k_map_adam): per-iteration constants of the whole call
 constexpr int kAdamTabLds = 72;   // >= the k-NN prefetch block (64 iterations) + 1
 constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache lines
+constexpr int kKnnCandSlots = 256;       // the k-NN candidate counter likewise (one same-address atomic per query serialised a 25 000-query launch: 316 vs ~100 us)
 struct AdamLazy { const float4* tab; const int* list; const int* count; long long list_cap; int it;
                   unsigned long long* rows_done; int base; };
 struct AdamParSeg { float *p, *g, *m, *v; int n; float lr_bc1, sqrt_bc2;

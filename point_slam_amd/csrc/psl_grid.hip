@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_knn_rays_flat(const GridMeta* __restric
   const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
   const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
+  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand); }
   if (trace && lane == 0) {
     const unsigned long long cyc = clock64() - t0;
     atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ m
   const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
   const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter, n_cand); }
+  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand); }
   if (trace && lane == 0) {
     const unsigned long long cyc = clock64() - t0;
     atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict_
     if (last || thr != sentinel) break;
     rho *= 2.0f;
   }
-  if (lane == 0 && cand_counter) atomicAdd(cand_counter, n_cand);
+  if (lane == 0 && cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand);
   if (wsub != 0) return;
   const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
   const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_knn_rays2(const GridMeta* __restrict__ 
   for (int ray = wave0; ray < n_rays; ray += n_waves)
     knn_ray2_one(ray, m, spos, cell_start, rays_o, rays_d, depth, z_vals, r_query, r_fixed, r2_fixed, near_s, far_s, I_out,
                  cnt_out, cand, coarse);
-  if (cand_counter && (threadIdx.x & 63) == 0 && cand) atomicAdd(cand_counter, cand);
+  if (cand_counter && (threadIdx.x & 63) == 0 && cand) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), cand);
 }
 
 // sample_near_pcl marching test (src/neural_point.py:232-249): one wave per (ray, step); a step "hits" when at least
@@ -1074,24 +1074,28 @@ __global__ __launch_bounds__(256) void k_dedupe_count(const GridMeta* __restrict
   if (lane == 0) cnt_out[qi] = cnt;
 }
 
-int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch size (default), 1 = one wavefront per sample, 2 = per ray
+int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch (default), 1 / 3 / 4 = a per-sample kernel, 2 = per ray
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s, int max_blocks) {
   if (n_rays <= 0) return PSL_OK;
   if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0; }
-  // 0 = by launch size: from ~10^3 rays on (TUM/ScanNet tracking, the mapper's block prefetch of 10^4..10^5 rays) the
-  // shared candidate scan of one wavefront per ray (2); below that one wavefront per sample (1).  3 = four wavefronts
-  // per sample sharing the rows of every pass: measured no faster than (1) on the tracker's 200-ray launches, before
-  // and after both got the lane-distributed list (68 vs 67 us, then 67 vs 63 us; profiles/r02_knn_small_ab.txt) --
-  // those launches are not bound by the serial row walk of a wavefront -- so it stays an option (PSL_KNN_SMALL=3),
-  // covered by the exactness tests.
-  // 4 = one wavefront per sample with the FLAT candidate enumeration (two dependent memory trips per pass): the default
-  // below 1 024 rays since round 3
+  // 0 = by launch: the THROTTLED side-stream prefetch of the mapper (max_blocks > 0: a persistent grid whose wavefronts
+  // walk several rays each) takes the per-ray kernel (2), whose five samples share one scan of the union box (173
+  // candidates per query against 522); every unthrottled launch takes the per-sample kernel.  Round 2 switched to the
+  // per-ray kernel from 1 024 rays on; measured in round 3 with the flat enumeration (4) and the candidate counter spread
+  // over 256 cache lines (one same-address atomic per query had serialised the 25 000-query launches): tracker launches
+  // of 1 500 rays 131 -> 39 us, of 5 000 rays 199 -> 80 us (TUM / ScanNet yamls +12 % frames/s), the mapper's main-stream
+  // prefetch of 64 x 1 000 rays 996 -> 890 us.  PSL_KNN_SMALL_MAX=<rays> restores a size threshold.
+  // 1 = one wavefront per sample, row walk.  3 = four wavefronts per sample sharing the rows of every pass: measured no
+  // faster than (1) on the tracker's 200-ray launches (profiles/r02_knn_small_ab.txt); an option (PSL_KNN_SMALL=3).
+  // 4 = one wavefront per sample with the FLAT candidate enumeration (two dependent memory trips per pass): the default.
   static int small_ver = -1;
   if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; if (small_ver == 2) small_ver = 4; }
-  const int ver = g_knn_version ? g_knn_version : (n_rays >= 1024 ? 2 : small_ver);
+  static int small_max = -1;     // launches below this many rays take the per-sample kernel
+  if (small_max < 0) { const char* e = getenv("PSL_KNN_SMALL_MAX"); small_max = e ? atoi(e) : 0x7fffffff; }
+  const int ver = g_knn_version ? g_knn_version : ((n_rays >= small_max || max_blocks > 0) ? 2 : small_ver);
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
