@@ -155,6 +155,7 @@ static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& 
   d.r2_fixed = (float)((double)ctx->cfg.radius_query * (double)ctx->cfg.radius_query);
   d.rays_o = a->rays_o; d.rays_d = a->rays_d; d.depth = a->gt_depth; d.zv = a->z_vals; d.r_query = a->r_query;
   d.pos = ctx->pos;
+  d.zero64 = ctx->fwd_zero64;
   d.geo_feats = a->geo_feats; d.col_feats = a->col_feats;
   d.master = a->params; d.Bcol = a->col_embed_B;
   d.fb_geo = a->fallback_geo; d.fb_col = a->fallback_col; d.affine = a->exposure_affine;
@@ -236,7 +237,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
     const size_t need = (3 * ns + kStageTabIters + lcap) * sizeof(int) + 2 * ns;
     PSL_HIP(hipMalloc(&c->touched, need)); c->touched_cap = need;
     PSL_HIP(hipMalloc(&c->adam_tab, sizeof(float4) * (kStageTabIters + 64))); c->adam_tab_cap = kStageTabIters + 64;
-    PSL_HIP(hipMalloc(&c->loss_acc, sizeof(double) * 4 * kStageTabIters)); c->loss_acc_cap = (int)kStageTabIters;
+    PSL_HIP(hipMalloc(&c->loss_acc, sizeof(double) * 4 * kLossSlots * kStageTabIters)); c->loss_acc_cap = (int)kStageTabIters;
     PSL_HIP(hipHostMalloc((void**)&c->h_stage, 4 * kStageSlot, hipHostMallocDefault));
     for (int i = 0; i < 4; ++i) PSL_HIP(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
   }
@@ -370,7 +371,7 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused; int knn_trace_dump(); }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
@@ -380,6 +381,7 @@ extern "C" int psl_debug_option(const char* name, int value) {
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }
   if (!strcmp(name, "knn_overlap")) { psl::g_knn_overlap = value; return PSL_OK; }
   if (!strcmp(name, "geo_fused")) { psl::g_geo_fused = value; return PSL_OK; }
+  if (!strcmp(name, "ray_in_bwd")) { psl::g_ray_in_bwd = value; return PSL_OK; }
   if (!strcmp(name, "knn_trace_dump")) return psl::knn_trace_dump();
   set_error("psl_debug_option: unknown option %s", name);
   return PSL_ERR_ARG;

@@ -165,7 +165,9 @@ struct psl_ctx {
   int* pre_cnt = nullptr;
   unsigned* img_hist = nullptr;   // 65536-bin histogram + select state of psl_topgrad_select_sync
   bool fused_ray = false;    // psl_map_iters: compositing fwd/bwd + loss run in its own fused kernel
-  double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters
+  double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters: [iteration][kLossSlots][4]
+  float* fwd_zero64 = nullptr;   // psl_map_iters, ray stage inside the backward: the colour-stage forward clears the backward's accumulators
+  const void* ray_fuse = nullptr; const void* ray_wl = nullptr;   // ... RayFuse* / AdamWorklist* handed to launch_decode_bwd2
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   float* d_expo;         // per-frame exposure scratch: affines [64][12], hidden activations [64][128], d(affine) [64][12]
   int* scan_flags;       // for add_points compaction
@@ -267,6 +269,7 @@ struct AdamRowsSeg { float* feats; const int* rows; float4 *g, *m, *v; int n_row
 // Lazy, exact Adam of the mapper's feature rows (see k_map_adam): per-iteration constants of the whole call
 constexpr int kAdamTabLds = 72;   // >= the k-NN prefetch block (64 iterations) + 1
 constexpr int kAdamRowSlots = 256 * 8;   // rows_done is spread over 256 cache lines
+constexpr int kLossSlots = 32;          // per-iteration loss sums of psl_map_iters: [slot][4] doubles, slot = workgroup & 31 (one address took ~10^3 atomics per launch)
 constexpr int kKnnCandSlots = 256;       // the k-NN candidate counter likewise (one same-address atomic per query serialised a 25 000-query launch: 316 vs ~100 us)
 struct AdamLazy { const float4* tab; const int* list; const int* count; long long list_cap; int it;
                   unsigned long long* rows_done; int base; };

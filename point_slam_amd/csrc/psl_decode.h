@@ -16,6 +16,7 @@ struct DecodeArgs {
   const float* Bcol;     // [3][20]
   const float *fb_geo, *fb_col, *affine;
   RenderWs ws;
+  float* zero64;             // psl_map_iters, ray stage inside the backward: the forward clears the backward's 64 accumulators
   unsigned long long* dbg;   // optional phase timestamps (PSL_DEBUG_PHASES=1)
   unsigned long long* blk;   // optional per-workgroup trace [grid][4]: wall start, wall end, hw id, shader cycles (PSL_DEBUG_BLOCKS=<file>)
 };
@@ -32,6 +33,83 @@ struct BlkTrace {
     o[0] = w0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - c0;
   }
 };
+// ---- the mapper's ray stage inside the colour-stage decode backward (psl_map_iters without per-frame exposure) --------
+// k_map_ray_fused (psl_ray.hip) is 8 us of launch latency between the two decode kernels, 240 times per mapped frame.  Its
+// work per ray is ~150 instructions on 5 samples, and a ray's cotangents depend on nothing but that ray: the thread that
+// owns a sample in the backward's set-up phase evaluates the sample's ray itself (compositing common.py:298-336, mapper loss
+// Mapper.py:524-553, compositing backward) and keeps the cotangent of its own sample; the thread of a ray's FIRST sample
+// also writes the ray's outputs and adds its loss terms.  Same expressions, same order as k_map_ray_fused.
+struct RayFuse {
+  const int* active; const float* gt_color; float coef, w_color; int n_rays;
+  float *depth, *var, *rgb; unsigned char* valid;
+  double* loss_acc;        // this iteration's [kLossSlots][4]
+  int on;
+};
+
+// cotangent of raw[p] (rgb after sigmoid, occupancy logit); owner (first sample of its ray): outputs + loss terms
+__device__ __forceinline__ float4 ray_cotangent(const DecodeArgs& a, const RayFuse& rf, int p, bool owner_writes, double& lg,
+                                                double& lc, double& lcnt) {
+  const int r = p / S, sj = p - r * S;
+  float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S];
+  float T = 1.0f, wsum = 0.f;
+  int nhas = 0;
+  const float gt = a.depth[r];
+  const float4* raw = reinterpret_cast<const float4*>(a.ws.raw);
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float4 q = raw[r * S + s];
+    z[s] = sample_z(gt, s, a.near_s, a.far_s);
+    al[s] = sigmoidf(rf.coef * q.w);
+    Tt[s] = T;
+    w[s] = al[s] * T;
+    T = T * (1.0f - al[s] + 1e-10f);
+    wsum += w[s];
+    c0[s] = q.x; c1[s] = q.y; c2[s] = q.z;
+    nhas += (a.ws.cnt[r * S + s] >= a.min_nn) ? 1 : 0;
+  }
+  const float W = wsum + 1e-10f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a0 += w[s] * c0[s]; a1 += w[s] * c1[s]; a2 += w[s] * c2[s]; ad += w[s] * z[s]; }
+  const float d = ad / W, m0 = a0 / W, m1 = a1 / W, m2 = a2 / W;
+  const bool vr = nhas >= (S / 2 + 1);
+  const bool owner = owner_writes && sj == 0;
+  if (owner) {
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { const float tmp = z[s] - d; v += w[s] * tmp * tmp; }
+    rf.depth[r] = d; rf.var[r] = v; rf.rgb[r * 3] = m0; rf.rgb[r * 3 + 1] = m1; rf.rgb[r * 3 + 2] = m2; rf.valid[r] = vr ? 1 : 0;
+  }
+  float gd = 0.f, gr0 = 0.f, gr1 = 0.f, gr2 = 0.f;
+  if (rf.active[r] && gt > 0.f && vr && d == d) {
+    gd = (d > gt) ? 1.f : ((d < gt) ? -1.f : 0.f);
+    const float g0 = rf.gt_color[r * 3], g1 = rf.gt_color[r * 3 + 1], g2 = rf.gt_color[r * 3 + 2];
+    gr0 = rf.w_color * ((m0 > g0) ? 1.f : ((m0 < g0) ? -1.f : 0.f));
+    gr1 = rf.w_color * ((m1 > g1) ? 1.f : ((m1 < g1) ? -1.f : 0.f));
+    gr2 = rf.w_color * ((m2 > g2) ? 1.f : ((m2 < g2) ? -1.f : 0.f));
+    if (owner) {
+      lg = (double)fabsf(gt - d);
+      lc = (double)fabsf(g0 - m0) + (double)fabsf(g1 - m1) + (double)fabsf(g2 - m2);
+      lcnt = 1.0;
+    }
+  }
+  float gw[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+    gw[s] = (gd * (z[s] - d) + gr0 * (c0[s] - m0) + gr1 * (c1[s] - m1) + gr2 * (c2[s] - m2)) / W;
+  float suffix = 0.f;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = S - 1; s >= 0; --s) {
+    const float ga = gw[s] * Tt[s] - suffix / (1.0f - al[s] + 1e-10f);
+    const float gocc = ga * rf.coef * al[s] * (1.0f - al[s]);
+    const float ws = w[s] / W;
+    if (s == sj) out = make_float4(gr0 * ws, gr1 * ws, gr2 * ws, gocc);
+    suffix += gw[s] * w[s];
+  }
+  return out;
+}
+
 // work list of the lazy Adam (as adam_worklist_role, psl_ray.hip), one int4 of neighbour indices per lane; wave-level appends
 __device__ __forceinline__ void worklist_role_wave(const AdamWorklist& wl, int i) {
   const int lane = threadIdx.x & 63;
@@ -67,7 +145,7 @@ struct GeoIterRays {
   float coef;                   // sigmoid coefficient of the mapper (Mapper.py:45)
   float *depth, *var, *rgb;     // [R], [R], [R][3] render outputs (rgb = 0 in this stage)
   unsigned char* valid;         // [R]
-  double* loss_acc;             // [4]: sum |d_gt - d|, (colour: unused), #rays in the mask
+  double* loss_acc;             // [kLossSlots][4]: sum |d_gt - d|, (colour: unused), #rays in the mask; slot = workgroup & 31
   float* zero64;                // accumulators of a later colour-stage backward (cleared here as the ray kernel does)
   int n_rays;
 };

@@ -78,7 +78,7 @@ static_assert(8 * TILE * C <= 2 * 8 * FRAG && 16 * LD_X2 <= TILE * C, "the per-w
 // One wavefront per tile.  d_occ flows for masked samples too (straight-through of the -100 write, Renderer.py:189-190).
 template <bool PTSG>
 __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0,
-                                             ScatterLds& sl) {
+                                             ScatterLds& sl, const RayFuse* rf = nullptr) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
   const bool live = p0 + rl < a.P;
@@ -97,7 +97,13 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
     w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
   }
   const bool has = live && a.ws.cnt[p] >= a.min_nn;
-  const float docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  float docc = 0.f;
+  if (rf && rf->on) {      // ray stage inside this kernel: every lane evaluates the ray of its own sample (outputs and loss
+    double u0, u1, u2;     // belong to the colour role)
+    docc = live ? ray_cotangent(a, *rf, p, false, u0, u1, u2).w : 0.f;
+  } else {
+    docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  }
   // G = d_occ * w_out (output_linear.weight [1][32]), channel 16 nt + 4 g + r
   f32x4 G[2], dcg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -222,7 +228,8 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
 
 // ------------------------------------------------------------------------------------------------ colour role
 template <bool PTSG>
-__device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0) {
+__device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0,
+                                               const RayFuse& rf) {
   using L = Bwd2Lds;
   int* sI = (int*)(smem + L::oI);           // [16][8]
   float* sW = smem + L::oW;                 // [16][8] normalised weights
@@ -276,8 +283,11 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     float ag[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) ag[j] = 0.f;
+    double lg = 0.0, lc = 0.0, lcnt = 0.0;
     if (p < a.P) {
-      const float4 dr = reinterpret_cast<const float4*>(a.ws.d_raw)[p];
+      // psl_map_iters without per-frame exposure: the ray stage (compositing, loss, compositing backward) of this sample's ray
+      // runs here instead of in a launch of its own between the two decode kernels
+      const float4 dr = rf.on ? ray_cotangent(a, rf, p, true, lg, lc, lcnt) : reinterpret_cast<const float4*>(a.ws.d_raw)[p];
       const float4 rw = reinterpret_cast<const float4*>(a.ws.raw)[p];
       d0 = dr.x; d1 = dr.y; d2 = dr.z;
       if (!(a.flags & PSL_NO_SIGMOID)) { d0 *= rw.x * (1.f - rw.x); d1 *= rw.y * (1.f - rw.y); d2 *= rw.z * (1.f - rw.z); }
@@ -297,6 +307,14 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 #pragma unroll
     for (int j = 0; j < 12; ++j) sAffP[s * 12 + j] = ag[j];
     sDO[s * 4] = d0; sDO[s * 4 + 1] = d1; sDO[s * 4 + 2] = d2; sDO[s * 4 + 3] = 0.f;
+    if (rf.on) {     // the tile's loss terms (owners of at most four rays among these 16 lanes) -> one slot of the iteration
+#pragma unroll
+      for (int ofs = 8; ofs > 0; ofs >>= 1) { lg += __shfl_xor(lg, ofs); lc += __shfl_xor(lc, ofs); lcnt += __shfl_xor(lcnt, ofs); }
+      if (s == 0 && lcnt != 0.0) {
+        double* acc = rf.loss_acc + 4 * (blockIdx.x & (kLossSlots - 1));
+        atomicAdd(acc + 0, lg); atomicAdd(acc + 1, lc); atomicAdd(acc + 2, lcnt);
+      }
+    }
   } else if (t < TILE * K + TILE + 32) {
     sDB[t - TILE * K - TILE] = 0.f;
   } else if (PTSG && t < TILE * K + TILE + 32 + 64) {
@@ -652,15 +670,22 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 }
 
 // grid as in the forward: [0, color_tiles) colour role, then one geometry-role WAVEFRONT per tile in a workgroup of its own
+// (psl_map_iters, colour stage without exposure: rf.on -- the ray stage runs inside this kernel, and the workgroups from
+//  wl_block0 on build the work list of the iteration's lazy Adam, which the ray kernel used to carry)
 template <bool PTSG, bool COLOR>
-__global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles) {
+__global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
+                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (COLOR && (int)blockIdx.x >= wl_block0) {
+    worklist_role_wave(wl, ((int)blockIdx.x - wl_block0) * (int)blockDim.x + (int)threadIdx.x);
+    return;
+  }
   BlkTrace bt(a);
   if (COLOR && (int)blockIdx.x < color_tiles) {
-    color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE);
+    color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE, rf);
   } else {
     if (threadIdx.x >= 64) return;
-    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem));
+    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
   }
   bt.done(a);
 }
@@ -687,16 +712,25 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   static int dbg_on = -1;
   if (dbg_on < 0) { const char* e = getenv("PSL_DEBUG_PHASES"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
   if (dbg_on && a.dbg) PSL_HIP(hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), s));
-  { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
+  RayFuse rf{};
+  AdamWorklist wl{};
+  int wl_blocks = 0;
+  if (ctx->ray_fuse && color && !ptsg) {
+    rf = *(const RayFuse*)ctx->ray_fuse;
+    if (ctx->ray_wl) wl = *(const AdamWorklist*)ctx->ray_wl;
+    if (wl.I_a && wl.n4 > 0) wl_blocks = ((wl.I_b ? 2 : 1) * wl.n4 + WG - 1) / WG;
+  }
+  const int grid_c = 2 * tiles + wl_blocks;
+  { int rc = blk_trace_begin(a, color ? grid_c : tiles, s); if (rc) return rc; }
   if (color) {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
-    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
+    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
   } else {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
-    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
+    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
   }
   PSL_LAUNCH_CHECK();
-  { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
+  { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? grid_c : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on && a.dbg && color) {
     unsigned long long h[64];
     PSL_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));

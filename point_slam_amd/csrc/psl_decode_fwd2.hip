@@ -495,6 +495,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 // workgroups, geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+  if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
   if (COLOR && (int)blockIdx.x < color_tiles) {

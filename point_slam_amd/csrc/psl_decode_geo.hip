@@ -207,8 +207,9 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { lg += __shfl_xor(lg, o); lcnt += __shfl_xor(lcnt, o); }
   if (lane == 0 && gr.loss_acc) {
-    if (lg != 0.0) atomicAdd(&gr.loss_acc[0], lg);
-    if (lcnt != 0.0) atomicAdd(&gr.loss_acc[2], lcnt);
+    double* acc = gr.loss_acc + 4 * (blockIdx.x & (kLossSlots - 1));
+    if (lg != 0.0) atomicAdd(&acc[0], lg);
+    if (lcnt != 0.0) atomicAdd(&acc[2], lcnt);
   }
 
   PSL_STAMP(5);

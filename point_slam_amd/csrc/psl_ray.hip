@@ -158,7 +158,7 @@ __device__ __forceinline__ void adam_worklist_role(const AdamWorklist& wl, int i
 // Mapper iteration, everything between the two decode kernels in ONE launch: compositing (common.py:298-336), the
 // mapper loss with its mask (Mapper.py:524-553: L1 sums, so every ray's cotangent is local) and the compositing
 // backward.  Replaces k_composite_fwd + k_mapper_loss + k_composite_bwd (three ~6 us launches per iteration).
-// loss_acc[0..2] += (sum |d_gt - d|, sum |c_gt - c|, #rays in the mask) in double.
+// loss_acc[slot][0..2] += (sum |d_gt - d|, sum |c_gt - c|, #rays in the mask) in double, slot = workgroup & (kLossSlots - 1).
 __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict__ raw, const int* __restrict__ cnt,
                                                        const float* __restrict__ gt_depth, const float* __restrict__ gt_color,
                                                        const int* __restrict__ active, float near_s, float far_s,
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
   __syncthreads();
   if (threadIdx.x < 3) {
     double t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    if (t != 0.0) atomicAdd(&loss_acc[threadIdx.x], t);
+    if (t != 0.0) atomicAdd(&loss_acc[4 * (blockIdx.x & (kLossSlots - 1)) + threadIdx.x], t);
   }
 }
 

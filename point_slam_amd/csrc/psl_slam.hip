@@ -251,12 +251,16 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
   }
 }
 
-// per-iteration loss record of psl_map_iters from the double accumulators of k_map_ray_fused: (L, L_geo, L_col, #rays)
+// per-iteration loss record of psl_map_iters from the double accumulators [iteration][kLossSlots][4] of the ray stage: (L, L_geo, L_col, #rays)
 __global__ void k_map_loss_finalize(const double* __restrict__ acc, int n_iters, int n_geo_iters, float w_color,
                                     float* __restrict__ loss_out) {
   int it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= n_iters) return;
-  const double Lg = acc[4 * it], Lc = acc[4 * it + 1], cnt = acc[4 * it + 2];
+  double Lg = 0.0, Lc = 0.0, cnt = 0.0;
+  for (int k = 0; k < kLossSlots; ++k) {      // slot order: the same sum whichever workgroups contributed
+    const double* q = acc + 4 * ((size_t)it * kLossSlots + k);
+    Lg += q[0]; Lc += q[1]; cnt += q[2];
+  }
   const double L = (it > n_geo_iters) ? Lg + (double)w_color * Lc : Lg;
   loss_out[4 * it] = (float)L; loss_out[4 * it + 1] = (float)Lg; loss_out[4 * it + 2] = (float)Lc;
   loss_out[4 * it + 3] = (float)cnt;
@@ -764,6 +768,8 @@ int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 // geometry-stage mapper iterations as ONE launch (psl_decode_geo.hip) instead of decode fwd / ray kernel / decode bwd
 int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
+// colour stage (no per-frame exposure): compositing + loss + compositing backward inside the decode backward, no ray kernel
+int g_ray_in_bwd = env_flag("PSL_RAY_IN_BWD", 1);
 constexpr int kGeoIterMaxSamples = 10000;
 }  // namespace psl
 
@@ -1009,11 +1015,11 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
   }
   if (ctx->loss_acc_cap < m->n_iters) {
     if (ctx->loss_acc) (void)hipFree(ctx->loss_acc);
-    PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters)); psl::poison(ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
+    PSL_HIP(hipMalloc(&ctx->loss_acc, sizeof(double) * 4 * kLossSlots * (size_t)m->n_iters)); psl::poison(ctx->loss_acc, sizeof(double) * 4 * kLossSlots * (size_t)m->n_iters);
     ctx->loss_acc_cap = m->n_iters;
-    dbg_range("loss_acc", ctx->loss_acc, sizeof(double) * 4 * (size_t)m->n_iters);
+    dbg_range("loss_acc", ctx->loss_acc, sizeof(double) * 4 * kLossSlots * (size_t)m->n_iters);
   }
-  PSL_HIP(hipMemsetAsync(ctx->loss_acc, 0, sizeof(double) * 4 * (size_t)m->n_iters, s));
+  PSL_HIP(hipMemsetAsync(ctx->loss_acc, 0, sizeof(double) * 4 * kLossSlots * (size_t)m->n_iters, s));
   dbg_range("map.ws", m->ws, sizeof(float) * (size_t)psl_map_ws_floats(n, m->n_frames));
   dbg_range("map.pix_idx", m->pix_idx, sizeof(int) * (size_t)m->n_iters * n);
   dbg_range("map.fallback", m->fallback, sizeof(float) * (size_t)m->n_iters * 64);
@@ -1129,22 +1135,33 @@ extern "C" int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream) 
     if (geo_one_launch) {
       // stage 'geometry': decode forward, compositing, loss, compositing backward and decode backward of whole ray triples
       // per wavefront, ONE launch (+ the work list of this iteration's Adam as extra workgroups)
-      rc = geo_iter_impl(ctx, &ra, &rg, b.active, ctx->loss_acc + 4 * (size_t)it, &wl, s, repack);
+      rc = geo_iter_impl(ctx, &ra, &rg, b.active, ctx->loss_acc + 4 * kLossSlots * (size_t)it, &wl, s, repack);
       if (rc) return rc;
     } else {
+    // colour stage without per-frame exposure: the ray stage (compositing, loss, compositing backward) and the work list run
+    // inside the decode backward; the forward clears the backward's accumulators, which the ray kernel used to do
+    const bool ray_in_bwd = color_stage && !ex && g_ray_in_bwd != 0;
+    ctx->fwd_zero64 = ray_in_bwd ? ctx->d_small : nullptr;
     rc = render_fwd_impl(ctx, &ra, s, repack);
+    ctx->fwd_zero64 = nullptr;
     if (rc) return rc;
-    { // compositing + mapper loss + compositing backward in one launch (+ the work list of this iteration's Adam)
+    RayFuse rf{};
+    if (ray_in_bwd) {
+      rf = RayFuse{b.active, b.gc, m->sigmoid_coef, m->w_color, n, b.depth, b.var, b.rgb, b.valid,
+                   ctx->loss_acc + 4 * kLossSlots * (size_t)it, 1};
+      ctx->ray_fuse = &rf; ctx->ray_wl = &wl;
+    } else { // compositing + mapper loss + compositing backward in one launch (+ the work list of this iteration's Adam)
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
       const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
       rc = launch_map_ray_fused((const float4*)rw.raw, ctx->pre_cnt, b.gd, b.gc, b.active, ctx->cfg.near_end_surface,
                                 ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, n, m->sigmoid_coef, m->w_color,
                                 color_stage ? 1 : 0, b.depth, b.var, b.rgb, b.valid, (float4*)rw.d_raw,
-                                ctx->loss_acc + 4 * (size_t)it, ctx->d_small, (ex && color_stage) ? ex_aff : nullptr,
+                                ctx->loss_acc + 4 * kLossSlots * (size_t)it, ctx->d_small, (ex && color_stage) ? ex_aff : nullptr,
                                 m->pix_per_frame, ex_g, s, &wl);
       if (rc) return rc;
     }
     rc = render_bwd_impl(ctx, &ra, &rg, s);
+    ctx->ray_fuse = nullptr; ctx->ray_wl = nullptr;
     if (rc) return rc;
     }
     // Adam (Mapper.py:394-402,425-439,556): geometry features every iteration; colour features and the colour

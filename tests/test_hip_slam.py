@@ -273,7 +273,7 @@ def _map_switch_runs(n_it, variants, dev, frozen_decoder=False):
     cfg["mapping"]["fix_color_decoder"] = bool(frozen_decoder)
     L = _lib.lib()
     res, draws = {}, None
-    keys = (b"lazy_adam", b"dw_fused", b"knn_overlap", b"geo_fused")
+    keys = (b"lazy_adam", b"dw_fused", b"knn_overlap", b"geo_fused", b"ray_in_bwd")
     try:
         for name, opts in variants.items():
             for k in keys:
@@ -322,7 +322,8 @@ def test_map_native_scheduling_switches_agree():
     keys = ("loss_rel_max", "loss_rel_mean", "geo_mean", "col_mean", "geo_frac_gt_1e3", "col_frac_gt_1e3")
     all_variants = {"all_on": {}, "all_on_again": {}, "dense_adam": {b"lazy_adam": 0},
                     "separate_dw_reduce": {b"dw_fused": 0}, "knn_on_main_stream": {b"knn_overlap": 0},
-                    "geometry_stage_in_three_launches": {b"geo_fused": 0}}
+                    "geometry_stage_in_three_launches": {b"geo_fused": 0},
+                    "ray_stage_in_its_own_launch": {b"ray_in_bwd": 0}}
     for n_it, variants, frozen in ((24, all_variants, False), (150, all_variants, True)):
         res = _map_switch_runs(n_it, variants, dev, frozen_decoder=frozen)
         ref = res["all_on"]
