@@ -18,7 +18,7 @@ def main():
     tot = sum(r[2] for r in rows) or 1
     lines = ["kernel,calls,total_us,avg_us,min_us,max_us,pct"]
     for n, c, t, a, mn, mx in rows:
-        short = n.split("(")[0][-60:]
+        short = n.split("(")[0][-110:]      # long enough to keep the template arguments of k_decode_bwd2 apart
         lines.append(f"{short},{c},{t/1e3:.1f},{a/1e3:.2f},{mn/1e3:.2f},{mx/1e3:.2f},{100*t/tot:.1f}")
     out = "\n".join(lines)
     if "--csv" in sys.argv:
