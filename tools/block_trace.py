@@ -27,6 +27,7 @@ def main(path, limit=None):
         print(f"== {d['kernel']} P={d['P']} flags={d['flags']:#x} grid={d['grid']} colour tiles={ct} threads={d['threads']}: "
               f"first start -> last end {span:.1f} us")
         for role, blocks in (("colour", B[:ct]), ("geometry", B[ct:])):
+            blocks = [b for b in blocks if b[0]]      # work-list workgroups of a launch leave no record
             if not blocks:
                 continue
             cus = Counter(cu_of(b[2]) for b in blocks)
@@ -43,7 +44,7 @@ def main(path, limit=None):
                 by_n[cus[cu_of(b[2])]].append((b[1] - b[0]) / 100.0)
             print("            duration by workgroups sharing the CU: " +
                   ", ".join(f"{k}: med {st.median(v):.1f} max {max(v):.1f} us (n={len(v)})" for k, v in sorted(by_n.items())))
-        xcc = Counter(cu_of(b[2])[0] for b in B)
+        xcc = Counter(cu_of(b[2])[0] for b in B if b[0])
         print(f"  workgroups per XCC: {dict(sorted(xcc.items()))}")
         if limit and n + 1 >= limit:
             break
