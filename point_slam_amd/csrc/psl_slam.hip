@@ -783,7 +783,10 @@ static RayBufs carve_rays(float*& p, int n) {
   b.g_depth = take(n); b.g_rgb = take(3 * (size_t)n); b.g_o = take(3 * (size_t)n); b.g_d = take(3 * (size_t)n);
   return b;
 }
-static int64_t rays_floats(int n) { float* p = nullptr; (void)carve_rays(p, n); return (int64_t)(p - (float*)nullptr); }
+static int64_t rays_floats(int n) {   // size of carve_rays' layout: carved from an aligned dummy base that is never dereferenced
+  float* const base = reinterpret_cast<float*>((uintptr_t)1 << 20);
+  float* p = base; (void)carve_rays(p, n); return (int64_t)(p - base);
+}
 
 extern "C" int64_t psl_track_ws_floats(int n_pix) {
   if (n_pix < 0) return PSL_ERR_ARG;
