@@ -1,0 +1,97 @@
+"""CPU: the measurement tools that turn rocprofv3 databases and PMC tables into the files under profiles/ -- run on small
+synthetic inputs with the schema this image's rocprofv3 writes (rocpd sqlite), so that a tool edit cannot silently break
+the artefacts the bench line reads (`roofline.traffic` comes from tools/pmc_traffic.py's output)."""
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(ROOT, "tools")
+
+FWD = "_ZN3psl13k_decode_fwd2ILb1EEEvNS_10DecodeArgsEPKfi.kd"
+BWD = "_ZN3psl13k_decode_bwd2ILb0ELb1EEEvNS_10DecodeArgsENS_7Bwd2OutEPKfiNS_7RayFuseENS_12AdamWorklistEi.kd"
+BWD_T = "_ZN3psl13k_decode_bwd2ILb1ELb1EEEvNS_10DecodeArgsENS_7Bwd2OutEPKfiNS_7RayFuseENS_12AdamWorklistEi.kd"
+DW = "_ZN3psl4k_dwENS_6DwArgsE.kd"
+
+
+def _trace_db(path):
+    db = sqlite3.connect(path)
+    db.execute("create table rocpd_info_kernel_symbol (id integer primary key, kernel_name text)")
+    db.execute("create table rocpd_kernel_dispatch (id integer primary key, kernel_id integer, start integer, end integer)")
+    for i, n in enumerate((FWD, BWD, BWD_T, DW)):
+        db.execute("insert into rocpd_info_kernel_symbol values (?, ?)", (i, n))
+    t = 1_000_000
+    for it in range(40):                     # fwd 48 us, hole 1 us, bwd 49 us, dW 26 us; every 10th iteration a 60-us host stall
+        for kid, dur in ((0, 48_000), (1, 49_000), (3, 26_000)):
+            db.execute("insert into rocpd_kernel_dispatch (kernel_id, start, end) values (?, ?, ?)", (kid, t, t + dur))
+            t += dur + 1_000
+        if it % 10 == 9:
+            t += 60_000
+    db.execute("insert into rocpd_kernel_dispatch (kernel_id, start, end) values (2, ?, ?)", (t, t + 25_000))
+    db.commit(); db.close()
+
+
+def _run(tool, *args):
+    p = subprocess.run([sys.executable, os.path.join(TOOLS, tool), *args], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+def test_rocpd_stats_keeps_the_backward_instantiations_apart(tmp_path):
+    db = str(tmp_path / "t_results.db")
+    _trace_db(db)
+    out = _run("rocpd_stats.py", db, "--csv", str(tmp_path / "s.csv"))
+    rows = {l.split(",")[0]: l.split(",") for l in out.splitlines()[1:]}
+    assert len(rows) == 4                    # mapper and tracker backward are two rows (60-char names used to merge them)
+    fwd = next(v for k, v in rows.items() if "k_decode_fwd2ILb1E" in k)
+    assert int(fwd[1]) == 40 and abs(float(fwd[3]) - 48.0) < 1e-6
+    bwd_t = next(v for k, v in rows.items() if "bwd2ILb1ELb1E" in k)
+    assert int(bwd_t[1]) == 1
+    assert open(tmp_path / "s.csv").read().strip() == out.strip()
+
+
+def test_rocpd_timeline_and_gaps(tmp_path):
+    db = str(tmp_path / "t_results.db")
+    _trace_db(db)
+    out = _run("rocpd_timeline.py", db, "1.0")
+    head = out.splitlines()[0]
+    busy = float(head.split("busy")[1].split("ms")[0])
+    assert abs(busy - 40 * (48 + 49 + 26) / 1e3) < 0.2           # window = span of the k_dw launches
+    long_holes = [l for l in out.splitlines() if l.strip().startswith("holes") and "20.." in l][0]
+    assert int(long_holes.split(":")[1].split("holes")[0]) == 3  # the host stalls inside the window (the fourth ends it)
+    assert "k_decode_fwd2" in out.split("long holes")[1]         # ... are charged to the kernel that follows them
+    gaps = _run("rocpd_gaps.py", db)
+    assert "kernels 121" in gaps.splitlines()[0]
+
+
+def test_pmc_traffic_classes_and_fetch_correction(tmp_path):
+    def table(counter, rows):
+        p = tmp_path / f"{counter}.csv"
+        p.write_text("# x\nkernel,counter,dispatches,mean,sum\n" +
+                     "".join(f"{n}@{g},{counter},{k},{m},{m * k}\n" for n, g, k, m in rows))
+        return str(p)
+    f = table("FETCH_SIZE", [(FWD, 320512, 2, 9000.0), (FWD, 64512, 2, 3500.0), (BWD, 320512, 2, 28000.0), (DW, 64768, 2, 50000.0),
+                             ("_ZN3psl10k_geo_iterENS_10DecodeArgsE.kd", 41344, 2, 6000.0)])
+    w = table("WRITE_SIZE", [(FWD, 320512, 2, 65000.0), (FWD, 64512, 2, 9000.0), (BWD, 320512, 2, 58000.0), (DW, 64768, 2, 12000.0),
+                             ("_ZN3psl10k_geo_iterENS_10DecodeArgsE.kd", 41344, 2, 3800.0)])
+    out = str(tmp_path / "traffic.json")
+    _run("pmc_traffic.py", f, w, out, "abc1234")
+    d = json.load(open(out))
+    assert d["_meta"]["commit"] == "abc1234"
+    assert set(d) >= {"decode_fwd", "decode_fwd_track", "decode_bwd", "dw_gemm", "geo_iter"}
+    # FETCH_SIZE (KiB) doubled for the 16-B/lane streams, WRITE_SIZE as reported (MI355X_MICROARCH.md)
+    assert d["decode_fwd"]["read_bytes"] == round(9000.0 * 1024 * 2) and d["decode_fwd"]["write_bytes"] == round(65000.0 * 1024)
+    assert d["decode_fwd_track"]["read_bytes"] == round(3500.0 * 1024 * 2)       # the tracker's launches are a class of their own
+    assert d["decode_bwd"]["bytes_per_launch"] == round(28000.0 * 1024 * 2 + 58000.0 * 1024)
+
+
+def test_block_trace_skips_untraced_workgroups(tmp_path):
+    rec = {"kernel": "bwd2", "P": 32, "flags": 0, "grid": 6, "color_tiles": 2, "threads": 512,
+           "blocks": [[100, 3000, 0x1000, 7000], [120, 3100, 0x2100, 7100], [110, 500, 0x1200, 900], [115, 520, 0x3300, 950],
+                      [0, 0, 0, 0], [0, 0, 0, 0]]}
+    p = tmp_path / "b.jsonl"
+    p.write_text(json.dumps(rec) + "\n")
+    out = _run("block_trace.py", str(p))
+    assert "first start -> last end 30.0 us" in out and "colour  : 2 workgroups" in out and "geometry: 2 workgroups" in out
