@@ -21,16 +21,15 @@ struct DecodeArgs {
   unsigned long long* blk;   // optional per-workgroup trace [grid][4]: wall start, wall end, hw id, shader cycles (PSL_DEBUG_BLOCKS=<file>)
 };
 // per-workgroup trace: where the workgroups of a launch ran (XCC / SE / CU), when they started and how long they took
-struct BlkTrace {
-  unsigned long long w0, c0; bool on;
-  __device__ __forceinline__ BlkTrace(const DecodeArgs& a) : w0(0), c0(0), on(a.blk != nullptr && threadIdx.x == 0) {
-    if (on) { w0 = wall_clock64(); c0 = clock64(); }
+struct BlkTrace {     // the start stamps go straight to memory: nothing is carried in registers across the kernel
+  __device__ __forceinline__ BlkTrace(const DecodeArgs& a) {
+    if (a.blk != nullptr && threadIdx.x == 0) { unsigned long long* o = a.blk + 4 * (size_t)blockIdx.x; o[0] = wall_clock64(); o[3] = clock64(); }
   }
   __device__ __forceinline__ void done(const DecodeArgs& a) {
-    if (!on) return;
+    if (a.blk == nullptr || threadIdx.x != 0) return;
     unsigned long long* o = a.blk + 4 * (size_t)blockIdx.x;
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    o[0] = w0; o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - c0;
+    o[1] = wall_clock64(); o[2] = ((unsigned long long)xcc << 32) | hw; o[3] = clock64() - o[3];
   }
 };
 // ---- the mapper's ray stage inside the colour-stage decode backward (psl_map_iters without per-frame exposure) --------

@@ -47,18 +47,15 @@ constexpr int LD_X2 = 22;   // rel-pos part of F_theta's dX1, per wave [16][20]
 // linear1^T (32), contiguous at the start of the backward fragment buffer.
 constexpr int kNbrFragsB = 48;
 static_assert(bfirst(BL_N2) == 0 && bfirst(BL_N1) == 16 && bfirst(BL_C1) == kNbrFragsB, "F_theta fragments lead the backward buffer");
-template <int NT>
-struct NbrStageB {
-  f32x4 v[kNbrFragsB * FRAG / 4 / NT];
-  __device__ __forceinline__ void load(const float* __restrict__ W) {
+// LDS-DMA copy (glds16, psl_device.h), 1 KiB per wave-instruction.  Wave 2 issues the global stores / atomics of the d(logits)
+// set-up (ray outputs, loss slots) before the first barrier and would have to drain them with the copy, so the six waves
+// 0, 1, 3..6 carry eight fragments each.
+__device__ __forceinline__ void nbr_stage_dma_b(const float* __restrict__ W, float* sW, int wave, int lane) {
+  if (wave == 2 || wave == 7) return;
+  const int slot = wave < 2 ? wave : wave - 1;
 #pragma unroll
-    for (int j = 0; j < kNbrFragsB * FRAG / 4 / NT; ++j) v[j] = *reinterpret_cast<const f32x4*>(W + ((size_t)j * NT + threadIdx.x) * 4);
-  }
-  __device__ __forceinline__ void store(float* sW) const {
-#pragma unroll
-    for (int j = 0; j < kNbrFragsB * FRAG / 4 / NT; ++j) *reinterpret_cast<f32x4*>(sW + ((size_t)j * NT + threadIdx.x) * 4) = v[j];
-  }
-};
+  for (int j = 0; j < kNbrFragsB / 6; ++j) glds16(W + ((size_t)(j * 6 + slot) * 64 + lane) * 4, sW + (j * 6 + slot) * FRAG);
+}
 __device__ __forceinline__ f32x4 ldsfragb(const float* sW, int frag, int lane) {
   return *reinterpret_cast<const f32x4*>(sW + frag * FRAG + lane * 4);
 }
@@ -226,6 +223,177 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
   }
 }
 
+// ------------------------------------------------------------------------------------------------ geometry role, pose gradient
+// The tracker's instantiation of the geometry role (d/d(sample position): through the 93 Fourier features of layers 0 and 3
+// and through the interpolation weights, decoder.py:143-160,175-222).  Round 3 ran it through geo_tile_bwd<true>: 188 VGPRs,
+// which put the whole colour-stage kernel at 189 -> ONE 512-thread workgroup per CU.  Same products, same order of every
+// sum, but written for a 128-register budget (two colour tiles per CU):
+//  * the neighbour lists / weights are loaded AFTER the layer chain (they are only needed by the epilogue);
+//  * the 12 embedding fragments of a layer are walked one input tile at a time, the next tile's pair in flight (the
+//    compiler otherwise hoists all twelve loads: 48 registers);
+//  * the Fourier epilogue consumes dE before the interpolation-weight epilogue builds its per-neighbour arrays.
+__device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0,
+                                                  ScatterLds& sl) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  const int p = min(p0 + rl, a.P - 1);
+  const bool live = p0 + rl < a.P;
+  const float* __restrict__ M = a.master;
+  const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
+  const bool has = live && a.ws.cnt[p] >= a.min_nn;
+  const float docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  // G = d_occ * w_out (output_linear.weight [1][32]), channel 16 nt + 4 g + r
+  f32x4 G[2], dcg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[nt][r] = docc * M[MO(PI_G_OUT) + nt * 16 + 4 * g + r];
+  f32x4 dE[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dE[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    constexpr int BLs[5] = {BL_G0, BL_G1, BL_G2, BL_G3, BL_G4};
+    constexpr int BLf[5] = {BL_GF0, BL_GF1, BL_GF2, BL_GF3, BL_GF4};
+    sched_fence_b();
+    const int ff = bfirst(BLf[i]), fb = bfirst(BLs[i]);
+    f32x4 wc[4], wh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wc[j] = ldfragb(WB, ff + j, lane);            // fragment (it, q) at ff + 2 it + q
+    if (i > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wh[j] = ldfragb(WB, fb + j, lane);          // hidden tiles come first
+    }
+    f32x4 dz[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(a.ws.g_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HG + nt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz[nt][r] = (y[r] > 0.f) ? G[nt][r] : 0.f;      // ReLU
+    }
+    sched_fence_b();
+    // dL/dc += Wc_i^T G   (fc_c.i.weight [32][32]); same accumulation order as geo_tile_bwd: q outer, it inner
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) mma4b(dcg[it], wc[it * 2 + q], G[q]);
+    // dL/d(input of layer i) = W_i^T dz
+    if (i > 0) {
+      f32x4 Gn[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) mma4b(Gn[it], wh[it * 2 + q], dz[q]);
+      G[0] = Gn[0]; G[1] = Gn[1];
+    }
+    if (i == 3 || i == 0) {
+      // embedding part of the skip layer (input tiles 2..7) / of layer 0 (tiles 0..5): dE[it] += W^T[tile it] dz, q = 0 then 1
+      const int e0 = fb + (i == 3 ? 4 : 0);
+      f32x4 wa = ldfragb(WB, e0, lane), wb2 = ldfragb(WB, e0 + 1, lane);
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        sched_fence_b();
+        const f32x4 c0 = wa, c1 = wb2;
+        if (it < 5) { wa = ldfragb(WB, e0 + (it + 1) * 2, lane); wb2 = ldfragb(WB, e0 + (it + 1) * 2 + 1, lane); }
+        mma4b(dE[it], c0, dz[0]);
+        mma4b(dE[it], c1, dz[1]);
+      }
+    }
+  }
+  sched_fence_b();
+  // lane-derived indices again from an opaque copy of the lane id (left to CSE, hipcc carries the sign-extended sample
+  // index and 4 g across the chain and spills them)
+  int l2 = threadIdx.x;
+  asm volatile("" : "+v"(l2));
+  const int rl2 = l2 & 15, g2 = (l2 >> 4) & 3;
+  const int p2 = min(p0 + rl2, a.P - 1);
+  const SampleGeom sg = sample_geom(a, p2);
+  // ---- (2) Fourier embedding sin(2 pi p . B) (93 frequencies), this lane's 24 channels: consumes dE
+  float px, py, pz;
+  {
+    const float* __restrict__ Bg = M + MO(PI_G_B);
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      sched_fence_b();      // four channels (12 loads of B, four cosines) at a time: unfenced, all 72 loads are hoisted
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = 16 * q + 4 * g2 + r;
+        if (f < EG) {
+          const float dy2 = TWO_PI * dE[q][r] * fast_cosf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
+          ax += dy2 * Bg[f]; ay += dy2 * Bg[EG + f]; az += dy2 * Bg[2 * EG + f];
+        }
+      }
+    }
+    ax += __shfl_xor(ax, 16); ax += __shfl_xor(ax, 32);
+    ay += __shfl_xor(ay, 16); ay += __shfl_xor(ay, 32);
+    az += __shfl_xor(az, 16); az += __shfl_xor(az, 32);
+    px = ax; py = ay; pz = az;
+  }
+  sched_fence_b();
+  // ---- neighbour lists and weights (saved by the forward)
+  int nb[K];
+  {
+    const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p2 * K);
+    const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p2 * K + 4);
+    nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
+  }
+  float w[K];
+  {
+    const float4 w0 = *reinterpret_cast<const float4*>(a.ws.w + (size_t)p2 * K), w1 = *reinterpret_cast<const float4*>(a.ws.w + (size_t)p2 * K + 4);
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w; w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+  }
+  if (featg) {
+    int dst[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = nb[k];
+      dst[k] = (i >= 0 && has && w[k] != 0.f) ? (o.row_map ? o.row_map[i] : i) : -1;
+    }
+    scatter_interp_rows(sl, o.g_geo, o.t_geo, dcg, w, dst);
+  }
+  // ---- (1) interpolation weights: w = a/S, a = [D<=r2]/(D+1e-10), D = |x_k - p|^2   (decoder.py:143-160)
+  float gw[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    gw[k] = 0.f;
+    const int i = nb[k];
+    if (i >= 0 && has) {
+      const float* frow = a.geo_feats + (size_t)i * C + 4 * g2;
+      const f32x4 f0 = *reinterpret_cast<const f32x4*>(frow), f1 = *reinterpret_cast<const f32x4*>(frow + 16);
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v += f0[r] * dcg[0][r] + f1[r] * dcg[1][r];
+      gw[k] = v;
+    }
+  }
+  sched_fence_b();
+  {
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float av[K], rx[K], ry[K], rz[K];
+    float S1 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      gw[k] += __shfl_xor(gw[k], 16); gw[k] += __shfl_xor(gw[k], 32);       // over the four channel groups
+      const float4 q = a.pos[max(nb[k], 0)];
+      rx[k] = (nb[k] >= 0) ? __fsub_rn(q.x, sg.x) : 0.f; ry[k] = (nb[k] >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
+      rz[k] = (nb[k] >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
+      const float D = (nb[k] >= 0) ? __fadd_rn(__fadd_rn(__fmul_rn(rx[k], rx[k]), __fmul_rn(ry[k], ry[k])), __fmul_rn(rz[k], rz[k]))
+                                   : __int_as_float(0x7F800000);
+      av[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+      S1 += av[k];
+      gw[k] = has ? gw[k] : 0.f;
+      dot += gw[k] * w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float da = (gw[k] - dot) / fmaxf(S1, 1e-12f);
+      const float dD = -da * av[k] * av[k];
+      qx += -2.f * dD * rx[k]; qy += -2.f * dD * ry[k]; qz += -2.f * dD * rz[k];
+    }
+    if (g2 == 0 && live) reinterpret_cast<float4*>(a.ws.dp2)[p2] = make_float4(qx + px, qy + py, qz + pz, 0.f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ colour role
 template <bool PTSG>
 __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0,
@@ -255,8 +423,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 
   PSL_STAMP(0);
   const float* sWn = smem + L::oWn;
-  NbrStageB<WG> stage;
-  if (relpos) stage.load(WB);      // F_theta's backward weights -> LDS; the loads fly during phase 0
+  if (relpos) nbr_stage_dma_b(WB, smem + L::oWn, wave, lane);      // F_theta's backward weights -> LDS; the loads fly during phase 0
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -320,7 +487,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   } else if (PTSG && t < TILE * K + TILE + 32 + 64) {
     sDP[t - TILE * K - TILE - 32] = 0.f;
   }
-  if (relpos) stage.store(smem + L::oWn);
+  if (relpos && wave != 2 && wave != 7) wait_dma();     // phases of waves 0, 1, 3..6 issue no global store before this point
   lds_barrier();
   PSL_STAMP(1);
 
@@ -673,7 +840,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 // (psl_map_iters, colour stage without exposure: rf.on -- the ray stage runs inside this kernel, and the workgroups from
 //  wl_block0 on build the work list of the iteration's lazy Adam, which the ray kernel used to carry)
 template <bool PTSG, bool COLOR>
-__global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
+__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
                                                                                             RayFuse rf, AdamWorklist wl, int wl_block0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x >= wl_block0) {
@@ -685,7 +852,8 @@ __global__ __launch_bounds__(COLOR ? WG : 64, (COLOR && !PTSG) ? 4 : 2) void k_d
     color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE, rf);
   } else {
     if (threadIdx.x >= 64) return;
-    geo_tile_bwd<PTSG>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
+    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem));
+    else geo_tile_bwd<false>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
   }
   bt.done(a);
 }

@@ -38,26 +38,24 @@ struct Fwd2Lds {
 // once per workgroup -- all loads of the copy in flight together, ONE L2 round trip -- and read from there (ds_read_b128,
 // ~100 cycles) by every step.
 static_assert(ffirst(FL_N1) == 0 && ffirst(FL_N2) == 32 && ffirst(FL_C0) == kNbrFrags, "F_theta fragments lead the forward buffer");
-template <int NT>
-struct NbrStage {      // the copy in two halves, so that its global loads fly during the set-up phase of the kernel
-  f32x4 v[kNbrFrags * FRAG / 4 / NT];
-  __device__ __forceinline__ void load(const float* __restrict__ W) {
+// The copy is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane l -> base + 16 l, which IS the fragment
+// layout): no staging registers (round 3 bounced 24 VGPRs per thread through NbrStage::load/store and spilled 19), no
+// ds_write pass.  hipcc does not count these loads: the issuing wave waits vmcnt(0) itself before the barrier that
+// publishes the fragments (lds_barrier_dma), so no global STORE may be issued before that barrier.
+template <int NFRAG>
+__device__ __forceinline__ void nbr_stage_dma(const float* __restrict__ W, float* sW, int slot, int nslots, int lane) {
 #pragma unroll
-    for (int j = 0; j < kNbrFrags * FRAG / 4 / NT; ++j) v[j] = *reinterpret_cast<const f32x4*>(W + ((size_t)j * NT + threadIdx.x) * 4);
-  }
-  __device__ __forceinline__ void store(float* sW) const {
-#pragma unroll
-    for (int j = 0; j < kNbrFrags * FRAG / 4 / NT; ++j) *reinterpret_cast<f32x4*>(sW + ((size_t)j * NT + threadIdx.x) * 4) = v[j];
-  }
-};
+  for (int j = 0; j < NFRAG / nslots; ++j) glds16(W + ((size_t)(j * nslots + slot) * 64 + lane) * 4, sW + (j * nslots + slot) * FRAG);
+}
 __device__ __forceinline__ f32x4 ldsfrag(const float* sW, int frag, int lane) {
   return *reinterpret_cast<const f32x4*>(sW + frag * FRAG + lane * 4);
 }
 
 // ------------------------------------------------------------------------------------------------ geometry role
 // One wavefront, 16 samples: lane (rl = sample, g).  Writes raw[p].w (and xyz = 0 when `full_raw`), g_y, w (when asked).
-// GEO_AHEAD: prefetch distance in steps (4 in the stage-'geometry' kernel, which may use 256 registers; 2 inside the
-// colour-stage kernel, whose 128-register budget is set by the colour role).
+// GEO_AHEAD: prefetch distance in steps (4 in the stage-'geometry' kernel; 3 inside the colour-stage kernel, whose
+// 128-register budget is set by the colour role's two workgroups per CU -- 122 registers, no spill; at distance 4 three
+// registers go to scratch).
 template <int GEO_AHEAD>
 __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __restrict__ WF, int p0, bool full_raw, bool save_w) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
@@ -74,6 +72,7 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
     const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K + 4);
     nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
   }
+  const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150); loaded with the lists, kept as a lane mask
   float w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -90,7 +89,6 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
     *reinterpret_cast<float4*>(a.ws.w + (size_t)(p0 + rl) * K) = make_float4(w[0], w[1], w[2], w[3]);
     *reinterpret_cast<float4*>(a.ws.w + (size_t)(p0 + rl) * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
   }
-  const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150)
   PSL_STAMP(33);
   f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -109,6 +107,7 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
   }
+  pin(cg[0]); pin(cg[1]);
   sched_fence();
   PSL_STAMP(34);
   // weight fragments of the first steps: their L2 latency elapses behind the 24 sine evaluations
@@ -122,13 +121,17 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
   const float* __restrict__ Bg = M + MO(PI_G_B);
   f32x4 eg[6];
 #pragma unroll
-  for (int q = 0; q < 6; ++q)
+  for (int q = 0; q < 6; ++q) {
+    // under the colour-stage kernel's 128-register budget: two groups of four channels (their 24 entries of B) at a time;
+    // the stage-'geometry' kernel leaves all 72 loads and 24 polynomials to the scheduler
+    if (GEO_AHEAD < 4 && (q & 1) == 0) sched_fence();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = min(16 * q + 4 * g + r, EG - 1);
       const float v = fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
       eg[q][r] = (16 * q + 4 * g + r < EG) ? v : 0.f;
     }
+  }
   PSL_STAMP(35);
   // ---- five blocks: h = relu(W_i h + b_i) + (Wc_i c + bc_i); the embedding is re-attached after block 2
   f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -173,11 +176,18 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
   }
   PSL_STAMP(41);
   // ---- output_linear 32 -> 1 as one padded tile: row 0 of the accumulator = occupancy logit of sample rl
-  if (g == 0 && p0 + rl < a.P) {
-    // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
-    const float occ = has ? (oo[0][0] + oo[1][0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
-    if (full_raw) reinterpret_cast<float4*>(a.ws.raw)[p] = make_float4(0.f, 0.f, 0.f, occ);
-    else a.ws.raw[(size_t)p * 4 + 3] = occ;
+  {
+    // the sample index again from an opaque copy of the lane id: left to CSE, hipcc carries the sign-extended index of the
+    // first lines across the whole tile (and spills it under the colour-stage kernel's 128-register budget)
+    int l2 = threadIdx.x;
+    asm volatile("" : "+v"(l2));
+    const int pe = p0 + (l2 & 15);
+    if ((l2 & 48) == 0 && pe < a.P) {
+      // raw[~point_mask, -1] = -100 (Renderer.py:189-190)
+      const float occ = has ? (oo[0][0] + oo[1][0]) + M[MO(PI_G_OUT + 1)] : -100.0f;
+      if (full_raw) reinterpret_cast<float4*>(a.ws.raw)[pe] = make_float4(0.f, 0.f, 0.f, occ);
+      else a.ws.raw[(size_t)pe * 4 + 3] = occ;
+    }
   }
 }
 
@@ -219,9 +229,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   // F_theta's weight fragments do not depend on anything: their copy into LDS is requested before the neighbour set-up
   constexpr int f1 = ffirst(FL_N1);
   const float* sWn = smem + L::oWn;
-  {
-    NbrStage<WG> stage;
-    if (relpos) stage.load(WF);
+  if (relpos) nbr_stage_dma<kNbrFrags>(WF, smem + L::oWn, wave, WG / 64, lane);
 
   // ---------------------------------------------------------------- phase 0: neighbours, weights (one thread per pair)
   if (t < TILE * K) {
@@ -239,16 +247,14 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f;
     sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
     sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
-    a.ws.w[(size_t)(p0 + s) * K + k] = w;
     if (k == 0) {
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
       sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
     }
   }
-    if (relpos) stage.store(smem + L::oWn);
-  }
-  lds_barrier();
+  lds_barrier_dma();
   PSL_STAMP(1);
+  if (t < TILE * K) a.ws.w[(size_t)p0 * K + t] = sW[t];     // saved for the backward; after the barrier (see nbr_stage_dma)
   f32x4 afn[4];
   if (relpos) {
 #pragma unroll
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(
   } else {
     if (threadIdx.x >= 64) return;
     const int p0 = ((int)blockIdx.x - color_tiles) * TILE;
-    geo_tile<COLOR ? 2 : 4>(a, WF, p0, !COLOR, !COLOR);
+    geo_tile<COLOR ? 3 : 4>(a, WF, p0, !COLOR, !COLOR);
   }
   bt.done(a);
 }

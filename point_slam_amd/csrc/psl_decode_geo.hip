@@ -77,6 +77,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
   }
+  pin(cg[0]); pin(cg[1]);      // see psl_device.h: the interpolation must not be sunk behind the sine phase
   sched_fence();
   PSL_STAMP(2);
 #pragma unroll

@@ -65,11 +65,14 @@ __device__ __forceinline__ float softplus100_grad_from_out(float y) {
 // these per 16-sample tile.
 __device__ __forceinline__ void fast_sincosf(float x, float& sn, float& cs) {
   // huge or non-finite arguments (never produced by the Fourier phases of a room-scale scene): one double-precision
-  // reduction by 2 pi first -- a dozen instructions instead of the library's Payne-Hanek path, which inlined at every
-  // call site made the unrolled kernels several times larger than the instruction cache; NaN / inf come out as NaN
-  if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) {
+  // reduction by 2 pi first; NaN / inf come out as NaN.  Evaluated unconditionally and SELECTED (five full-rate fp64
+  // instructions): as a branch -- rounds 2-3 -- every call site became its own basic block, the 24 sines of a geometry tile
+  // turned into 24 serial [load three B entries, wait, test, branch] steps (one cache round trip each, nothing overlapped),
+  // and the scheduler could not interleave the polynomials with anything.
+  {
     const double xd = (double)x;
-    x = (float)fma(-rint(xd * 0.15915494309189535), 6.283185307179586, xd);
+    const float xr = (float)fma(-rint(xd * 0.15915494309189535), 6.283185307179586, xd);
+    x = (fabsf(x) < 1.0e5f) ? x : xr;
   }
   const float j = rintf(__fmul_rn(x, 0.636619772f));
   float r = fmaf(j, -1.57079601e+00f, x);
@@ -102,6 +105,23 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+
+// LDS-DMA: 16 bytes per lane from global memory straight into LDS at (wave-uniform base) + 16 * lane; no VGPR in between.
+// The compiler does not wait for these loads before later LDS reads (checked on the ROCm 7.2 hipcc: no vmcnt in front of
+// the ds_read): the issuing wave drains them itself with lds_barrier_dma() / wait_dma().
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier_dma() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// forces a value to exist at this point of the program: without it the machine-sink pass moves the arithmetic that produces
+// it into a later basic block (next to its first use), away from the loads that feed it, and the loads' registers stay live
+// (or are spilled) across everything in between
+__device__ __forceinline__ void pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 
 // orders one wave's own LDS writes before its later LDS reads (wave-private scratch needs no workgroup barrier)
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
