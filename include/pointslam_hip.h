@@ -353,13 +353,31 @@ int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_d, const fl
  *                        32 geometry + 32 colour features + add-radius = 68 floats; touched feature rows: row id + 64
  *                        changes) in rank order into rec_all [sum][rec_floats]; counts_host[world] receives the per-rank row
  *                        counts.  nccl_comm: an ncclComm_t the host already owns (then `world` is its size), or NULL for
- *                        the ctx's communicator.  Two ncclAllGather on `stream` (counts, padded records); synchronises
- *                        `stream` once to learn the counts.  Returns the total number of rows (>= 0) or a psl_status. */
+ *                        the ctx's communicator.  Two ncclAllGather on `stream` ((rows, capacity) pairs, padded records);
+ *                        synchronises `stream` once to learn the counts.  Returns the total number of rows (>= 0) or a
+ *                        psl_status.  PSL_ERR_CAPACITY is decided on the gathered pairs (total > the SMALLEST capacity_rows of
+ *                        any rank), i.e. by every rank alike and before the records collective: all ranks may grow their
+ *                        buffers from counts_host (valid on that return) and call again. */
 int psl_comm_unique_id(void* id_out_128_bytes);
 int psl_comm_init(psl_ctx* ctx, const void* id_128_bytes, int rank, int world);
 int psl_comm_destroy(psl_ctx* ctx);
 int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world, const float* rec_local, int n_local, int rec_floats,
                              float* rec_all, int capacity_rows, int32_t* counts_host, void* stream);
+/* the counts-phase decision of psl_allgather_new_points by itself (host only, no GPU): pairs[world][2] = (rows, capacity) as
+ * gathered; fills counts_out[world], *total_out, *n_max_out; PSL_ERR_CAPACITY iff total > min capacity. */
+int psl_allgather_decide(const int32_t* pairs, int world, int32_t* counts_out, long long* total_out, int* n_max_out);
+
+/* ---- unit harness of the fast-math device helpers (tests only; no reference counterpart: the reference calls torch's
+ * sin/cos (decoder.py:33-36), nn.Softplus(beta=100) (decoder.py:124,231,335) and torch.optim.Adam, this library evaluates
+ * them with hardware transcendentals).  kind: see psl_selftest_kind; in/out device arrays:
+ *   SINCOS        in [n] angles            -> out [n][2] (sin, cos) of fast_sincosf
+ *   SOFTPLUS(_NB) in [n]                   -> out [n]   softplus100 / its branch-free twin
+ *   SOFTPLUS_GRAD in [n] softplus OUTPUTS  -> out [n]   d softplus / d input expressed through the output
+ *   ADAM_REPLAY   in [n][6] (p, m, v, lr/bc1, sqrt(bc2), steps) -> out [n][6]: (p, m, v) after `steps` gradient-free steps
+ *                 with the lazy Adam's replay arithmetic, then the same with the dense kernel's IEEE sequence */
+typedef enum { PSL_SELFTEST_SINCOS = 0, PSL_SELFTEST_SOFTPLUS = 1, PSL_SELFTEST_SOFTPLUS_NB = 2, PSL_SELFTEST_SOFTPLUS_GRAD = 3,
+               PSL_SELFTEST_ADAM_REPLAY = 4 } psl_selftest_kind;
+int psl_selftest_math(int kind, const float* in, float* out, int n, void* stream);
 
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);

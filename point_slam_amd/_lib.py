@@ -9,16 +9,18 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpointslam_hip.so")
+# PSL_LIB=<path>: load another build of the same ABI (A/B measurements of two builds on ONE box, tools/gpu_round.sh)
+LIB_PATH = os.environ.get("PSL_LIB") or os.path.join(_HERE, "libpointslam_hip.so")
 
 
 class PslError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
+ABI_VERSION = 5     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
 #                     full-image pixel indices in psl_track_args, step0_params in psl_map_args; v4: psl_dedupe_count / psl_dedupe_blocks,
-#                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields
+#                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields;
+#                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math
 EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 
 
@@ -112,6 +114,8 @@ _SIGS = {
     "psl_comm_destroy": (C.c_int, [C.c_void_p]),
     "psl_allgather_new_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                            C.POINTER(C.c_int32), C.c_void_p]),
+    "psl_allgather_decide": (C.c_int, [C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "psl_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "psl_frame_radii": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "psl_topgrad_select_sync": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -161,7 +165,12 @@ def lib():
                            "(there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(L, name)   # AttributeError if the symbol is missing
+            try:
+                fn = getattr(L, name)   # AttributeError if the symbol is missing
+            except AttributeError:
+                if os.environ.get("PSL_LIB"):     # an older build loaded for an A/B run: newer entry points are absent
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include "psl_decode.h"
+#include "psl_adam.h"
 #include "psl_frag.h"
 
 namespace psl {
@@ -183,7 +184,7 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
 using namespace psl;
 
 extern "C" const char* psl_last_error(void) { return g_err; }
-extern "C" int psl_abi_version(void) { return 4; }
+extern "C" int psl_abi_version(void) { return 5; }
 
 extern "C" int psl_param_count(void) { return kNumParams; }
 extern "C" int psl_param_color_count(void) { return kNumColorParams; }
@@ -445,4 +446,44 @@ extern "C" int psl_profile_read(psl_ctx* ctx, double* ms_out, int* count_out, do
     work_out[cls] += 20.0 * C * (double)rows;
   }
   return n;
+}
+
+// ---------------------------------------------------------------------------------------------- fast-math unit harness
+// The hot kernels replace libm / IEEE sequences by hardware transcendentals (psl_device.h, psl_adam.h).  They are bounded
+// end to end by the parity tests; this entry point lets tests/test_hip_fastmath.py pin each helper BY ITSELF against its
+// exact counterpart (torch in float64), so that the next person to touch one has a unit bound to keep.
+namespace psl {
+__global__ void k_selftest_math(int kind, const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (kind) {
+    case PSL_SELFTEST_SINCOS: { float s, c; fast_sincosf(in[i], s, c); out[2 * i] = s; out[2 * i + 1] = c; break; }
+    case PSL_SELFTEST_SOFTPLUS: out[i] = softplus100(in[i]); break;
+    case PSL_SELFTEST_SOFTPLUS_NB: out[i] = softplus100_nb(in[i]); break;
+    case PSL_SELFTEST_SOFTPLUS_GRAD: out[i] = softplus100_grad_from_out(in[i]); break;
+    case PSL_SELFTEST_ADAM_REPLAY: {
+      // in[i] = (p, m, v, lr_bc1, sqrt_bc2, n_steps): n_steps gradient-free steps, once with the replay arithmetic of the
+      // lazy Adam and once with the dense kernel's IEEE sequence (g = 0); out[i] = (p, m, v)_replay, (p, m, v)_ieee
+      const float* a = in + 6 * (size_t)i;
+      float p = a[0], m = a[1], v = a[2], p2 = a[0], m2 = a[1], v2 = a[2];
+      const int steps = (int)a[5];
+      for (int t = 0; t < steps; ++t) {
+        adam_replay(p, m, v, a[3], __builtin_amdgcn_rcpf(a[4]), 0.9f, 0.999f, 1e-8f);
+        adam_update(p2, 0.f, m2, v2, a[3], a[4], 0.9f, 0.999f, 1e-8f);
+      }
+      float* o = out + 6 * (size_t)i;
+      o[0] = p; o[1] = m; o[2] = v; o[3] = p2; o[4] = m2; o[5] = v2;
+      break;
+    }
+    default: break;
+  }
+}
+}  // namespace psl
+
+extern "C" int psl_selftest_math(int kind, const float* in, float* out, int n, void* stream) {
+  if (kind < 0 || kind > PSL_SELFTEST_ADAM_REPLAY || !in || !out || n < 0) { set_error("psl_selftest_math: bad argument"); return PSL_ERR_ARG; }
+  if (n == 0) return PSL_OK;
+  hipLaunchKernelGGL(psl::k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, kind, in, out, n);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
 }

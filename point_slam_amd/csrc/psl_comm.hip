@@ -24,6 +24,7 @@ struct Rccl {
 };
 static Rccl g_rccl;
 constexpr int kNcclInt32 = 2, kNcclFloat32 = 7;   // ncclDataType_t (rccl.h:459-466)
+constexpr int kMaxCommWorld = 1024;
 
 static int rccl_load() {
   if (g_rccl.lib) return PSL_OK;
@@ -53,7 +54,18 @@ static int rccl_load() {
     }                                                                                          \
   } while (0)
 
-__global__ void k_set_int(int* d, int v) { if (threadIdx.x == 0) *d = v; }
+__global__ void k_set_int2(int* d, int v0, int v1) { if (threadIdx.x == 0) { d[0] = v0; d[1] = v1; } }
+
+// device ints of the counts phase: [world][2] gathered (rows, capacity) pairs + this rank's own pair; sized for the LARGEST
+// world seen (a host-owned communicator passed to psl_allgather_new_points may be larger than the ctx's own)
+static int comm_counts_reserve(psl_ctx* ctx, int world) {
+  if (ctx->comm_counts && ctx->comm_counts_world >= world) return PSL_OK;
+  if (ctx->comm_counts) (void)hipFree(ctx->comm_counts);
+  ctx->comm_counts = nullptr; ctx->comm_counts_world = 0;
+  PSL_HIP(hipMalloc(&ctx->comm_counts, sizeof(int) * 2 * (size_t)(world + 1)));
+  ctx->comm_counts_world = world;
+  return PSL_OK;
+}
 
 }  // namespace psl
 
@@ -76,8 +88,9 @@ extern "C" int psl_comm_init(psl_ctx* ctx, const void* id_in, int rank, int worl
   RcclId id; memcpy(&id, id_in, sizeof(id));
   void* comm = nullptr;
   PSL_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  rc = comm_counts_reserve(ctx, world);
+  if (rc) { (void)g_rccl.CommDestroy(comm); return rc; }       // no communicator is left behind on a failed init
   ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
-  PSL_HIP(hipMalloc(&ctx->comm_counts, sizeof(int) * (size_t)(world + 1)));
   return PSL_OK;
 }
 
@@ -87,7 +100,25 @@ extern "C" int psl_comm_destroy(psl_ctx* ctx) {
   ctx->comm = nullptr;
   if (ctx->comm_counts) (void)hipFree(ctx->comm_counts);
   if (ctx->comm_stage) (void)hipFree(ctx->comm_stage);
-  ctx->comm_counts = nullptr; ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
+  ctx->comm_counts = nullptr; ctx->comm_counts_world = 0; ctx->comm_stage = nullptr; ctx->comm_stage_cap = 0;
+  return PSL_OK;
+}
+
+// The decision of the counts phase, on the gathered (rows, capacity) pairs alone -- nothing rank-local enters it, so every
+// rank of the communicator takes the same branch (tests/test_abi_cpu.py drives it with unequal capacities).
+extern "C" int psl_allgather_decide(const int32_t* pairs, int world, int32_t* counts_out, long long* total_out, int* n_max_out) {
+  if (!pairs || world < 1 || !counts_out || !total_out || !n_max_out) { set_error("psl_allgather_decide: bad argument"); return PSL_ERR_ARG; }
+  long long total = 0; int n_max = 0, cap_min = pairs[1];
+  for (int k = 0; k < world; ++k) {
+    if (pairs[2 * k] < 0) { set_error("psl_allgather_decide: rank %d announced %d rows", k, pairs[2 * k]); return PSL_ERR_ARG; }
+    counts_out[k] = pairs[2 * k];
+    total += pairs[2 * k]; n_max = std::max(n_max, pairs[2 * k]); cap_min = std::min(cap_min, pairs[2 * k + 1]);
+  }
+  *total_out = total; *n_max_out = n_max;
+  if (total > cap_min) {
+    set_error("psl_allgather_new_points: %lld rows exceed the smallest receive capacity of the ranks (%d)", total, cap_min);
+    return PSL_ERR_CAPACITY;
+  }
   return PSL_OK;
 }
 
@@ -101,17 +132,22 @@ extern "C" int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world
   if (!comm || world < 1) { set_error("psl_allgather_new_points: no communicator (psl_comm_init, or pass an ncclComm_t)"); return PSL_ERR_STATE; }
   int rc = rccl_load(); if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (!ctx->comm_counts) PSL_HIP(hipMalloc(&ctx->comm_counts, sizeof(int) * (size_t)(world + 1)));
-  // 1. counts: one int per rank
-  int* d_mine = ctx->comm_counts + world;
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(64), 0, s, d_mine, n_local);
+  if (world > kMaxCommWorld) { set_error("psl_allgather_new_points: world %d > %d", world, kMaxCommWorld); return PSL_ERR_ARG; }
+  rc = comm_counts_reserve(ctx, world); if (rc) return rc;
+  // 1. counts: every rank contributes (rows, capacity of ITS receive buffer).  The capacity decision below is taken on the
+  //    gathered pairs, i.e. on the same numbers on every rank: either every rank returns PSL_ERR_CAPACITY here, or every
+  //    rank enters the records collective.  (Round 3 compared the total with the LOCAL capacity: with unequal buffers one
+  //    rank retried the counts collective while the others had entered the records collective.)
+  int* d_mine = ctx->comm_counts + 2 * world;
+  hipLaunchKernelGGL(k_set_int2, dim3(1), dim3(64), 0, s, d_mine, n_local, capacity_rows);
   PSL_LAUNCH_CHECK();
-  PSL_NCCL(g_rccl.AllGather(d_mine, ctx->comm_counts, 1, kNcclInt32, comm, s));
-  PSL_HIP(hipMemcpyAsync(counts_host, ctx->comm_counts, sizeof(int) * (size_t)world, hipMemcpyDeviceToHost, s));
+  PSL_NCCL(g_rccl.AllGather(d_mine, ctx->comm_counts, 2, kNcclInt32, comm, s));
+  int pairs[2 * kMaxCommWorld];
+  PSL_HIP(hipMemcpyAsync(pairs, ctx->comm_counts, sizeof(int) * 2 * (size_t)world, hipMemcpyDeviceToHost, s));
   PSL_HIP(hipStreamSynchronize(s));
   long long total = 0; int n_max = 0;
-  for (int k = 0; k < world; ++k) { total += counts_host[k]; n_max = std::max(n_max, (int)counts_host[k]); }
-  if (total > capacity_rows) { set_error("psl_allgather_new_points: %lld rows exceed the capacity %d", total, capacity_rows); return PSL_ERR_CAPACITY; }
+  rc = psl_allgather_decide(pairs, world, counts_host, &total, &n_max);
+  if (rc) return rc;
   if (n_max == 0) return 0;
   if (total > 0 && !rec_all) { set_error("psl_allgather_new_points: rec_all missing"); return PSL_ERR_ARG; }
   // 2. records: ncclAllGather wants equal send counts -> every rank sends n_max rows out of a staging buffer (the padding

@@ -159,8 +159,8 @@ struct psl_ctx {
   unsigned long long* adam_rows = nullptr;                        // feature rows stepped by the lazy Adam since the last profile read
   unsigned long long* knn_cand = nullptr;   // [kKnnCandSlots * 8] candidates examined by the ray k-NN since the last psl_knn_candidates() read
   int* d_counter;
-  // multi-GPU exchange (psl_comm.hip): RCCL communicator (ncclComm_t), device counts [world + 1], staging buffer
-  void* comm = nullptr; int comm_rank = 0, comm_world = 0; int* comm_counts = nullptr; float* comm_stage = nullptr; size_t comm_stage_cap = 0;
+  // multi-GPU exchange (psl_comm.hip): RCCL communicator (ncclComm_t), device (rows, capacity) pairs [world + 1][2], staging buffer
+  void* comm = nullptr; int comm_rank = 0, comm_world = 0; int* comm_counts = nullptr; int comm_counts_world = 0; float* comm_stage = nullptr; size_t comm_stage_cap = 0;
   int* pre_I = nullptr;      // neighbour lists answered ahead of the render call (psl_map_iters block prefetch)
   int* pre_cnt = nullptr;
   unsigned* img_hist = nullptr;   // 65536-bin histogram + select state of psl_topgrad_select_sync

@@ -27,9 +27,11 @@ scales with the size of the map:
  4. COLOUR DECODER.  The same rule on the trainable colour-decoder blob (all-reduce of the per-rank changes, 109 k
     floats): features gathered from rank k were trained against rank k's decoder, so the decoders must not drift apart.
 
-Transport: torch.distributed collectives (the "nccl" backend IS RCCL on ROCm), or -- `transport="native"` /
-PSL_NATIVE_RCCL=1 -- `psl_allgather_new_points` inside libpointslam_hip.so on the library's own RCCL communicator
-(`psl_comm_init`; the 128-byte ncclUniqueId travels over torch.distributed once).
+Transport: on the "nccl" backend (= RCCL on ROCm; what a multi-GPU node runs) the all-gather-v's go through
+`psl_allgather_new_points` inside libpointslam_hip.so on the library's own RCCL communicator (`psl_comm_init`; the
+128-byte ncclUniqueId travels over torch.distributed once); on gloo (CPU tests, ranks sharing one GPU) through
+torch.distributed collectives.  `transport="native"|"torch"` / PSL_NATIVE_RCCL=1|0 force either.  Unmeasured on xGMI: no
+multi-GPU node has been available to any session so far.
 """
 from __future__ import annotations
 
@@ -96,7 +98,10 @@ class _NativeTransport:
         while True:
             rc = L.psl_allgather_new_points(self.npc.handle, None, 0, _lib.ptr(rec), rec.shape[0], width, _lib.ptr(self.buf),
                                             self.buf.shape[0], counts, _lib.stream_ptr())
-            if rc == -3:       # PSL_ERR_CAPACITY: the counts are known now; every rank grows and repeats the same sequence
+            if rc == -3:
+                # PSL_ERR_CAPACITY is decided on the gathered (rows, capacity) pairs -- total > the SMALLEST buffer of any
+                # rank -- so every rank is here together, before the records collective, with the same counts: all grow to
+                # the same size and repeat the same sequence (buffers of different size on different ranks are fine)
                 self.buf = torch.empty(2 * sum(counts) + 1024, width, device=dev, dtype=torch.float32)
                 continue
             total = _lib.check(rc, "psl_allgather_new_points")
@@ -104,7 +109,15 @@ class _NativeTransport:
 
 
 def make_transport(npc, group=None, kind: Optional[str] = None):
-    kind = kind or ("native" if os.environ.get("PSL_NATIVE_RCCL") == "1" else "torch")
+    """`kind` None: the library's own RCCL all-gather-v when the process group runs on the "nccl" (= RCCL) backend -- the path
+    a multi-GPU node takes --, torch.distributed collectives otherwise (gloo: CPU tests, ranks sharing one GPU).
+    PSL_NATIVE_RCCL=1 / 0 forces either."""
+    if kind is None:
+        env = os.environ.get("PSL_NATIVE_RCCL")
+        if env in ("0", "1"):
+            kind = "native" if env == "1" else "torch"
+        else:
+            kind = "native" if dist.get_backend(group) == "nccl" else "torch"
     if kind == "native":
         return _NativeTransport(npc, group)
     return _TorchTransport(group)
