@@ -43,7 +43,16 @@ def parse():
                     help="seed the cloud without holes: (almost) no point growth during the run, as in round 1")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
-    ap.add_argument("--exchange-every", type=int, default=2, help="mapped frames between point all-gathers (N>1)")
+    ap.add_argument("--exchange-every", type=int, default=None,
+                    help="mapped frames between exchanges (N>1); default: derived from --exchange-every-keyframes")
+    ap.add_argument("--exchange-every-keyframes", type=int, default=10,
+                    help="BASELINE config 4: 'RCCL neural-point all-gather every 10 keyframes' -> one exchange every "
+                         "10 * keyframe_every / every_frame mapped frames of a rank; a run shorter than that still performs ONE "
+                         "exchange inside the timed region (at its last mapped frame), so that its cost is in `value`")
+    ap.add_argument("--track-only", action="store_true",
+                    help="BASELINE config 1: tracking only on a FIXED cloud (no mapping, no point growth); every frame starts "
+                         "from the constant-speed extrapolation of the tracker's own previous estimates (Tracker.py:259-270). "
+                         "Quoted with --points 50000 --width 1200 --height 680 --mix replica --steps 200")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -63,7 +72,13 @@ def build_world(args, rank, world, dev):
     slam = HipSLAM(cfg, cam, device=str(dev), max_points=int(args.points * 1.3) + 300_000, engine=args.engine)
     # one cube in four of a 25 cm checker is left unseeded: every mapped frame still finds uncovered surface and ADDS
     # points (thousands at first, fewer as the holes fill), like a real sequence; --saturated-map restores round 1
-    pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"], holes=not args.saturated_map)
+    track_only = getattr(args, "track_only", False)
+    if track_only:
+        # the fixed cloud of config 1: all of it around the stretch of the trajectory the run tracks (t = 200 + 2 i)
+        n_fr = args.warmup + 2 * args.steps
+        pts = syn.seed_cloud(cam, args.points, n_views=48, seed=cfg["setup_seed"], t0=190.0, dt=(2.0 * n_fr + 20.0) / 47.0)
+    else:
+        pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"], holes=not args.saturated_map)
     slam.seed_points(pts)
     every = cfg["mapping"]["every_frame"]
     n_total = args.warmup + args.steps * (1 if args.no_kernel_timing else 2)
@@ -79,6 +94,8 @@ def build_world(args, rank, world, dev):
         r_add, r_q = syn.dynamic_radii(color, cfg)
         fr = Frame(i, depth, color, r_add, r_q, c2w)
         if i < 0:
+            if track_only:
+                continue                                             # fixed cloud, no keyframes
             # earlier keyframes: their views were MAPPED when they were taken, i.e. points were added where they saw
             # uncovered surface (untimed set-up; otherwise half of their samples would query empty space for ever)
             slam.add_points(fr, c2w)
@@ -99,6 +116,22 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         # the per-frame radius maps are part of the reference's frame loop (Tracker.py:235-250): one kernel here
         from point_slam_amd import frame_ops
         fr.r_add, fr.r_query = frame_ops.dynamic_radius_maps(fr.color, cfg)
+    if getattr(args, "track_only", False):
+        # closed loop on the tracker's own estimates, no host copy of a pose anywhere: frames 0 and 1 take the ground truth
+        # (Tracker.py:254-255), frame i >= 2 starts from delta @ pre_c2w, delta = pre_c2w @ inv(c2w[i-2]) (:259-266)
+        est = state.setdefault("est", [])
+        if len(est) < 2:
+            est.append(fr.c2w.clone())
+            return
+        cam0 = H.camera_tensor_from_c2w_device(H.const_speed_init(est[-1], est[-2]))
+        best = slam.track(fr, cam0)
+        c34 = H.get_camera_from_tensor(best)
+        if "row4" not in state:
+            state["row4"] = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=c34.device)
+        est.append(torch.cat([c34, state["row4"]], 0))
+        state.setdefault("traj", []).append((i, est[-1][:3, 3]))
+        est.pop(0)
+        return
     best = slam.track(fr, cams0[i])
     if i % every == 0:
         c2w34 = H.get_camera_from_tensor(best)
@@ -107,7 +140,7 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         slam.map(fr, c2w)
         state["mapped"] += 1
         state["added"] += slam.npc.pts_num() - n_base
-        if world > 1 and state["mapped"] % args.exchange_every == 0:
+        if world > 1 and (state["mapped"] % state["exchange_every"] == 0 or i in state.get("force_exchange_at_all", ())):
             # new points (cross-rank dedupe), features of shared rows and the colour decoder are reconciled
             import time as _t
             torch.cuda.synchronize()
@@ -204,6 +237,54 @@ def parity_vs_oracle(slam, cfg, cam, frame):
     return worst, dict(checker="oracle/pointslam_oracle.py (pinned to the unmodified reference by tests/test_oracle_golden.py)",
                        cases=[{k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in d.items() if k in keep}
                               for d in detail])
+
+
+def cpu_baseline_track_only(cfg, cam, n_points, pts):
+    """BASELINE config 1 beside the GPU line: the CPU oracle's tracker iteration (exact cKDTree 8-NN + torch fp32 decoders +
+    autograd through the pose, Tracker.py:89-186) on the SAME fixed cloud and image size, a bounded sample of iterations
+    (~10-20 s), extrapolated to tracking.iters per frame."""
+    import torch
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.decoders import PointDecoders
+    n_thr = min(os.cpu_count(), 16)
+    torch.set_num_threads(n_thr)
+    O.KNN_WORKERS = n_thr
+    torch.manual_seed(cfg["setup_seed"])
+    dec = PointDecoders(cfg)
+    P = {k: v.detach() for k, v in dec.state_dict().items()}
+    P["color_decoder.embedder._B"] = dec.color_decoder.embedder._B
+    pts = pts.cpu().float()
+    g = torch.Generator().manual_seed(7)
+    geo = torch.zeros(pts.shape[0], 32).normal_(0, 0.1, generator=g)
+    col = torch.zeros(pts.shape[0], 32).normal_(0, 0.1, generator=g)
+    c2w = syn.pose(230.0)
+    depth, color = syn.render_frame(cam, c2w)
+    _, rq_img = syn.dynamic_radii(color, cfg)
+    tr = cfg["tracking"]
+    eh, ew = tr["ignore_edge_H"], tr["ignore_edge_W"]
+    O.knn_exact(pts, pts[:8], 8)
+    fb = torch.zeros(32)
+
+    def one_iter():
+        idx = torch.randint((cam["H"] - 2 * eh) * (cam["W"] - 2 * ew), (tr["pixels"],), generator=g)
+        u, v = O.pixels_from_flat_index(idx, eh, cam["H"] - eh, ew, cam["W"] - ew)
+        ro, rd = O.rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        gd, gc, rq = depth[v.long(), u.long()], color[v.long(), u.long()], rq_img[v.long(), u.long()]
+        ro = ro.clone().requires_grad_(True); rd = rd.clone().requires_grad_(True)
+        d, var, rgb, valid, _ = O.render_batch_ray(cfg, P, pts, geo, col, ro, rd, gd, "color", rq, fb, fb, True)
+        loss, *_ = O.tracker_loss(d, var, rgb, gd, gc)
+        loss.backward()
+    one_iter()
+    n = 24
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_iter()
+    t_it = (time.perf_counter() - t0) / n
+    return dict(value=round(1.0 / (tr["iters"] * t_it), 5), unit="frames/s", cores=n_thr, kind="port",
+                sample=f"kind=port (/root/reference does not exist on the GPU box); oracle tracker iteration (cKDTree exact 8-NN + "
+                       f"torch fp32 + autograd to the pose), N={pts.shape[0]} points, {cam['W']}x{cam['H']}, {tr['pixels']} px: "
+                       f"{n} iterations of {t_it * 1e3:.0f} ms each, extrapolated to {tr['iters']} iterations per frame")
 
 
 def cpu_baseline(cfg, cam, n_points):
@@ -335,8 +416,19 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.track_only and (args.warmup < 2 or world > 1):
+        raise SystemExit("--track-only: one GPU, and --warmup >= 2 (frames 0 and 1 take the ground-truth pose, Tracker.py:254-255)")
     cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
     state = dict(mapped=0, added=0)
+    mpc = cfg["mapping"]
+    per_kf = max(mpc["keyframe_every"] // mpc["every_frame"], 1)               # mapped frames per keyframe
+    state["exchange_every"] = args.exchange_every or max(args.exchange_every_keyframes * per_kf, 1)
+    mapped_in_timed = len([i for i in range(args.warmup, args.warmup + args.steps) if i % every == 0])
+    if world > 1 and mapped_in_timed < state["exchange_every"]:
+        # shorter than the cadence: one exchange at the last mapped frame of each timed pass
+        last = [max([i for i in range(a, a + args.steps) if i % every == 0], default=-1)
+                for a in (args.warmup, args.warmup + args.steps)]
+        state["force_exchange_at_all"] = last
     if world > 1:
         from point_slam_amd import params as P_
         from point_slam_amd.dist import FrameParallelSync
@@ -398,7 +490,7 @@ def main():
     # (3) SURVEY.md 8(d): tracking-only and mapping-only rates next to the combined one (single GPU; after the measured
     #     regions, on frames already seen: 10 tracked frames, then 2 mapped frames at their true poses)
     split = None
-    if world == 1 and not args.no_kernel_timing:
+    if world == 1 and not args.no_kernel_timing and not args.track_only:
         from point_slam_amd import frame_ops
         ids = list(range(max(len(frames) - 10, 0), len(frames)))
         torch.cuda.synchronize()
@@ -434,6 +526,10 @@ def main():
                        "points_added_per_mapped_frame": round(state["added"] / mapped_total, 1),
                        "mapped_frames": state["mapped"],
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
+                       "exchange_cadence": (f"every {state['exchange_every']} mapped frames of a rank"
+                                            + (f" (= {args.exchange_every_keyframes} keyframes, BASELINE config 4)" if not args.exchange_every else "")
+                                            + ("; this run is shorter: ONE exchange forced at the last mapped frame of the timed region"
+                                               if state.get("force_exchange_at_all") else "")) if world > 1 else None,
                        "keyframes_kept": "last 40 (the reference keeps every keyframe on the CPU)",
                        # measured in this run by the cpu_baseline leg (parity_vs_oracle); null when that leg is off
                        "render_loss_rel_err_vs_reference": None},
@@ -445,12 +541,40 @@ def main():
             "kernels": {k: {kk: (round(vv, 5) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                         for k, v in per.items()},
         }
+        if args.track_only:
+            # the trajectory the closed loop produced against the ground truth (translation, cm)
+            ids_ = [k for k, _ in state.get("traj", [])]
+            if ids_:
+                est_t = torch.stack([t for _, t in state["traj"]]).cpu()
+                gt_t = torch.stack([frames[k].c2w[:3, 3] for k in ids_]).cpu()
+                err = (est_t - gt_t).norm(dim=1) * 100.0
+                out["config"]["ate_rmse_cm"] = round(float((err ** 2).mean().sqrt()), 4)
+                out["config"]["ate_max_cm"] = round(float(err.max()), 4)
+                out["config"]["tracked_frames"] = len(ids_)
+            out["metric"] = (f"tracking FPS @{args.width}x{args.height}, fixed {args.points / 1e3:g}k-point cloud "
+                             f"(BASELINE config 1: tracking only)")
+            out["config"]["workload"] = (f"synthetic {args.width}x{args.height} RGB-D room, FIXED cloud of {args.points} neural points, "
+                                         f"tracking only: {tr['pixels']}px x {tr['iters']}it per frame ({args.mix} mix), every frame "
+                                         f"initialised by constant-speed extrapolation of the tracker's own two previous estimates")
+            for k in ("points_added_per_mapped_frame", "mapped_frames", "keyframes_kept"):
+                out["config"].pop(k, None)
         if per_rank is not None:
             out["config"]["per_rank"] = per_rank
             out["config"]["replicas_identical_after_exchange"] = (
                 len({r["points_after_final_exchange"] for r in per_rank}) == 1 and
                 len({r["feat_checksum"] for r in per_rank}) == 1)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.track_only:
+            try:
+                from tests import parity_probe as PP
+                d = PP.probe(slam, cfg, cam, frames[args.warmup + args.steps - 1], "tracker", tr["pixels"], seed=31)
+                out["config"]["render_loss_rel_err_vs_reference"] = float(f"{max(d['loss_rel'], d['geo_loss_rel'], d['col_loss_rel']):.4g}")
+            except Exception as e:
+                out["config"]["render_loss_parity"] = {"error": repr(e)}
+            try:
+                out["cpu_baseline"] = cpu_baseline_track_only(cfg, cam, args.points, slam.npc.cloud_pos())
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        elif world == 1 and not args.no_cpu_baseline:
             try:
                 worst, detail = parity_vs_oracle(slam, cfg, cam, frames[args.warmup + args.steps - 1])
                 out["config"]["render_loss_rel_err_vs_reference"] = float(f"{worst:.4g}")

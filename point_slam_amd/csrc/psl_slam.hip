@@ -883,7 +883,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     float* lo = t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch;
     if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
-      hipLaunchKernelGGL(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
+      PSL_KLAUNCH(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
                          ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, t->sigmoid_coef, t->w_color, t->handle_dynamic,
                          t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
     } else {

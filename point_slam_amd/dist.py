@@ -92,9 +92,9 @@ class _NativeTransport:
         dev, width = rec.device, rec.shape[1]
         rec = rec.contiguous()
         counts = (C.c_int32 * self.world)()
-        need = max(4 * self.world * max(rec.shape[0], 1024), 65536)
-        if self.buf is None or self.buf.shape[0] < need or self.buf.shape[1] != width:
-            self.buf = torch.empty(need, width, device=dev, dtype=torch.float32)
+        if self.buf is None or self.buf.shape[1] != width:
+            # first guess from this rank's own block; from then on the buffer grows through the CAPACITY round below only
+            self.buf = torch.empty(max(4 * self.world * max(rec.shape[0], 1024), 65536), width, device=dev, dtype=torch.float32)
         while True:
             rc = L.psl_allgather_new_points(self.npc.handle, None, 0, _lib.ptr(rec), rec.shape[0], width, _lib.ptr(self.buf),
                                             self.buf.shape[0], counts, _lib.stream_ptr())

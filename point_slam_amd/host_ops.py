@@ -80,3 +80,33 @@ def mapper_loss(depth, rgb, valid_ray, gt_depth, gt_color, stage, w_color=0.1):
         col = torch.abs(gt_color[m] - rgb[m]).sum()
         loss = loss + w_color * col
     return loss, geo, col, m
+
+
+def const_speed_init(prev_c2w: torch.Tensor, prev_prev_c2w: torch.Tensor = None) -> torch.Tensor:
+    """Initial pose of the next frame (src/Tracker.py:259-266): delta = pre_c2w @ inv(c2w[idx-2]), estimate = delta @ pre_c2w
+    (const_speed_assumption); the previous estimate itself when there is no frame idx-2."""
+    prev = prev_c2w.float()
+    if prev_prev_c2w is None:
+        return prev
+    return (prev @ prev_prev_c2w.float().inverse()) @ prev
+
+
+def camera_tensor_from_c2w_device(c2w: torch.Tensor) -> torch.Tensor:
+    """get_tensor_from_camera (src/common.py:270-295) without leaving the device: [quat(w,x,y,z), T] of a 4x4 (or 3x4)
+    pose.  The reference goes through scipy on the host; a frame loop that feeds the tracker's own estimates back as the next
+    initial pose would stall on that copy once per frame.  Shepperd's method, the branch taken by selects; the sign of the
+    quaternion is free (q and -q are the same rotation; the reference flips it towards the ground-truth hemisphere,
+    Tracker.py:272-273, which changes nothing in the optimisation)."""
+    R = c2w[:3, :3].float()
+    m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
+    tr = m00 + m11 + m22
+    cands = torch.stack([
+        torch.stack([1.0 + tr, R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]),
+        torch.stack([R[2, 1] - R[1, 2], 1.0 + m00 - m11 - m22, R[0, 1] + R[1, 0], R[0, 2] + R[2, 0]]),
+        torch.stack([R[0, 2] - R[2, 0], R[0, 1] + R[1, 0], 1.0 - m00 + m11 - m22, R[1, 2] + R[2, 1]]),
+        torch.stack([R[1, 0] - R[0, 1], R[0, 2] + R[2, 0], R[1, 2] + R[2, 1], 1.0 - m00 - m11 + m22])])
+    k = torch.argmax(torch.stack([tr, m00, m11, m22]))          # the largest diagonal term: the best-conditioned candidate
+    q = cands.index_select(0, k.reshape(1))[0]
+    q = q / q.norm()
+    q = torch.where(q[0] < 0, -q, q)
+    return torch.cat([q, c2w[:3, 3].float()])

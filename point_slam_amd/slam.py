@@ -51,10 +51,16 @@ class Frame:
         v.color = self.color.data_ptr()
         v.r_query = self.r_query.data_ptr() if self.r_query is not None else None
         if pose and self.c2w is not None:
-            key = (id(self.c2w), self.c2w._version)
-            if getattr(self, "_c2w_host_key", None) != key:      # one copy per pose, not one per mapping call
+            # one device-to-host copy per pose, not one per mapping call.  The cache holds a REFERENCE to the tensor it copied
+            # (an id() alone can be recycled by a new tensor at the same address, version 0 again) plus its version
+            # counter; tensors without one (inference mode) are copied every time.
+            try:
+                ver = self.c2w._version
+            except Exception:
+                ver = None
+            if ver is None or getattr(self, "_c2w_ref", None) is not self.c2w or self._c2w_ver != ver:
                 self._c2w_host = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
-                self._c2w_host_key = key
+                self._c2w_ref, self._c2w_ver = self.c2w, ver
             for i in range(12):
                 v.c2w[i] = self._c2w_host[i]
         return v
@@ -154,6 +160,12 @@ class HipSLAM:
         return ck
 
     # ------------------------------------------------------------------ tracking
+    def init_pose(self, est_c2w: list) -> torch.Tensor:
+        """Camera tensor the tracker starts frame len(est_c2w) from (Tracker.py:259-270): constant-speed extrapolation of
+        the last two ESTIMATED poses."""
+        c2w = H.const_speed_init(est_c2w[-1], est_c2w[-2] if len(est_c2w) >= 2 else None)
+        return camera_tensor_from_c2w(c2w)
+
     def track(self, frame: Frame, cam0: torch.Tensor, n_iters=None, n_pix=None) -> torch.Tensor:
         """Optimise the pose of `frame` from the initial camera tensor cam0 [7]; returns the lowest-loss
         camera tensor (candidate_cam_tensor, Tracker.py:347-350)."""
@@ -413,6 +425,8 @@ class HipSLAM:
         n_iters = n_iters or 2 * mp["iters"]
         N = self.npc.pts_num()
         sel = torch.arange(N, dtype=torch.int32, device=self.device)
+        if self.sync is not None:
+            self.sync.note_rows(self.npc, sel)      # every row is trained: all of them belong to the next exchange
         lr = dict(geo_geo=0.0, geo_col=0.0, col=mp["stage"]["color"]["color_lr"] / 10.0, dec=mp["stage"]["color"]["decoders_lr"])
         for _ in range(n_outer):
             window = self.select_window(frame, None, size=2 * mp["mapping_window_size"], method="global")

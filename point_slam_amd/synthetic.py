@@ -116,10 +116,12 @@ def in_hole(p: torch.Tensor, cell: float = 0.5) -> torch.Tensor:
 
 
 def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed: int = 1219, device="cpu",
-               near=0.98, far=1.02, holes: bool = False):
+               near=0.98, far=1.02, holes: bool = False, t0: float = 0.0, dt: float = 40.0):
     """Seed ~n_points neural point positions by back-projecting a jittered pixel grid
     from n_views poses (add_neural_points geometry: n_add pts/location at
-    linspace(near,far)*depth, src/neural_point.py:126-145).  No dedupe.  holes: leave the cubes of in_hole() empty."""
+    linspace(near,far)*depth, src/neural_point.py:126-145).  No dedupe.  holes: leave the cubes of in_hole() empty.
+    The views are pose(t0 + dt * v): the default walks the whole trajectory, a small (t0, dt) packs a small cloud around
+    the stretch a run will track (bench.py --track-only: BASELINE config 1's fixed 50 k-point cloud)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     per_view = (n_points // n_add + n_views - 1) // n_views
     if holes:
@@ -127,7 +129,7 @@ def seed_cloud(cam: dict, n_points: int, n_add: int = 3, n_views: int = 64, seed
     out = []
     t = torch.linspace(0.0, 1.0, n_add)
     for v in range(n_views):
-        c2w = pose(40.0 * v, "cpu")
+        c2w = pose(t0 + dt * v, "cpu")
         u = torch.rand(per_view, generator=g) * (cam["W"] - 1)
         w = torch.rand(per_view, generator=g) * (cam["H"] - 1)
         dirs = torch.stack([(u - cam["cx"]) / cam["fx"], -(w - cam["cy"]) / cam["fy"], -torch.ones_like(u)], -1)

@@ -156,3 +156,36 @@ def test_struct_layouts_match_ctypes(tmp_path):
             if stmt:
                 n_decl += stmt.count(",") + 1
         assert n_decl == len(getattr(_lib, sname)._fields_), (sname, n_decl)
+
+
+def test_allgather_capacity_decision_is_rank_invariant():
+    """psl_allgather_decide (the counts phase of psl_allgather_new_points) sees only the gathered (rows, capacity) pairs:
+    with UNEQUAL receive buffers -- the advisor's round-3 case: one rank contributes ~500 rows and sized its buffer for
+    that, the others ~10 k each -- every rank must take the SAME branch (all PSL_ERR_CAPACITY, before the records
+    collective), and all proceed once every buffer holds the total."""
+    import ctypes as C
+    from point_slam_amd import _lib
+    L = _lib.lib()
+    world = 8
+    rows = [500] + [10000] * 7
+    caps = [65536] + [280000] * 7                      # rank 0's buffer only ever grew with its own history
+    total = sum(rows)                                  # 70 500 > 65 536
+
+    def decide(rows, caps):
+        pairs = (C.c_int32 * (2 * world))(*[x for rc in zip(rows, caps) for x in rc])
+        counts = (C.c_int32 * world)()
+        tot, nmax = C.c_longlong(0), C.c_int(0)
+        rc = L.psl_allgather_decide(pairs, world, counts, C.byref(tot), C.byref(nmax))
+        return rc, list(counts), tot.value, nmax.value
+
+    rc, counts, tot, nmax = decide(rows, caps)
+    assert rc == -3 and counts == rows and tot == total and nmax == 10000       # PSL_ERR_CAPACITY with valid counts
+    # the function has no rank-local input: what rank 0 and rank 5 compute is the same call -> the same branch.  After all
+    # ranks grow to 2 * total + 1024 (dist._NativeTransport), the next round passes everywhere
+    rc, counts, tot, nmax = decide(rows, [2 * total + 1024] * world)
+    assert rc == 0 and tot == total
+    # an empty round and a single huge block
+    assert decide([0] * world, caps)[0] == 0
+    rc, counts, tot, _ = decide([0, 70000] + [0] * 6, [65536] * world)
+    assert rc == -3 and tot == 70000
+    assert decide([0, -1] + [0] * 6, caps)[0] == -1                              # PSL_ERR_ARG: a corrupt count

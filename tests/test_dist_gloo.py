@@ -157,3 +157,73 @@ def test_exchange_new_points_world2():
     assert torch.allclose(th0[:6], torch.arange(6, dtype=torch.float32) + 2.0) and torch.equal(th0[:6], th1[:6])
     assert th0[6] == 106.0 and th1[6] == 6.0
     assert fr0 == [0, 2, 4, 6] and fr1 == [1, 3, 5]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world 4: ragged blocks with TWO empty ranks and a rank whose WHOLE block is deduped away by an
+# earlier rank's block; then an exchange in which nobody contributes; features touched on a subset of ranks.
+def _worker4(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from point_slam_amd.dist import FrameParallelSync
+    g = torch.Generator().manual_seed(100)
+    base = torch.rand(12, 3, generator=g) + 5.0
+    bg, bc = torch.rand(12, 32, generator=g), torch.rand(12, 32, generator=g)
+    cloud = FakeCloud(base.clone(), bg.clone(), bc.clone())
+    theta = torch.arange(8, dtype=torch.float32)
+    sync = FrameParallelSync(cloud, theta, n_color=6)
+    # rank 0: nothing.  rank 1: locations A, B.  rank 2: nothing.  rank 3: A + 5 mm and B - 5 mm -> both inside rank 1's
+    # add-radius (4 cm): its whole block goes.
+    A, B = torch.tensor([[1.0, 1.0, 1.0]]), torch.tensor([[2.0, 1.0, 0.5]])
+    gr = torch.Generator().manual_seed(rank + 1)
+    if rank == 1:
+        new = _triplets(torch.cat([A, B]))
+    elif rank == 3:
+        new = _triplets(torch.cat([A + 0.005, B - 0.005]))
+    else:
+        new = torch.zeros(0, 3)
+    if new.shape[0]:
+        cloud.append_points(new, torch.rand(new.shape[0], 32, generator=gr), torch.rand(new.shape[0], 32, generator=gr))
+    builds0 = getattr(cloud, "builds", 0)
+    # rows: rank 0 trains rows 0,1; rank 2 trains row 1; ranks 1,3 announce row 3 but leave it unchanged
+    sync.note_rows(cloud, torch.tensor([0, 1]) if rank == 0 else (torch.tensor([1]) if rank == 2 else torch.tensor([3])))
+    if rank == 0:
+        cloud.geo[0] += 1.0; cloud.geo[1] += 2.0
+    if rank == 2:
+        cloud.geo[1] += 6.0
+    counts = sync.exchange(cloud, theta)
+    stats = dict(sync.last_stats)
+    n_after = cloud.pts_num()
+    builds = cloud.builds - builds0
+    # second exchange: nobody has anything (no rows, no points): the replica must stand as it is, no rebuild needed
+    pos_before = cloud.pos.clone()
+    counts2 = sync.exchange(cloud, theta)
+    same = bool(torch.equal(pos_before, cloud.pos)) and cloud.index_ok
+    q.put(tuple(_np(x) for x in (rank, counts, counts2, n_after, builds, cloud.pos.clone(), cloud.geo.clone(), bg, stats["rows_sent"],
+                                 stats["rows_received"], same)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_world4_empty_ranks_and_a_block_deduped_away():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted([tuple(_t(x) for x in q.get(timeout=180)) for _ in range(4)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        rank, counts, counts2, n_after, builds, pos, geo, bg, sent, recv, same = r
+        assert counts == [0, 6, 0, 6] and counts2 == [0, 0, 0, 0]
+        assert n_after == 12 + 6                      # rank 1's two locations; rank 3's block is gone entirely
+        assert builds == 1 and same                   # one rebuild per exchange; an empty exchange changes nothing
+        assert torch.equal(pos, res[0][5]) and torch.equal(geo, res[0][6])          # identical replicas
+        assert recv == 3                              # rows 0, 1 from rank 0 and row 1 from rank 2; the untouched row 3 is not sent
+        assert sent == {0: 2, 1: 0, 2: 1, 3: 0}[rank]
+    geo, bg = res[0][6], res[0][7]
+    d = geo[:4, 0] - bg[:4, 0]
+    assert torch.allclose(d, torch.tensor([1.0, 4.0, 0.0, 0.0]))                    # row 1: mean of +2 and +6

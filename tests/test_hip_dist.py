@@ -141,6 +141,12 @@ def _native_worker(port, q):
         got, counts = sync.transport.allgather_v(rec)
         ref, counts_t = _TorchTransport().allgather_v(rec)
         empty, counts_e = sync.transport.allgather_v(rec[:0])
+        # a block larger than the receive buffer (65 536 rows after the first call): PSL_ERR_CAPACITY -- decided on the gathered
+        # (rows, capacity) pairs, so on every rank alike --, the buffer grows from the counts, the second round delivers
+        big = torch.randn(70000, 68, generator=g).to(dev)
+        cap0 = sync.transport.buf.shape[0]
+        got_big, counts_big = sync.transport.allgather_v(big)
+        assert cap0 < 70000 <= sync.transport.buf.shape[0] and counts_big == [70000] and torch.equal(got_big, big)
         # and a whole exchange over it: new points + a touched row
         n_base = npc.pts_num()
         new = base[:300].to(dev) + torch.tensor([10.0, 0.0, 0.0], device=dev)
