@@ -172,7 +172,7 @@ def pmc_traffic(mix):
     """HBM bytes per launch of each kernel class from the PMC pass of the same command (tools/pmc_traffic.sh: separate
     rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md applied there);
     rocprofv3 cannot run inside the timed process, so the figures are read from the committed summary."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{mix}.json")
         if not os.path.exists(path):
             continue
@@ -188,7 +188,17 @@ def pmc_traffic(mix):
     return {}
 
 
-def roofline_of(prof, traffic=None):
+def algorithmic_bytes(cfg):
+    """SURVEY.md 8(d) algorithmic HBM bytes per LAUNCH of the decode classes: per sample, query 12 + neighbour positions 96 +
+    8 feature rows of 128 B per feature set (2 156 B colour stage, 1 132 B geometry stage) gathered by the forward and again
+    by the backward, + the read-modify-write of the gradient rows (4 096 / 2 048 B) where features are trained (mapper)."""
+    tr, mp = cfg["tracking"], cfg["mapping"]
+    pt, pm = 5 * tr["pixels"], 5 * mp["pixels"]
+    return {"decode_fwd": 2156 * pm, "decode_bwd": (2156 + 4096) * pm, "decode_fwd_geo": 1132 * pm, "decode_bwd_geo": (1132 + 2048) * pm,
+            "geo_iter": (1132 + 2048) * pm, "decode_fwd_track": 2156 * pt, "decode_bwd_track": 2156 * pt}
+
+
+def roofline_of(prof, traffic=None, algo=None):
     if not prof:
         return None, {}
     per = {}
@@ -213,6 +223,10 @@ def roofline_of(prof, traffic=None):
     roof = dict(kernel=dom, bound=r["bound"], achieved=round(r["achieved"], 4), peak=r["peak"], unit=r["unit"],
                 frac=round(r["frac"], 5), traffic=tr.get("bytes_per_launch") if tr else None,
                 avg_launch_us=round(r["avg_us"], 2), launches=r["launches"])
+    if algo and dom in algo:
+        roof["algorithmic_bytes_per_launch"] = int(algo[dom])
+        if tr and tr.get("bytes_per_launch"):
+            roof["traffic_over_algorithmic"] = round(tr["bytes_per_launch"] / algo[dom], 2)
     if tr:
         roof["traffic_detail"] = tr
     roof["traffic_source"] = (traffic or {}).get("_source") if tr else None
@@ -511,7 +525,15 @@ def main():
                  "map_only_fps": round(cfg["mapping"]["every_frame"] / t_map, 2)}
 
     if rank == 0:
-        roof, per = roofline_of(prof, pmc_traffic(args.mix))
+        pmc_key = "cfg5" if (args.points >= 2_000_000 and args.width >= 1280) else args.mix
+        roof, per = roofline_of(prof, pmc_traffic(pmc_key), algorithmic_bytes(cfg))
+        if roof is not None:
+            # `value` comes from pass (1) (no instrumentation); the kernel classes -- and therefore `roofline` -- from pass (2),
+            # the NEXT `steps` frames with an event pair on every hot launch.  Both wall times are in the line.
+            roof["measured_on"] = (f"pass 2: frames {args.warmup + args.steps}..{args.warmup + 2 * args.steps - 1}, event-carrying launches, "
+                                   f"{round(dt_prof / args.steps * 1e3, 3) if dt_prof else None} ms/step; `value` is pass 1: frames "
+                                   f"{args.warmup}..{args.warmup + args.steps - 1}, {round(dt / args.steps * 1e3, 3)} ms/step")
+            roof["class_sum_ms_per_step"] = round(sum(v["total_ms"] for k, v in per.items() if k != "knn_side_stream") / args.steps, 3)
         tr, mp = cfg["tracking"], cfg["mapping"]
         out = {
             "metric": f"mapping+tracking FPS @{args.width}x{args.height}, {args.points / 1e6:g}M neural points",

@@ -74,17 +74,31 @@ class _NativeTransport:
     """all-gather-v inside libpointslam_hip.so (psl_allgather_new_points on the library's RCCL communicator)."""
 
     def __init__(self, npc, group=None):
+        """Collective.  Raises RuntimeError ON EVERY RANK when the communicator cannot be brought up on any of them (the
+        ranks agree through torch.distributed before anybody returns), so that a caller may fall back as one."""
         from . import _lib
         self._lib, self.npc, self.group = _lib, npc, group
         self.world, rank = dist.get_world_size(group), dist.get_rank(group)
         L = _lib.lib()
         ident = C.create_string_buffer(128)
+        box = [None]
         if rank == 0:
-            _lib.check(L.psl_comm_unique_id(ident), "psl_comm_unique_id")
-        box = [bytes(ident.raw)]
-        dist.broadcast_object_list(box, src=0, group=group)      # the only use of torch.distributed on this path
+            if L.psl_comm_unique_id(ident) >= 0:
+                box = [bytes(ident.raw)]
+            else:
+                box = [None]                                     # e.g. librccl not found: tell the others instead of leaving them waiting
+        dist.broadcast_object_list(box, src=0, group=group)      # the only use of torch.distributed on the data path set-up
+        if box[0] is None:
+            raise RuntimeError("psl_comm_unique_id failed on rank 0: " + (L.psl_last_error().decode() if rank == 0 else "(see rank 0)"))
         ident = C.create_string_buffer(box[0], 128)
-        _lib.check(L.psl_comm_init(npc.handle, ident, rank, self.world), "psl_comm_init")
+        rc = L.psl_comm_init(npc.handle, ident, rank, self.world)
+        dev = npc.get_geo_feats().device
+        ok = torch.tensor([1 if rc >= 0 else 0], device=dev if dev.type == "cuda" else "cpu", dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if rc >= 0:
+                L.psl_comm_destroy(npc.handle)
+            raise RuntimeError("psl_comm_init failed on some rank" + (": " + L.psl_last_error().decode() if rc < 0 else ""))
         self.buf = None
 
     def allgather_v(self, rec: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
@@ -112,14 +126,24 @@ def make_transport(npc, group=None, kind: Optional[str] = None):
     """`kind` None: the library's own RCCL all-gather-v when the process group runs on the "nccl" (= RCCL) backend -- the path
     a multi-GPU node takes --, torch.distributed collectives otherwise (gloo: CPU tests, ranks sharing one GPU).
     PSL_NATIVE_RCCL=1 / 0 forces either."""
+    forced = kind is not None
     if kind is None:
         env = os.environ.get("PSL_NATIVE_RCCL")
         if env in ("0", "1"):
-            kind = "native" if env == "1" else "torch"
+            kind, forced = ("native" if env == "1" else "torch"), True
         else:
             kind = "native" if dist.get_backend(group) == "nccl" else "torch"
     if kind == "native":
-        return _NativeTransport(npc, group)
+        try:
+            return _NativeTransport(npc, group)
+        except RuntimeError as e:
+            if forced:
+                raise
+            # the default choice could not be brought up (on all ranks alike, see _NativeTransport.__init__): the same
+            # exchange through torch.distributed's collectives -- said loudly, the path is not silently swapped
+            import sys
+            print(f"[point_slam_amd.dist] native RCCL transport unavailable ({e}); using torch.distributed collectives",
+                  file=sys.stderr, flush=True)
     return _TorchTransport(group)
 
 

@@ -12,6 +12,7 @@
 #   trace[:<args>]                rocprofv3 --kernel-trace --stats of bench.py <args> -> <tag>_kernel_trace_stats.csv (+ timeline)
 #   pmc:<mix>                     PMC passes (FETCH_SIZE / WRITE_SIZE / SQ groups) on tools/pmc_probe.py --mix <mix>
 #                                 -> <tag>_pmc_<mix>/*.csv and profiles-ready <tag>_pmc_traffic_<mix>.json
+#   x8[:<steps>[:<points>]]       bench.py --gpus 8 with all ranks sharing the one GPU (gloo) -> <tag>_bench_frame_parallel_x8_shared_gpu.json
 #   knn                           tools/knn_roofline.py -> <tag>_knn_roofline.json
 #   exchange                      tools/exchange_timing.py -> <tag>_exchange_timing.json
 #   py:<script>[:<args>]          python <script> <args> -> <tag>_<basename>.log
@@ -63,14 +64,22 @@ EOF
       rm -rf $O/prof_$TAG ;;
     pmc)
       mix=${a1:-base}; P=$O/${TAG}_pmc_$mix; mkdir -p $P
-      run() { n=$1; shift; timeout 200 rocprofv3 --pmc "$@" -d $P -o $n -- python tools/pmc_probe.py --mix $mix > $P/$n.log 2>&1; python tools/rocpd_pmc.py $P/${n}_results.db > $P/$n.csv 2>&1; rm -f $P/${n}_results.db; }
+      pargs="--mix $mix"; pname=$mix
+      if [ "$mix" = "cfg5" ]; then pargs="--mix base --points 2000000 --width 1280 --height 960"; fi
+      run() { n=$1; shift; timeout 300 rocprofv3 --pmc "$@" -d $P -o $n -- python tools/pmc_probe.py $pargs > $P/$n.log 2>&1; python tools/rocpd_pmc.py $P/${n}_results.db > $P/$n.csv 2>&1; rm -f $P/${n}_results.db; }
       run fetch FETCH_SIZE
       run write WRITE_SIZE
       if [ "$a2" = "sq" ]; then
         run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
         run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS
       fi
-      python tools/pmc_traffic.py $P/fetch.csv $P/write.csv $O/${TAG}_pmc_traffic_$mix.json $COMMIT | tail -12 ;;
+      cp $O/pmc_probe_meta.json $P/probe_meta.json
+      python tools/pmc_traffic.py $P/fetch.csv $P/write.csv $O/${TAG}_pmc_traffic_$mix.json $COMMIT $P/probe_meta.json | python -c "import json,sys; d=json.load(sys.stdin); [print(k, v.get('bytes_per_launch')) for k,v in d.items() if k!='_meta']" ;;
+    x8)
+      # N = 8 ranks on the ONE GPU over gloo (RCCL refuses two ranks per device): launcher, rank-order merge, ragged / empty
+      # blocks and the replica check at N = 8 -- functional evidence, not a scaling number
+      PSL_BENCH_SHARE_GPU=1 timeout 900 python bench.py --no-cpu-baseline --no-kernel-timing --gpus 8 --steps ${a1:-6} --points ${a2:-300000} 2> $O/${TAG}_bench_x8.err | tail -1 > $O/${TAG}_bench_frame_parallel_x8_shared_gpu.json
+      python -c "import json; d=json.load(open('$O/${TAG}_bench_frame_parallel_x8_shared_gpu.json')); c=d['config']; print('x8', d['value'], d['unit'], 'identical', c.get('replicas_identical_after_exchange'), c.get('exchange_cadence')); print([ (r['rank'], r['added'], r['exchange_ms']) for r in c['per_rank']])" ;;
     knn)
       timeout 300 python tools/knn_roofline.py > $O/${TAG}_knn_roofline.log 2>&1; cp $O/knn_roofline.json $O/${TAG}_knn_roofline.json; tail -3 $O/${TAG}_knn_roofline.log ;;
     exchange)

@@ -7,14 +7,23 @@ on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) streaming
 the kernels whose reads are such streams (the weight-fragment and activation streams of the register-chained decode
 kernels, the dW GEMM, Adam); WRITE_SIZE is taken as reported (uncalibrated there).
 
-usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc_<tag>/write.csv out.json [commit]
+usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag>/fetch.csv gpurun_out/pmc_<tag>/write.csv out.json [commit [probe_meta.json]]
 """
 import json
 import sys
 
-CLASS_OF = [   # (substring of the (possibly left-truncated) mangled kernel name, grid predicate, class)
-    # probe: mapper batch 4 995 samples = 626 workgroups x 512 work-items, tracker batch 1 000 samples = 126 x 512
-    ("decode_fwd2ILb1", lambda g: g >= 150000, "decode_fwd"),
+# (substring of the (possibly left-truncated) mangled kernel name, predicate on the launch's work-item count, class).
+# One symbol serves the tracker's and the mapper's colour-stage forward: they are told apart by the work-item count of the
+# TRACKER's launch, which tools/pmc_probe.py writes to gpurun_out/pmc_probe_meta.json (base mix: 126 x 512 = 64 512).
+TRACK_ITEMS = [64512]
+
+
+def _is_track(g):
+    return g == TRACK_ITEMS[0]
+
+
+CLASS_OF = [
+    ("decode_fwd2ILb1", lambda g: not _is_track(g), "decode_fwd"),
     ("decode_fwd2ILb1", lambda g: True, "decode_fwd_track"),
     ("decode_fwd2ILb0", lambda g: True, "decode_fwd_geo"),
     ("2ILb0ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd"),
@@ -25,6 +34,7 @@ CLASS_OF = [   # (substring of the (possibly left-truncated) mangled kernel name
     ("k_dwE", lambda g: True, "dw_gemm"),
     ("AdamRowsSeg", lambda g: True, "adam"),
     ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn"),
+    ("k_map_ray_fused", lambda g: True, "map_ray"),
 ]
 DOUBLE_FETCH = {"geo_iter", "decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
                 "dw_gemm", "adam"}
@@ -54,6 +64,13 @@ def read(path, counter):
 
 
 def main():
+    meta_probe = None
+    if len(sys.argv) > 5:
+        try:
+            meta_probe = json.load(open(sys.argv[5]))
+            TRACK_ITEMS[0] = int(meta_probe["track_fwd_items"])
+        except Exception:
+            meta_probe = None
     fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
     res = {}
     for cls in sorted(set(fetch) | set(write)):
@@ -64,8 +81,8 @@ def main():
                         fetch_size_kib_raw=round(f_kib, 1), write_size_kib_raw=round(w_kib, 1),
                         fetch_doubled=cls in DOUBLE_FETCH,
                         source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/pmc_probe.py")
-    res["_meta"] = dict(commit=sys.argv[4] if len(sys.argv) > 4 else None, command="bash tools/pmc_run.sh <tag> (tools/pmc_probe.py)",
-                        passes=["--pmc FETCH_SIZE", "--pmc WRITE_SIZE"])
+    res["_meta"] = dict(commit=sys.argv[4] if len(sys.argv) > 4 else None, command="bash tools/gpu_round.sh <tag> pmc:<mix> (tools/pmc_probe.py)",
+                        passes=["--pmc FETCH_SIZE", "--pmc WRITE_SIZE"], probe=meta_probe)
     json.dump(res, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(res, indent=1))
 
