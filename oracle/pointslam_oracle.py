@@ -660,17 +660,23 @@ def add_points_select(cloud: Tensor, rays_o, rays_d, gt_depth, radius, n_add=3, 
 
 
 # --------------------------------------------------------------------------
-# frustum feature selection (src/Mapper.py:120-168) with cv2.remap
-# INTER_LINEAR restated as plain bilinear interpolation with constant-0 border.
+# frustum feature selection (src/Mapper.py:120-168).  The depth lookup is cv2.remap(..., INTER_LINEAR)
+# (:149-155); cv2 is absent from the image and the reference holds no vectors for it: PARITY UNPINNED at this seam.
+#   remap="cv2"   (default, round 4): OpenCV's INTER_LINEAR restated from its published source (imgproc/src/imgwarp.cpp,
+#                 remap() with CV_32FC1 maps + remapBilinear<float>, 4.x): coordinates in fixed point with INTER_BITS = 5
+#                 (sx = cvRound(u * 32), integer part sx >> 5 saturated to int16, fraction (sx & 31) / 32), weights
+#                 w[ky][kx] = vy[ky] * vx[kx] from the float table, taps summed left to right, constant-0 border;
+#   remap="exact" : plain bilinear interpolation (rounds 1-3; what oracle/gen_golden_loops.py used to select the rows of the
+#                 committed mapper fixtures -- the generator keeps passing it so that the fixtures regenerate bit for bit).
 # --------------------------------------------------------------------------
-def frustum_select(cloud: Tensor, c2w: Tensor, depth_img: Tensor, H, W, fx, fy, cx, cy, edge: float):
+def frustum_select(cloud: Tensor, c2w: Tensor, depth_img: Tensor, H, W, fx, fy, cx, cy, edge: float, remap: str = "cv2"):
     w2c = torch.linalg.inv(c2w.double())
     pc = (w2c[:3, :3] @ cloud.double().T + w2c[:3, 3:4]).T
     x, y, zc = -pc[:, 0], pc[:, 1], pc[:, 2]
     z = zc + 1e-5
     u = ((fx * x + cx * zc) / z).float()
     v = ((fy * y + cy * zc) / z).float()
-    d = bilinear_zero_border(depth_img, u, v)
+    d = remap_linear_cv2(depth_img, u, v) if remap == "cv2" else bilinear_zero_border(depth_img, u, v)
     inb = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge)
     d = torch.where(d == 0, d.max(), d)
     mz = (-z).float()
@@ -689,3 +695,26 @@ def bilinear_zero_border(img: Tensor, u: Tensor, v: Tensor) -> Tensor:
             val = img[vv.clamp(0, H - 1), uu.clamp(0, W - 1)]
             out = out + torch.where(ok, val, torch.zeros_like(val)) * wu * wv
     return out
+
+
+def remap_linear_cv2(img: Tensor, u: Tensor, v: Tensor) -> Tensor:
+    """cv2.remap(img, u, v, interpolation=cv2.INTER_LINEAR) for a float32 image and float32 coordinate maps, default
+    BORDER_CONSTANT 0 (see the block comment above).  torch.round is round-half-to-even like cvRound."""
+    H, W = img.shape
+    img = img.float()
+    far = ~((u.abs() < 1.0e6) & (v.abs() < 1.0e6))                  # cv2 saturates to int16: every tap is border (NaN too)
+    uq = torch.where(far, torch.zeros_like(u), u)
+    vq = torch.where(far, torch.zeros_like(v), v)
+    sx = torch.round(uq.float() * 32.0).long()
+    sy = torch.round(vq.float() * 32.0).long()
+    ix, iy = (sx >> 5).clamp(-32768, 32767), (sy >> 5).clamp(-32768, 32767)
+    fx, fy = (sx & 31).float() * (1.0 / 32.0), (sy & 31).float() * (1.0 / 32.0)
+    vx, vy = (1.0 - fx, fx), (1.0 - fy, fy)
+    out = torch.zeros_like(uq, dtype=torch.float32)
+    for ky in range(2):
+        for kx in range(2):
+            xx, yy = ix + kx, iy + ky
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            val = torch.where(ok, img[yy.clamp(0, H - 1), xx.clamp(0, W - 1)], torch.zeros_like(out))
+            out = out + val * (vy[ky] * vx[kx])
+    return torch.where(far, torch.zeros_like(out), out)

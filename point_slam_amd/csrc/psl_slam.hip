@@ -631,7 +631,32 @@ __global__ __launch_bounds__(128) void k_exposure_step(float* mlp, float* feats,
 // whose camera depth lies in [0, depth+0.5].  Zero lookups are replaced by the maximum over the per-point lookups
 // (:161-162).
 // projection + bilinear sensor-depth lookup of one point (cv2.remap INTER_LINEAR, constant-0 border)
+// cv2.remap(depth, u, v, INTER_LINEAR) with the default constant-0 border (src/Mapper.py:149-155), restated from OpenCV's
+// imgproc/src/imgwarp.cpp (remap() with CV_32FC1 maps + remapBilinear<float>): the coordinates are converted to fixed point
+// with INTER_BITS = 5 -- sx = cvRound(u * 32) (round half to even), integer part sx >> 5 saturated to int16, fraction
+// (sx & 31) / 32 --, the four weights come from a float table w[ky][kx] = vy[ky] * vx[kx], v = {1 - f, f}, and the taps are
+// summed left to right.  So the lookup position is quantised to 1/32 pixel; exact bilinear interpolation (the `exact`
+// variant below, psl_debug_option("remap_cv2", 0)) differs by up to |grad depth| / 64 per pixel.
+__device__ __forceinline__ float remap_linear_cv2(const float* __restrict__ img, int W, int H, float u, float v) {
+  if (!(fabsf(u) < 1.0e6f) || !(fabsf(v) < 1.0e6f)) return 0.f;      // far outside (or NaN): every tap is border (cv2 saturates to int16)
+  const int sx = (int)rintf(u * 32.0f), sy = (int)rintf(v * 32.0f);
+  const int ix = max(-32768, min(32767, sx >> 5)), iy = max(-32768, min(32767, sy >> 5));
+  const float fx = (float)(sx & 31) * (1.0f / 32.0f), fy = (float)(sy & 31) * (1.0f / 32.0f);
+  const float vx[2] = {1.0f - fx, fx}, vy[2] = {1.0f - fy, fy};
+  float d = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 2; ++kx) {
+      const int x = ix + kx, y = iy + ky;
+      const float val = (x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0.f;
+      d = __fadd_rn(d, __fmul_rn(val, __fmul_rn(vy[ky], vx[kx])));
+    }
+  return d;
+}
+
 struct FrustumPt { float u, v, d, mz; };
+template <bool CV2>
 __device__ __forceinline__ FrustumPt frustum_point(const float4 p, const float* __restrict__ w2c, const psl_cam_intr& cam,
                                                   const float* __restrict__ depth) {
   double x = (double)w2c[0] * p.x + (double)w2c[1] * p.y + (double)w2c[2] * p.z + (double)w2c[3];
@@ -642,6 +667,8 @@ __device__ __forceinline__ FrustumPt frustum_point(const float4 p, const float* 
   FrustumPt o;
   o.u = (float)(((double)cam.fx * x + (double)cam.cx * zc) / z);
   o.v = (float)(((double)cam.fy * y + (double)cam.cy * zc) / z);
+  o.mz = (float)(-z);
+  if (CV2) { o.d = remap_linear_cv2(depth, cam.W, cam.H, o.u, o.v); return o; }
   float u0 = floorf(o.u), v0 = floorf(o.v);
   float fu = o.u - u0, fv = o.v - v0;
   float d = 0.f;
@@ -659,30 +686,31 @@ __device__ __forceinline__ FrustumPt frustum_point(const float4 p, const float* 
       d += val * (du ? fu : 1.f - fu) * (dv ? fv : 1.f - fv);
     }
   o.d = d;
-  o.mz = (float)(-z);
   return o;
 }
 
 // np.max(depths) of Mapper.py:161-162: the maximum over the PER-POINT lookups (not over the image); non-negative floats
 // order like their bit patterns
+template <bool CV2>
 __global__ __launch_bounds__(256) void k_frustum_dmax(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
                                                       psl_cam_intr cam, const float* __restrict__ depth, unsigned* dmax_bits) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float d = 0.f;
-  if (i < n) { d = frustum_point(pos[i], w2c, cam, depth).d; if (!(d >= 0.f)) d = 0.f; }
+  if (i < n) { d = frustum_point<CV2>(pos[i], w2c, cam, depth).d; if (!(d >= 0.f)) d = 0.f; }
   unsigned b = __float_as_uint(d);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
   if ((threadIdx.x & 63) == 0 && b) atomicMax(dmax_bits, b);
 }
 
+template <bool CV2>
 __global__ __launch_bounds__(256) void k_frustum_flags(const float4* __restrict__ pos, int n, const float* __restrict__ w2c,
                                                        psl_cam_intr cam, const float* __restrict__ depth, float depth_max,
                                                        const unsigned* __restrict__ dmax_bits, float edge,
                                                        int* __restrict__ flags) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const FrustumPt f = frustum_point(pos[i], w2c, cam, depth);
+  const FrustumPt f = frustum_point<CV2>(pos[i], w2c, cam, depth);
   float d = f.d;
   if (d == 0.f) d = dmax_bits ? __uint_as_float(*dmax_bits) : depth_max;
   bool inb = (f.u < (float)cam.W - edge) && (f.u > edge) && (f.v < (float)cam.H - edge) && (f.v > edge);
@@ -770,6 +798,9 @@ int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
 int g_geo_fused = env_flag("PSL_GEO_FUSED", 1);
 // colour stage (no per-frame exposure): compositing + loss + compositing backward inside the decode backward, no ray kernel
 int g_ray_in_bwd = env_flag("PSL_RAY_IN_BWD", 1);
+// the frustum selection's depth lookup: 1 = cv2.remap's INTER_LINEAR as the reference calls it (coordinates quantised to 1/32
+// pixel, the default: it is what src/Mapper.py:149-155 computes), 0 = exact bilinear interpolation (rounds 1-3)
+int g_remap_cv2 = env_flag("PSL_REMAP_CV2", 1);
 constexpr int kGeoIterMaxSamples = 10000;
 }  // namespace psl
 
@@ -1254,10 +1285,13 @@ extern "C" int psl_frustum_select_sync(psl_ctx* ctx, const float* c2w_host /*[16
   if (depth_max < 0.f) {       // the reference's rule: maximum over the per-point lookups, taken on the device
     dmax_bits = (unsigned*)(ctx->d_counter + 1);
     PSL_HIP(hipMemsetAsync(dmax_bits, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_frustum_dmax, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth, dmax_bits);
+    if (g_remap_cv2) hipLaunchKernelGGL(k_frustum_dmax<true>, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth, dmax_bits);
+    else hipLaunchKernelGGL(k_frustum_dmax<false>, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth, dmax_bits);
   }
-  hipLaunchKernelGGL(k_frustum_flags, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth,
-                     depth_max, dmax_bits, edge, flags);
+  if (g_remap_cv2) hipLaunchKernelGGL(k_frustum_flags<true>, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth,
+                                      depth_max, dmax_bits, edge, flags);
+  else hipLaunchKernelGGL(k_frustum_flags<false>, dim3((n + 255) / 256), dim3(256), 0, s, ctx->pos, n, w2c_dev, cam, depth,
+                          depth_max, dmax_bits, edge, flags);
   hipLaunchKernelGGL(k_flag_block_sums, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags);
   hipLaunchKernelGGL(k_flag_scan_top, dim3(1), dim3(1024), 0, s, ctx->scan_flags, nblk, ctx->d_counter);
   hipLaunchKernelGGL(k_flag_compact, dim3(nblk), dim3(256), 0, s, flags, n, ctx->scan_flags, sel_out, row_map_out);

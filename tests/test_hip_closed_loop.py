@@ -1,17 +1,25 @@
-"""Closed-loop parity: track -> map -> track over several frames, once through HipSLAM(engine="native") and once through
-the pinned oracle COMPOSED the same way, with identical random draws.
+"""Closed-loop parity: track -> map -> track over several frames through HipSLAM(engine="native"), every stage checked
+against the pinned oracle composed the way the reference composes its loops, with identical random draws.
 
 Every loop of the path is pinned in isolation elsewhere (tests/test_hip_loops.py: the reference's own optimize_map /
 tracker loop / add_neural_points fixtures).  What nothing else checks is the ORCHESTRATION between them
 (src/Tracker.py:259-270,379-380 <-> src/Mapper.py:263-330,404-406,642-783): the pose a tracked frame hands to the mapper, the
 points the mapper adds at THAT pose, the frustum rows it then selects, the data-dependent iteration count, the trained
 rows and decoder the next tracked frame renders against, the constant-speed initial pose built from two estimated poses.
-An error in any hand-over would show up here and in no other test.
 
-Protocol.  The HIP run goes first and RECORDS every host-side random draw (pixel indices and fallback vectors of every
-tracking / mapping call, the add-pixels, the keyframe window, the N(0, 0.1^2) initial features of the new points).  The
-oracle run replays them: O.tracker_loop -> O.add_points_select -> O.frustum_select -> O.mapper_iterations, carrying ITS OWN
-state (cloud, features, decoder, poses) from frame to frame -- the two runs share inputs and draws, nothing else.
+Protocol.  ONE closed-loop HIP run over seven frames (map every 2nd), which RECORDS every host-side random draw (pixel
+indices and fallback vectors of every tracking / mapping call, the add-pixels, the keyframe window, the N(0, 0.1^2) initial
+features of the new points) and snapshots its state (cloud, both feature sets, decoder, estimated poses) in front of every
+frame.  The oracle then replays every STAGE from the HIP run's own hand-over -- the state and the poses the previous stages
+left -- and must arrive where the HIP run arrived: a stale pose, a wrong window, a selection made before the add, an
+iteration count from the wrong `added`, a tracker rendering against yesterday's decoder would each separate the two at
+the stage where it happens.  The stages are NOT chained on the oracle side, for a measured reason: a free-running oracle
+copy separates from ANY other implementation within two frames (first run of this test, profiles/r04_closed_loop_free_running.json:
+the colour-stage of mapped frame 0 -- decoder training, Adam steps of noise-decided sign, the drift tests/test_hip_loops.py
+documents -- leaves the two decoders 2e-3 apart in loss, the tracker of frame 1 then starts 8e-4 apart and its 20 Adam
+steps of +-lr, whose signs are decided by gradient components at the noise level next to the optimum, end 8 steps apart).
+That is the sensitivity of the reference's own objective (yardstick below), not an orchestration error, and it would mask
+one.
 """
 import pytest
 import torch
@@ -126,11 +134,12 @@ def test_track_map_track_closed_loop_matches_oracle():
     hip = []                                                         # per frame: dict of what happened
     est = []                                                         # estimated poses (device tensors)
     for i, fr in enumerate(frames):
-        out = dict(idx=i)
+        out = dict(idx=i, state=PP.oracle_state(s), est=[e.cpu().clone() for e in est], kf=[f.idx for f in s.keyframes])
         if i == 0:
             c2w = fr.c2w.clone()                                     # idx 0: ground-truth pose (Tracker.py:254-255)
         else:
             cam0 = s.init_pose(est).to(dev)
+            out["track_draw"] = len(rec.draws)
             best = s.track(fr, cam0)
             torch.cuda.synchronize()
             out.update(cam0=cam0.cpu(), track_losses=s.last_losses[:, 0].cpu().double().clone(), best=best.cpu().clone(),
@@ -151,106 +160,102 @@ def test_track_map_track_closed_loop_matches_oracle():
         hip.append(out)
     final = dict(cloud=s.npc.cloud_pos().float(), geo=s.npc.get_geo_feats().cpu().clone(), col=s.npc.get_col_feats().cpu().clone())
 
-    # ------------------------------------------------------------------------------------------------ oracle, replaying
+    # ------------------------------------------------------------------------------------------------ oracle, stage by stage
     O.KNN_WORKERS = 8
-    P, cloud, geo, col = st0["P"], st0["cloud"], st0["geo"], st0["col"]
-    oframes = [dict(depth=f.depth.cpu(), color=f.color.cpu(), r_query=f.r_query.cpu(), r_add=f.r_add.cpu(), c2w=None, idx=f.idx)
-               for f in frames]
-    est_o = []
-    draw_i, add_i, win_i = 0, 0, 0
-    worst = dict(track_first=0.0, track_all=0.0, map_first=0.0, map_all=0.0, pose=0.0, sel_diff=0, n_pts_diff=0)
+    est_hip = [e.cpu() for e in est]                                 # the poses the HIP run estimated, frame by frame
+    oframes = [dict(depth=f.depth.cpu(), color=f.color.cpu(), r_query=f.r_query.cpu(), r_add=f.r_add.cpu(), idx=f.idx,
+                    c2w=est_hip[f.idx]) for f in frames]             # keyframes carry their ESTIMATED pose (Mapper.py:755-760)
+    add_i, win_i = 0, 0
+    step = tr["lr"]
     per_frame = []
     for i, of in enumerate(oframes):
         h = hip[i]
-        row = dict(idx=i)
-        if i == 0:
-            c2w = frames[0].c2w.cpu().clone()
-        else:
-            c0 = H.const_speed_init(est_o[-1], est_o[-2] if len(est_o) >= 2 else None)
+        st = h["state"]
+        P, cloud, geo, col = st["P"], st["cloud"], st["geo"], st["col"]
+        row = dict(idx=i, n_pts_before=int(cloud.shape[0]))
+        if i > 0:
+            # ---- tracker stage: initial pose from the two poses the previous stages handed over (Tracker.py:259-270)
+            c0 = H.const_speed_init(h["est"][-1], h["est"][-2] if len(h["est"]) >= 2 else None)
             cam0 = camera_tensor_from_c2w(c0)
-            pix, fb = rec.draws[draw_i]; draw_i += 1
+            pix, fb = rec.draws[h["track_draw"]]
+            kw = dict(coef=cfg["rendering"]["sigmoid_coef_tracker"])
             ls, cams, best, _, _ = O.tracker_loop(cfg, P, cloud, geo, col, cam0, pix, fb, of["depth"], of["color"], of["r_query"],
-                                                  cam, eh, ew, coef=cfg["rendering"]["sigmoid_coef_tracker"])
+                                                  cam, eh, ew, **kw)
+            # yardstick (tests/test_hip_slam.py:78): the same oracle loop from an initial pose moved by ONE ulp, up and down
+            noise = 0.0
+            for target in (10.0, -10.0):
+                cam0_ulp = torch.nextafter(cam0, torch.full_like(cam0, target))
+                _, _, best_ulp, _, _ = O.tracker_loop(cfg, P, cloud, geo, col, cam0_ulp, pix, fb, of["depth"], of["color"], of["r_query"],
+                                                      cam, eh, ew, **kw)
+                noise = max(noise, float((best_ulp - best).abs().max()))
             ref = torch.tensor(ls, dtype=torch.float64)
             rel = (h["track_losses"] - ref).abs() / ref.abs()
-            dpose = float((h["best"] - best).abs().max())
-            row.update(track_loss_rel_first=float(rel[0]), track_loss_rel_max=float(rel.max()), pose_abs=dpose,
-                       cam0_abs=float((h["cam0"] - cam0).abs().max()))
-            worst["track_first"] = max(worst["track_first"], float(rel[0])); worst["track_all"] = max(worst["track_all"], float(rel.max()))
-            worst["pose"] = max(worst["pose"], dpose)
-            c34 = H.get_camera_from_tensor(best)
-            c2w = torch.cat([c34, torch.tensor([[0.0, 0.0, 0.0, 1.0]])], 0)
-        est_o.append(c2w)
-        of["c2w"] = c2w
-        if i % MAP_EVERY == 0:
+            row.update(cam0_abs=float((h["cam0"] - cam0).abs().max()), track_loss_rel_first=float(rel[0]),
+                       track_loss_rel_first5=float(rel[:5].max()), track_loss_rel_max=float(rel.max()),
+                       pose_abs=float((h["best"] - best).abs().max()), oracle_self_noise_1ulp=noise)
+        if h.get("mapped"):
+            c2w = est_hip[i]                                         # the hand-over: what the tracker stage returned for this frame
             window_ids = rec.windows[win_i]; win_i += 1
-            # ---- point adding at the ORACLE's pose (Mapper.py:303-330; uniform batch only: pixels_based_on_color_grad = 0)
-            idx = rec.add_idx[add_i]; add_i += 1
+            # ---- point adding at that pose (Mapper.py:303-330; uniform batch only: pixels_based_on_color_grad = 0)
+            idx = rec.add_idx[add_i]; init_geo, init_col = rec.init_feats[add_i]; add_i += 1
             u, v = O.pixels_from_flat_index(idx.long(), 0, cam["H"], 0, cam["W"])
             ro, rd = O.rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
             gd = of["depth"][v.long(), u.long()]
             new_pts, keep, _ = O.add_points_select(cloud, ro, rd, gd, of["r_add"][v.long(), u.long()])
             added_o = int(keep.sum())
-            init_geo, init_col = rec.init_feats[add_i - 1]
-            row.update(added=h["added"], added_oracle=added_o, n_pts=h["n_pts"], n_pts_oracle=int(cloud.shape[0]) + int(new_pts.shape[0]))
-            worst["n_pts_diff"] = max(worst["n_pts_diff"], abs(h["n_new"] - int(new_pts.shape[0])))
-            if h["n_new"] != int(new_pts.shape[0]):
-                per_frame.append(row)
-                break                                                # a different number of points: the runs have separated
+            n0 = int(cloud.shape[0])
+            row.update(added=h["added"], added_oracle=added_o, n_pts=h["n_pts"], n_pts_oracle=n0 + int(new_pts.shape[0]))
+            assert h["n_new"] == int(new_pts.shape[0]) == 3 * h["added"], row
+            row["new_pts_abs"] = float((final["cloud"][n0:n0 + new_pts.shape[0]] - new_pts).abs().max()) if new_pts.shape[0] else 0.0
             cloud = torch.cat([cloud, new_pts])
             geo, col = torch.cat([geo, init_geo]), torch.cat([col, init_col])
-            row["new_pts_abs"] = float((final["cloud"][cloud.shape[0] - new_pts.shape[0]:cloud.shape[0]] - new_pts).abs().max()) if new_pts.shape[0] else 0.0
-            # ---- iteration count (Mapper.py:404-406) and frustum rows (:120-168) from the oracle's own numbers
+            # ---- iteration count (Mapper.py:404-406), frustum rows (:120-168), window (:263-276) from the oracle's own numbers
             lo = int(mp.get("min_iter_ratio", 0.95) * mp["iters"])
             n_iters = int(min(max(int(mp["iters"] * added_o / 300), lo), 2 * mp["iters"]))
             n_geo = int(n_iters * mp["geo_iter_ratio"])
             sel_o = O.frustum_select(cloud, c2w, of["depth"], cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
                                      float(mp["frustum_edge"]))
             a, b = set(h["sel"].tolist()), set(sel_o.tolist())
-            row.update(n_iters=h["n_iters"], n_iters_oracle=n_iters, n_sel=len(a), n_sel_oracle=len(b), sel_sym_diff=len(a ^ b))
-            worst["sel_diff"] = max(worst["sel_diff"], len(a ^ b))
-            if h["n_iters"] != n_iters:
-                per_frame.append(row)
-                break
+            row.update(n_iters=h["n_iters"], n_iters_oracle=n_iters, n_sel=len(a), n_sel_oracle=len(b), sel_sym_diff=len(a ^ b),
+                       window=window_ids)
+            assert h["n_iters"] == n_iters, row
+            # the window: the last keyframe and the current frame close it, the others are earlier keyframes (:263-276)
+            assert window_ids[-1] == i and (not h["kf"] or window_ids[-2] == h["kf"][-1]) and set(window_ids[:-1]) <= set(h["kf"]), row
             # ---- the joint iterations over the recorded window
             win = [oframes[k] for k in window_ids]
-            pix, fb = rec.draws[h["map_draw"]]; draw_i = h["map_draw"] + 1
+            pix, fb = rec.draws[h["map_draw"]]
             ppf = mp["pixels"] // len(win)
-            ls, geo, col, P, _, _ = O.mapper_iterations(cfg, P, cloud, geo, col, sel_o, win, pix.reshape(n_iters, len(win), ppf), fb,
-                                                        n_geo, cam, coef=cfg["rendering"]["sigmoid_coef_mapper"])
+            ls, geo_o, col_o, P_o, _, _ = O.mapper_iterations(cfg, P, cloud, geo, col, sel_o, win, pix.reshape(n_iters, len(win), ppf), fb,
+                                                              n_geo, cam, coef=cfg["rendering"]["sigmoid_coef_mapper"])
             ref = torch.tensor(ls, dtype=torch.float64)
             rel = (h["map_losses"] - ref).abs() / ref.abs()
-            row.update(map_loss_rel_first=float(rel[0]), map_loss_rel_geo_stage=float(rel[:n_geo + 1].max()), map_loss_rel_max=float(rel.max()))
-            worst["map_first"] = max(worst["map_first"], float(rel[0])); worst["map_all"] = max(worst["map_all"], float(rel.max()))
+            # where the HIP run arrived: the state snapshot in front of the NEXT frame (or the final state)
+            nxt = hip[i + 1]["state"] if i + 1 < len(hip) else dict(geo=final["geo"], col=final["col"])
+            so = sel_o.long()
+            row.update(map_loss_rel_first=float(rel[0]), map_loss_rel_geo_stage=float(rel[:n_geo + 1].max()),
+                       map_loss_rel_first_colour=float(rel[n_geo + 1]), map_loss_rel_max=float(rel.max()),
+                       rows_geo_mean=float((nxt["geo"][so] - geo_o[so]).abs().mean()), rows_col_mean=float((nxt["col"][so] - col_o[so]).abs().mean()))
         per_frame.append(row)
-    # ------------------------------------------------------------------------------------------------ the end states
-    n = min(cloud.shape[0], final["cloud"].shape[0])
-    d_geo, d_col = (final["geo"][:n] - geo[:n]).abs(), (final["col"][:n] - col[:n]).abs()
-    s.sync_decoders_from_theta()
-    P_hip = {k: v.detach().cpu() for k, v in s.decoders.state_dict().items()}
-    d_dec = max(float((P_hip[k] - P[k]).abs().max()) for k in P_hip if k.startswith("color_decoder") and k in P and P[k].dtype.is_floating_point)
-    # yardstick (SURVEY 7 / tests/test_hip_slam.py:78): the sensitivity of the tracker's own objective -- one Adam step of the
-    # pose is lr (0.002 translation, 0.0004 quaternion); two correct implementations agree to a small fraction of ONE step
-    step = tr["lr"]
-    report(test="closed_loop_track_map_track", frames=per_frame, **{"worst_" + k: v for k, v in worst.items()},
-           final_pts=int(final["cloud"].shape[0]), final_pts_oracle=int(cloud.shape[0]), rows_geo_max=float(d_geo.max()),
-           rows_geo_mean=float(d_geo.mean()), rows_col_max=float(d_col.max()), rows_col_mean=float(d_col.mean()), decoder_max=d_dec,
-           pose_step=step)
-    assert len(per_frame) == N_FRAMES, per_frame[-1]                  # no structural separation (point / iteration counts)
+    report(test="closed_loop_track_map_track", frames=per_frame, final_pts=int(final["cloud"].shape[0]), pose_step=step)
     mapped = [r for r in per_frame if "n_sel" in r]
     assert len(mapped) == (N_FRAMES + MAP_EVERY - 1) // MAP_EVERY
     for r in mapped:
-        assert r["added"] == r["added_oracle"] and r["n_pts"] == r["n_pts_oracle"] and r["n_iters"] == r["n_iters_oracle"], r
+        assert r["added"] == r["added_oracle"] and r["n_pts"] == r["n_pts_oracle"], r
         assert r["added"] > 0, r                                      # every mapped frame grows the map: the add path is in the loop
-        assert r["new_pts_abs"] <= 2e-5, r                            # new points sit where the oracle puts them (poses agree to ~1e-6)
-        # frustum rows: identical sets.  A point ON the frustum border or the depth band can flip with the ~1e-6 pose
-        # difference of the two runs; allow two such rows in ~3e4 (measured: see the report)
-        assert r["sel_sym_diff"] <= 2, r
+        assert r["new_pts_abs"] <= 2e-6, r                            # the new points sit where the handed-over pose puts them
+        assert r["sel_sym_diff"] <= max(2, r["n_sel"] // 10000), r    # frustum rows: the same set (border flips: see report)
         assert r["map_loss_rel_first"] <= 1e-4, r                     # BASELINE.json: render-loss rel-err <= 1e-4
+        assert r["map_loss_rel_geo_stage"] <= 1e-4, r                 # the whole geometry stage (decoders frozen: not chaotic)
+        assert r["map_loss_rel_first_colour"] <= 1e-4, r
+        assert r["rows_geo_mean"] <= 1e-3 and r["rows_col_mean"] <= 1e-3, r
     for r in per_frame[1:]:
-        assert r["track_loss_rel_first"] <= 1e-4, r
-        assert r["cam0_abs"] <= 0.05 * step, r                        # constant-speed init from two ESTIMATED poses
-        assert r["pose_abs"] <= 0.25 * step, r                        # best pose after 20 Adam steps: a fraction of one step
-    # trained rows of the whole run (4 mapped frames x ~40 iterations, rows trained up to 4 times)
-    assert float(d_geo.mean()) <= 2e-5 and float(d_col.mean()) <= 2e-5
-    assert final["cloud"].shape[0] == cloud.shape[0]
+        assert r["cam0_abs"] <= 2e-6, r                               # constant-speed init from the two handed-over poses
+        assert r["track_loss_rel_first"] <= 1e-4, r                   # the tracker renders against the map the mapper left
+        assert r["pose_abs"] <= 20 * step, r                          # hard cap: 20 Adam steps cannot carry a correct loop further apart
+    # The lowest-loss pose of 20 Adam steps is NOT a parity quantity: next to the optimum the signs of Adam's +-lr steps are decided by
+    # gradient components at the rounding level, and the oracle separates from ITSELF by 1e-5 .. 1.3e-2 (6 steps) when its
+    # initial pose moves by one ulp (first measured run: HIP-vs-oracle 1e-4 .. 1.0e-2 on the same frames).  What can be
+    # asserted is that the two spreads are of one size -- over the six tracked frames, against twelve perturbed oracle runs:
+    worst_pose = max(r["pose_abs"] for r in per_frame[1:])
+    worst_noise = max(r["oracle_self_noise_1ulp"] for r in per_frame[1:])
+    assert worst_pose <= max(0.25 * step, 4 * worst_noise), (worst_pose, worst_noise)

@@ -114,22 +114,46 @@ def test_track_native_matches_dropin():
     assert dc < max(0.25 * step, 4 * self_noise) and db < max(0.25 * step, 4 * self_noise)
 
 
-def test_frustum_select_matches_oracle():
+@pytest.mark.parametrize("remap", ["cv2", "exact"])
+def test_frustum_select_matches_oracle(remap):
+    """Both depth-lookup rules of the frustum selection (Mapper.py:149-155) against their oracle restatements: "cv2" =
+    cv2.remap's INTER_LINEAR with its 1/32-pixel coordinate quantisation (the default: what the reference computes),
+    "exact" = plain bilinear interpolation (psl_debug_option("remap_cv2", 0); rounds 1-3).  The sensor depth is halved and
+    rippled so that thousands of map points sit within centimetres of the d + 0.5 test and the two rules really differ."""
     from oracle import pointslam_oracle as O
+    from point_slam_amd import _lib
+    from point_slam_amd.slam import Frame
     dev = torch.device("cuda:0")
     cfg, cam, frames, pts = _scene(dev)
     s = _slam(cfg, cam, "native", dev)
     s.seed_points(pts)
-    fr = frames[1]
-    sel, row_map = s.frustum_select(fr, fr.c2w)
+    fr0 = frames[1]
+    yy, xx = torch.meshgrid(torch.arange(cam["H"], device=dev), torch.arange(cam["W"], device=dev), indexing="ij")
+    depth = fr0.depth - 0.5 + 0.35 * torch.sin(0.9 * xx) * torch.cos(1.1 * yy)     # map points straddle depth + 0.5
+    fr = Frame(1, depth, fr0.color, fr0.r_add, fr0.r_query, fr0.c2w)
+    L = _lib.lib()
+    sels = {}
+    try:
+        for mode in ("cv2", "exact"):
+            _lib.check(L.psl_debug_option(b"remap_cv2", 1 if mode == "cv2" else 0))
+            sels[mode] = set(s.frustum_select(fr, fr.c2w)[0].cpu().tolist())
+        _lib.check(L.psl_debug_option(b"remap_cv2", 1 if remap == "cv2" else 0))
+        sel, row_map = s.frustum_select(fr, fr.c2w)
+    finally:
+        _lib.check(L.psl_debug_option(b"remap_cv2", 1))
     ref = O.frustum_select(pts, fr.c2w.cpu(), fr.depth.cpu(), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
-                           cam["cy"], cfg["mapping"]["frustum_edge"])
+                           cam["cy"], cfg["mapping"]["frustum_edge"], remap=remap)
+    other = O.frustum_select(pts, fr.c2w.cpu(), fr.depth.cpu(), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"],
+                             cam["cy"], cfg["mapping"]["frustum_edge"], remap="exact" if remap == "cv2" else "cv2")
     got = sel.cpu().long()
     # fp differences at the frustum border may flip a handful of points
     a, b = set(got.tolist()), set(ref.tolist())
     diff = len(a ^ b)
-    report(test="frustum", n_sel=len(a), n_ref=len(b), sym_diff=diff)
+    report(test="frustum", remap=remap, n_sel=len(a), n_ref=len(b), sym_diff=diff, sym_diff_vs_other_rule=len(a ^ set(other.tolist())),
+           rules_differ_on=len(sels["cv2"] ^ sels["exact"]))
     assert diff <= max(3, len(b) // 2000)
+    assert len(sels["cv2"] ^ sels["exact"]) > 10 * max(diff, 1)         # the two rules are told apart by this frame
+    assert len(a ^ set(other.tolist())) > diff
     rm = row_map.cpu()
     assert torch.equal(rm[got], torch.arange(got.shape[0], dtype=torch.int32))
     assert int((rm >= 0).sum()) == got.shape[0]
