@@ -247,7 +247,10 @@ def test_track_map_track_closed_loop_matches_oracle():
         assert r["map_loss_rel_first"] <= 1e-4, r                     # BASELINE.json: render-loss rel-err <= 1e-4
         assert r["map_loss_rel_geo_stage"] <= 1e-4, r                 # the whole geometry stage (decoders frozen: not chaotic)
         assert r["map_loss_rel_first_colour"] <= 1e-4, r
-        assert r["rows_geo_mean"] <= 1e-3 and r["rows_col_mean"] <= 1e-3, r
+        # where the stage ARRIVED: the rows after 38-80 iterations, the colour stage among them (decoder training: the drift the
+        # 140-iteration test documents; measured 4e-6 .. 1.9e-3 mean over four runs).  Training the wrong rows, or against the
+        # wrong window / decoder, leaves O(0.1).
+        assert r["rows_geo_mean"] <= 1e-2 and r["rows_col_mean"] <= 1e-2, r
     for r in per_frame[1:]:
         assert r["cam0_abs"] <= 2e-6, r                               # constant-speed init from the two handed-over poses
         assert r["track_loss_rel_first"] <= 1e-4, r                   # the tracker renders against the map the mapper left

@@ -95,3 +95,56 @@ def test_block_trace_skips_untraced_workgroups(tmp_path):
     p.write_text(json.dumps(rec) + "\n")
     out = _run("block_trace.py", str(p))
     assert "first start -> last end 30.0 us" in out and "colour  : 2 workgroups" in out and "geometry: 2 workgroups" in out
+
+
+def test_decode_kernels_fit_their_register_budget_without_scratch():
+    """tools/kernel_resources.py cross-compiles the decode kernels for gfx950 and reads hipcc's own metadata: every one of
+    them free of scratch, and the two colour-stage kernels that must run TWO 512-thread workgroups per CU (4 waves per SIMD)
+    within 128 VGPRs -- round 3 shipped the forward with 19 spilled registers and the tracker's backward at 189 VGPRs (one
+    workgroup per CU, 16.5 % of peak)."""
+    import os
+    import shutil
+    import pytest
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not installed")
+    from tools import kernel_resources as KR
+    seen = {}
+    for f in ("psl_decode_fwd2.hip", "psl_decode_bwd2.hip", "psl_decode_geo.hip"):
+        for k in KR.resources(os.path.join(KR.CSRC, f)):
+            seen[k["name"]] = k
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+    two_per_cu = [k for n, k in seen.items() if ("k_decode_fwd2ILb1E" in n or "k_decode_bwd2ILb0ELb1E" in n or "k_decode_bwd2ILb1ELb1E" in n)]
+    assert len(two_per_cu) == 3
+    for k in two_per_cu:
+        assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["max_flat_workgroup_size"] == 512, k
+
+
+def test_kernel_resources_parses_metadata():
+    from tools import kernel_resources as KR
+    text = """
+amdhsa.kernels:
+  - .agpr_count:     4
+    .args: []
+    .group_segment_fixed_size: 1024
+    .max_flat_workgroup_size: 256
+    .name:           _Z3fooPf
+    .private_segment_fixed_size: 16
+    .sgpr_count:     20
+    .sgpr_spill_count: 0
+    .vgpr_count:     33
+    .vgpr_spill_count: 2
+  - .agpr_count:     0
+    .group_segment_fixed_size: 0
+    .max_flat_workgroup_size: 64
+    .name:           _Z3barPf
+    .private_segment_fixed_size: 0
+    .sgpr_count:     8
+    .sgpr_spill_count: 0
+    .vgpr_count:     7
+    .vgpr_spill_count: 0
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+"""
+    ks = KR.parse_asm(text)
+    assert [k["name"] for k in ks] == ["_Z3fooPf", "_Z3barPf"]
+    assert ks[0]["vgpr_count"] == 33 and ks[0]["agpr_count"] == 4 and ks[0]["vgpr_spill_count"] == 2 and ks[0]["private_segment_fixed_size"] == 16
+    assert ks[1]["max_flat_workgroup_size"] == 64

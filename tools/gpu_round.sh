@@ -28,8 +28,8 @@ for step in "$@"; do
   case $kind in
     tests)
       rm -f $O/parity_report.jsonl
-      if [ -n "$a1" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$(sp "$a1")" --durations=8 2>&1 | tail -40 > $O/${TAG}_pytest_gpu.log
-      else timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 2>&1 | tail -40 > $O/${TAG}_pytest_gpu.log; fi
+      if [ -n "$a1" ]; then timeout 1500 python -m pytest tests -q -m gpu -k "$(sp "$a1")" --durations=8 2>&1 | tail -40 > $O/${TAG}_pytest_gpu.log
+      else timeout 1500 python -m pytest tests -q -m gpu --durations=8 2>&1 | tail -40 > $O/${TAG}_pytest_gpu.log; fi
       tail -3 $O/${TAG}_pytest_gpu.log; grep -E "^(FAILED|ERROR)|Error|assert" $O/${TAG}_pytest_gpu.log | head -10
       [ -f $O/parity_report.jsonl ] && cp $O/parity_report.jsonl $O/${TAG}_parity_report.jsonl ;;
     bench)
