@@ -75,9 +75,12 @@ def build_world(args, rank, world, dev):
     track_only = getattr(args, "track_only", False)
     if track_only:
         # the fixed cloud of config 1: all of it around the stretch of the trajectory the run tracks (t = 200 + 2 i)
+        # 0.5 trajectory units per frame (~1.4 cm, 0.1 degrees: a Replica-like camera speed; 50 k points cover the stretch
+        # 405 frames see about as densely as the headline's 1 M cover the whole room)
         n_fr = args.warmup + 2 * args.steps
-        pts = syn.seed_cloud(cam, args.points, n_views=48, seed=cfg["setup_seed"], t0=190.0, dt=(2.0 * n_fr + 20.0) / 47.0)
-        args._train_span = 2.0 * n_fr + 10.0
+        args._unit_per_frame = 0.5
+        pts = syn.seed_cloud(cam, args.points, n_views=48, seed=cfg["setup_seed"], t0=190.0, dt=(0.5 * n_fr + 20.0) / 47.0)
+        args._train_span = 0.5 * n_fr + 10.0
     else:
         pts = syn.seed_cloud(cam, args.points, n_views=64, seed=cfg["setup_seed"], holes=not args.saturated_map)
     slam.seed_points(pts)
@@ -85,11 +88,11 @@ def build_world(args, rank, world, dev):
         # A fixed cloud with RANDOM features localises nothing: tracked in closed loop the pose runs away within ten frames
         # (tools/track_probe.py --train-frames 0: 1 m after 10 frames, 5.7 m after 30) and the tracker's rays leave the map, which
         # is not config 1's workload.  Untimed set-up therefore: the features (and the colour decoder) are TRAINED by mapping a
-        # keyframe every 8 trajectory units at its true pose, no point adding (the cloud stays as seeded); afterwards the closed
+        # keyframe every 5 trajectory units at its true pose, no point adding (the cloud stays as seeded); afterwards the closed
         # loop holds the trajectory to millimetres (same probe: 0.05-0.41 cm over 60 frames; this run: config.ate_rmse_cm).
-        n_train = int(args._train_span / 8.0) + 2
+        n_train = int(args._train_span / 5.0) + 2
         for k in range(n_train):
-            c2w = syn.pose(195.0 + 8.0 * k, dev)
+            c2w = syn.pose(195.0 + 5.0 * k, dev)
             depth, color = syn.render_frame(cam, c2w)
             r_add, r_q = syn.dynamic_radii(color, cfg)
             kf = Frame(-1 - k, depth, color, r_add, r_q, c2w)
@@ -106,7 +109,7 @@ def build_world(args, rank, world, dev):
     g = torch.Generator().manual_seed(1000 + rank)
     for i in range(-4, n_total):
         # 2 trajectory units per frame = ~5.6 cm and ~0.4 degrees ("5 cm / 1 deg per frame"): every mapped frame sees new surface
-        t = float(rank + world * max(i, 0)) * 2.0 if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
+        t = float(rank + world * max(i, 0)) * getattr(args, "_unit_per_frame", 2.0) if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
         t = t + 200.0 if i >= 0 else t + 170.0
         c2w = syn.pose(t, dev)
         depth, color = syn.render_frame(cam, c2w)

@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=8)
     ap.add_argument("--new-locations", type=int, default=1000)
     ap.add_argument("--rows", type=int, default=40000)
-    ap.add_argument("--repeats", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=25)
+    ap.add_argument("--warmup", type=int, default=3, help="calls left out of the percentiles (first-touch: RCCL communicator, allocator)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -81,6 +82,7 @@ def main():
             rr[:, 0] = rk.to(torch.int32).view(torch.float32); rr[:, 1:] = 0.02
             row_blocks.append(rr)
         torch.cuda.synchronize()
+        ms0 = torch.cuda.memory_stats()
         # exchange = _reconcile_rows (first all-gather) + decoder all-reduce + merge_new_points (second all-gather)
         t0 = time.perf_counter()
         tr.pending = row_blocks
@@ -97,13 +99,24 @@ def main():
         sync.n_base = npc.pts_num()
         torch.cuda.synchronize(); t3 = time.perf_counter()
         times.append((t3 - t0) * 1e3)
+        ms1 = torch.cuda.memory_stats()
+        # what the caching allocator did during the call: new segments = hipMalloc calls, freed segments = hipFree (a
+        # device-wide synchronisation)
         parts.append(dict(rows_ms=round((t1 - t0) * 1e3, 3), decoder_ms=round((t2_ - t1) * 1e3, 3), points_ms=round((t3 - t2_) * 1e3, 3),
-                          contributed=sum(counts), admitted=npc.pts_num() - n_base, rows_received=sync.last_stats.get("rows_received")))
-    steady = sorted(times[1:])
+                          contributed=sum(counts), admitted=npc.pts_num() - n_base, rows_received=sync.last_stats.get("rows_received"),
+                          segments_allocated=ms1["segment.all.allocated"] - ms0["segment.all.allocated"],
+                          segments_freed=ms1["segment.all.freed"] - ms0["segment.all.freed"],
+                          alloc_retries=ms1["num_alloc_retries"] - ms0["num_alloc_retries"],
+                          reserved_mb=round(ms1["reserved_bytes.all.current"] / 2**20)))
+    steady = sorted(times[a.warmup:])
     res = json.dumps(dict(metric="frame-parallel exchange wall time (device work + host, no wire)", unit="ms", points=a.points,
                           blocks=a.blocks, new_locations_per_block=a.new_locations, trained_rows_per_block=a.rows,
                           median_ms=round(steady[len(steady) // 2], 3), min_ms=round(steady[0], 3), max_ms=round(steady[-1], 3),
-                          first_call_ms=round(times[0], 3), per_call=parts[1:],
+                          p50_ms=round(steady[len(steady) // 2], 3), p90_ms=round(steady[int(0.9 * (len(steady) - 1))], 3), p100_ms=round(steady[-1], 3),
+                          calls=len(steady), warmup_calls_ms=[round(t, 3) for t in times[:a.warmup]],
+                          slow_calls=[dict(call=i, ms=round(times[i], 3), **parts[i]) for i in range(a.warmup, len(times)) if times[i] > 5.0],
+                          allocator_conf=os.environ.get("PYTORCH_HIP_ALLOC_CONF") or os.environ.get("PYTORCH_CUDA_ALLOC_CONF"),
+                          first_call_ms=round(times[0], 3), per_call=parts[a.warmup:],
                           backend=a.backend,
                           note="world of one process: the two all-gathers return this rank's records plus seven prepared blocks "
                                "(no wire time); the decoder all-reduce (240 KB) runs on the one-rank communicator"))
@@ -113,5 +126,18 @@ def main():
     dist.destroy_process_group()
 
 
+def summary(files):
+    for f in files:
+        try:
+            d = json.loads(open(f).read())
+            print(os.path.basename(f), "p50", d["p50_ms"], "p90", d["p90_ms"], "p100", d["p100_ms"], "allocator", d.get("allocator_conf"), "slow calls",
+                  [(c["call"], c["ms"], "rows", c["rows_ms"], "segs +%d -%d" % (c["segments_allocated"], c["segments_freed"])) for c in d["slow_calls"]])
+        except Exception as e:
+            print(f, "failed", e)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--summary":
+        summary(sys.argv[2:])
+    else:
+        main()

@@ -5,7 +5,8 @@
 # its own `timeout`, so a hung kernel costs one step, not the box.  Steps (arguments after ':' are comma-separated):
 #   tests[:<pytest -k expr>]      pytest -m gpu (-x), tail of the log -> <tag>_pytest_gpu.log
 #   bench[:<name>[:<args>]]       python bench.py <args> (args with ',' for ' ') -> <tag>_bench_<name>.json
-#   ab:<name>:<args>              the same bench line with PSL_LIB=_old/libpointslam_hip_r03.so and with this build, twice each
+#   ab:<name>:<args>              the same bench line with PSL_LIB=_old/libpointslam_hip_${AB_BASE:-r03}.so (the "r03" column) and with this
+#                                 build, twice each, on this one box
 #   sweep                         tools/roofline_sweep.py -> <tag>_roofline_sweep.json
 #   phases                        tools/phase_probe.py (PSL_DEBUG_PHASES) -> <tag>_phases.log
 #   blocks                        per-workgroup trace of the decode launches -> <tag>_block_trace.txt
@@ -38,7 +39,7 @@ for step in "$@"; do
       echo "bench $name: $(python tools/show_bench.py $O/${TAG}_bench_$name.json 2>&1 | grep -E 'FPS|frames' | head -2 | tr '\n' ' ')" ;;
     ab)
       for rep in 1 2; do
-        PSL_LIB=$PWD/_old/libpointslam_hip_r03.so timeout 600 python bench.py --no-cpu-baseline $(sp "$a2") 2>/dev/null | tail -1 > $O/${TAG}_ab_${a1}_r03_$rep.json
+        PSL_LIB=$PWD/_old/libpointslam_hip_${AB_BASE:-r03}.so timeout 600 python bench.py --no-cpu-baseline $(sp "$a2") 2>/dev/null | tail -1 > $O/${TAG}_ab_${a1}_r03_$rep.json
         timeout 600 python bench.py --no-cpu-baseline $(sp "$a2") 2>/dev/null | tail -1 > $O/${TAG}_ab_${a1}_new_$rep.json
         python - <<EOF
 import json
@@ -83,7 +84,9 @@ EOF
     knn)
       timeout 300 python tools/knn_roofline.py > $O/${TAG}_knn_roofline.log 2>&1; cp $O/knn_roofline.json $O/${TAG}_knn_roofline.json; tail -3 $O/${TAG}_knn_roofline.log ;;
     exchange)
-      timeout 300 python tools/exchange_timing.py --out $O/${TAG}_exchange_timing.json > $O/${TAG}_exchange.log 2>&1; tail -5 $O/${TAG}_exchange.log ;;
+      timeout 300 python tools/exchange_timing.py --out $O/${TAG}_exchange_timing.json > $O/${TAG}_exchange.log 2>&1
+      PYTORCH_HIP_ALLOC_CONF=expandable_segments:True timeout 300 python tools/exchange_timing.py --out $O/${TAG}_exchange_timing_expandable.json > $O/${TAG}_exchange2.log 2>&1
+      python tools/exchange_timing.py --summary $O/${TAG}_exchange_timing.json $O/${TAG}_exchange_timing_expandable.json ;;
     py)
       b=$(basename "$a1" .py)
       timeout 900 python $a1 $(sp "$a2") > $O/${TAG}_$b.log 2>&1; tail -15 $O/${TAG}_$b.log ;;
