@@ -424,11 +424,6 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   PSL_STAMP(0);
   const float* sWn = smem + L::oWn;
   if (relpos) nbr_stage_dma_b(WB, smem + L::oWn, wave, lane);      // F_theta's backward weights -> LDS; the loads fly during phase 0
-  // the last trunk layer's saved activations (written by the forward kernel: an HBM / remote-L2 round trip) and its fc_c
-  // fragments depend on nothing but the tile: requested here, they arrive behind phase 0 instead of standing exposed in front
-  // of the first layer (phase stamps: "L4 pre" 5 k cycles against 2 k for the other layers)
-  f32x4 y4_early = *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)4 * a.ws.Ppad + p0 + rl) * HC + wave * 16 + 4 * g);
-  f32x4 wc4_early[2] = {ldfragb(WB, bfirst(BL_CF4) + 0 * 8 + wave, lane), ldfragb(WB, bfirst(BL_CF4) + 1 * 8 + wave, lane)};
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -512,10 +507,10 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     auto ld_y = [&](int i) {
       return *reinterpret_cast<const f32x4*>(a.ws.c_y + ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g);
     };
-    f32x4 ynext = y4_early;
+    f32x4 ynext = ld_y(4);
     // fc_c fragments of the NEXT layer in flight during the current one: dL/dc is the first product of a layer and its
     // weights were the one load whose L2 latency stood exposed at every layer start (phase stamps: "pre" 3-5 k cycles)
-    f32x4 wcn[2] = {wc4_early[0], wc4_early[1]};
+    f32x4 wcn[2] = {ldfragb(WB, bfirst(BL_CF4) + 0 * 8 + nt, lane), ldfragb(WB, bfirst(BL_CF4) + 1 * 8 + nt, lane)};
     auto layer = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
       constexpr int BLs[5] = {BL_C0, BL_C1, BL_C2, BL_C3, BL_C4};

@@ -230,15 +230,6 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   constexpr int f1 = ffirst(FL_N1);
   const float* sWn = smem + L::oWn;
   if (relpos) nbr_stage_dma<kNbrFrags>(WF, smem + L::oWn, wave, WG / 64, lane);
-  // The feature row of this lane's (sample, neighbour) pair is requested NOW, from the neighbour list itself: behind the
-  // phase-0 barrier (list -> LDS -> barrier -> gather) the 128-byte rows -- first touch after the optimiser rewrote them,
-  // i.e. an HBM round trip -- stood exposed in front of F_theta's first MFMA (phase stamps: "gather+sincos" 7.5 k cycles).
-  const int i_pair = a.ws.I[(size_t)min(p0 + ((16 * wave + rl) >> 3), a.P - 1) * K + ((16 * wave + rl) & 7)];
-  f32x4 xf_early[2];
-  {
-    const float* frow = a.col_feats + (size_t)max(i_pair, 0) * C + 4 * g;
-    xf_early[0] = *reinterpret_cast<const f32x4*>(frow); xf_early[1] = *reinterpret_cast<const f32x4*>(frow + 16);
-  }
 
   // ---------------------------------------------------------------- phase 0: neighbours, weights (one thread per pair)
   if (t < TILE * K) {
@@ -275,12 +266,16 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   {
     const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane; 4 lanes (g) share a pair
     const int s = row >> 3;
-    const int i = i_pair;                      // == sI[row]
+    const int i = sI[row];
     const float wgt = sW[row];
     const size_t grow = (size_t)p0 * K + row;  // row of the per-pair save buffers
     f32x4 xf[2];
+    {
+      const float* frow = a.col_feats + (size_t)max(i, 0) * C + 4 * g;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(frow), v1 = *reinterpret_cast<const f32x4*>(frow + 16);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? xf_early[0][r] : 0.f; xf[1][r] = (i >= 0) ? xf_early[1][r] : 0.f; }
+      for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? v0[r] : 0.f; xf[1][r] = (i >= 0) ? v1[r] : 0.f; }
+    }
     f32x4 cc[2];
     if (relpos) {
       // F_theta input [sin(10) cos(10) | feat(32)] (decoder.py:371-378); this lane holds sin or cos of f = 2 s + (g >> 1)

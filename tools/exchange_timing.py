@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=8)
     ap.add_argument("--new-locations", type=int, default=1000)
     ap.add_argument("--rows", type=int, default=40000)
-    ap.add_argument("--repeats", type=int, default=25)
+    ap.add_argument("--repeats", type=int, default=63)
     ap.add_argument("--warmup", type=int, default=3, help="calls left out of the percentiles (first-touch: RCCL communicator, allocator)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--out", default=None)
