@@ -5,6 +5,7 @@
 # its own `timeout`, so a hung kernel costs one step, not the box.  Steps (arguments after ':' are comma-separated):
 #   tests[:<pytest -k expr>]      pytest -m gpu (-x), tail of the log -> <tag>_pytest_gpu.log
 #   bench[:<name>[:<args>]]       python bench.py <args> (args with ',' for ' ') -> <tag>_bench_<name>.json
+#   eb:<name>:<ENV=V,...>;<args>  bench.py --no-cpu-baseline <args> under the given environment -> <tag>_bench_<name>.json
 #   ab:<name>:<args>              the same bench line with PSL_LIB=_old/libpointslam_hip_${AB_BASE:-r03}.so (the "r03" column) and with this
 #                                 build, twice each, on this one box
 #   sweep                         tools/roofline_sweep.py -> <tag>_roofline_sweep.json
@@ -37,6 +38,10 @@ for step in "$@"; do
       name=${a1:-base}
       timeout 900 python bench.py $(sp "$a2") 2> $O/${TAG}_bench_$name.err | tail -1 > $O/${TAG}_bench_$name.json
       echo "bench $name: $(python tools/show_bench.py $O/${TAG}_bench_$name.json 2>&1 | grep -E 'FPS|frames' | head -2 | tr '\n' ' ')" ;;
+    eb)   # bench with environment: eb:<name>:<ENV=V,ENV=V>;<args>
+      envs="${a2%%;*}"; bargs="${a2#*;}"
+      env $(sp "$envs") timeout 900 python bench.py --no-cpu-baseline $(sp "$bargs") 2> $O/${TAG}_bench_$a1.err | tail -1 > $O/${TAG}_bench_$a1.json
+      echo "bench $a1 [$envs]: $(python tools/show_bench.py $O/${TAG}_bench_$a1.json 2>&1 | grep -E 'FPS|adam ' | tr '\n' ' ')" ;;
     ab)
       for rep in 1 2; do
         PSL_LIB=$PWD/_old/libpointslam_hip_${AB_BASE:-r03}.so timeout 600 python bench.py --no-cpu-baseline $(sp "$a2") 2>/dev/null | tail -1 > $O/${TAG}_ab_${a1}_r03_$rep.json
