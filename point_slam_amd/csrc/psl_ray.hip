@@ -399,13 +399,19 @@ __device__ __forceinline__ void adam_par_segment(const AdamParSeg& par, int blk,
     for (int j = 1; j < kNumColorParams; ++j) if (e >= poff(j)) ent = j;
     const int n_chunks = par.ra.chunks_of_entry[ent];
     const float* sl = par.slabs + par.ra.slab_off[ent] + (e - poff(ent));
-    t = 0.f;
+    // eight chunk values in flight per trip (a serial walk over the ~40 chunks of F_theta's layers is 40 dependent cache
+    // round trips per thread: measured 42 us per launch instead of 25)
+    float pc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < n_chunks; j += 8) {
+      float v[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float pc = 0.f;
-      for (int k = c; k < n_chunks; k += 8) pc += sl[(size_t)k * kDwSlabStride];
-      t = (c == 0) ? pc : t + pc;
+      for (int c = 0; c < 8; ++c) v[c] = (j + c < n_chunks) ? sl[(size_t)(j + c) * kDwSlabStride] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pc[c] += v[c];
     }
+    t = pc[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) t += pc[c];
   }
   adam_par_apply(par, e, t, b1, b2, eps);
 }

@@ -37,3 +37,26 @@ for ppf in [40, 200, 1000, 2000, 5000, 13000]:
     print(json.dumps(row), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/roofline_sweep.json", "w"), indent=1)
+
+# ---- the tracker's instantiations (pose gradient: k_decode_bwd2<true, true>), rays per launch = tracking.pixels of the mixes
+from point_slam_amd.slam import camera_tensor_from_c2w
+out_t = []
+cam0 = camera_tensor_from_c2w(fr.c2w).to(dev)
+for n_pix in [200, 1500, 5000, 10000]:
+    slam.track(fr, cam0, n_iters=3, n_pix=n_pix)     # warm
+    torch.cuda.synchronize()
+    _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 1))
+    slam.track(fr, cam0, n_iters=9, n_pix=n_pix)
+    torch.cuda.synchronize()
+    prof = B.kernel_profile(slam)
+    _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 0))
+    row = dict(samples=5 * n_pix, tracker=True)
+    for k in ("decode_fwd_track", "decode_bwd_track", "knn"):
+        v = prof[k]
+        if v["launches"]:
+            row[k + "_us"] = round(v["ms"] * 1e3 / v["launches"], 1)
+            if k in B.MFMA_CLASSES:
+                row[k + "_frac"] = round(v["work"] / (v["ms"] * 1e-3) / 1e12 / B.PEAK_F32_MFMA_TFLOPS, 4)
+    out_t.append(row)
+    print(json.dumps(row), flush=True)
+json.dump(dict(mapper=out, tracker=out_t), open("gpurun_out/roofline_sweep.json", "w"), indent=1)
