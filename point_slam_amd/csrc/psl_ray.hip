@@ -376,44 +376,39 @@ __device__ __forceinline__ void adam_par_apply(const AdamParSeg& par, int i, flo
   if (wf >= 0) par.wf[wf] = pp;
   if (wb >= 0) par.wb[wb] = pp;
 }
-// workgroup `blk` of the parameter segment: 256 parameters.  par.slabs == null: gradient read from par.g.  Otherwise the chunk
-// partials of the dW kernel are summed here in k_dw_reduce's fixed order -- one launch and one pass over g_params less.
+// workgroup `blk` of the parameter segment.  par.slabs == null: 256 parameters, gradient read from par.g.  Otherwise
+// 32 parameters x 8 chunk lanes: the chunk partials of the dW kernel are summed here in k_dw_reduce's fixed order
+// (lane c takes chunks c, c+8, ...; the 8 sums are added in order) -- one launch and one pass over g_params less.
 __device__ __forceinline__ void adam_par_segment(const AdamParSeg& par, int blk, float b1, float b2, float eps) {
   if (!par.slabs) {
     const int i = blk * 256 + (int)threadIdx.x;
     if (i < par.n) adam_par_apply(par, i, par.g[i], b1, b2, eps);
     return;
   }
-  // one thread per parameter, 256 per workgroup (round 3: 32 parameters x 8 chunk lanes = 3 402 workgroups for the 109 k
-  // parameters, most lanes idle at the usual 5 chunks: the launch's dispatch cost more than its work).  The summation order is
-  // k_dw_reduce's: partial c = chunks c, c + 8, ... in order, then the eight partials in order.
-  const int e = blk * 256 + (int)threadIdx.x;
-  if (e >= par.n) return;
-  constexpr int b0 = poff(PI_C_BREL);
-  float t;
-  if (e >= b0 && e < b0 + 3 * ERF) {
-    t = par.g_brel[e - b0];
-  } else {
-    int ent = 0;
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, cl = threadIdx.x >> 5;
+  const int e = blk * 32 + el;
+  float v = 0.f;
+  if (e < par.n) {
+    constexpr int b0 = poff(PI_C_BREL);
+    if (e >= b0 && e < b0 + 3 * ERF) { if (cl == 0) v = par.g_brel[e - b0]; }
+    else {
+      int ent = 0;
 #pragma unroll
-    for (int j = 1; j < kNumColorParams; ++j) if (e >= poff(j)) ent = j;
-    const int n_chunks = par.ra.chunks_of_entry[ent];
-    const float* sl = par.slabs + par.ra.slab_off[ent] + (e - poff(ent));
-    // eight chunk values in flight per trip (a serial walk over the ~40 chunks of F_theta's layers is 40 dependent cache
-    // round trips per thread: measured 42 us per launch instead of 25)
-    float pc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < n_chunks; j += 8) {
-      float v[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = (j + c < n_chunks) ? sl[(size_t)(j + c) * kDwSlabStride] : 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) pc[c] += v[c];
+      for (int j = 1; j < kNumColorParams; ++j) if (e >= poff(j)) ent = j;
+      const int n_chunks = par.ra.chunks_of_entry[ent];
+      const int se = par.ra.slab_off[ent] + (e - poff(ent));
+      for (int c = cl; c < n_chunks; c += 8) v += par.slabs[(size_t)c * kDwSlabStride + se];
     }
-    t = pc[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) t += pc[c];
   }
-  adam_par_apply(par, e, t, b1, b2, eps);
+  part[cl][el] = v;
+  __syncthreads();
+  if (cl == 0 && e < par.n) {
+    float t = part[0][el];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) t += part[c][el];
+    adam_par_apply(par, e, t, b1, b2, eps);
+  }
 }
 
 // dense sweep: every selected row that ever had a gradient, one step (A/B baseline of the lazy kernel below)
@@ -473,9 +468,7 @@ namespace psl {
 int adam_lazy_row_blocks(const AdamLazy& lazy, int n_rows) {
   // a fixed grid of at most 2 048 workgroups per group (8 rows each per trip) walks the list with a stride
   const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, n_rows) : n_rows;
-  static int cap = -1;
-  if (cap < 0) { const char* e = getenv("PSL_ADAM_ROW_BLOCKS"); cap = e ? std::max(atoi(e), 64) : 2048; }
-  return (int)std::min<long long>((rows + 7) / 8, cap);
+  return (int)std::min<long long>((rows + 7) / 8, 2048);
 }
 
 int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col, int step_col, float lr_col, AdamParSeg par,
@@ -483,7 +476,7 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
   adam_consts(step_geo, lr_geo, 0.9f, 0.999f, geo.lr_bc1, geo.sqrt_bc2);
   if (col.n_rows > 0) adam_consts(step_col, lr_col, 0.9f, 0.999f, col.lr_bc1, col.sqrt_bc2);
   if (par.n > 0) adam_consts(step_par > 0 ? step_par : step_col, lr_par, 0.9f, 0.999f, par.lr_bc1, par.sqrt_bc2);
-  const int nb_par = par.n <= 0 ? 0 : (par.n + 255) / 256;
+  const int nb_par = par.n <= 0 ? 0 : (par.slabs ? (par.n + 31) / 32 : (par.n + 255) / 256);
   if (lazy.tab) {
     // work-list mode: the grid covers the list's capacity, workgroups past its length leave after one load
     const int nb_rows = adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
