@@ -619,8 +619,21 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     if (featg && dst >= 0 && o.t_col && g == 0) o.t_col[dst] = 1;
     if (!relpos) {
       // ---- plain interpolation: scatter w_k * dC into the colour feature rows, collect dL/dw_k
-      if (featg && dst >= 0) {
+      // coalesced as in the F_theta path (psl_decode2.h): the wave's 16 pair rows go through its slice of the dead dz
+      // buffers and leave as two whole 128-byte rows per atomic instruction.  Rounds 2-3 issued eight scalar atomics per lane
+      // here, each instruction touching 16 rows with four scattered dwords -- the TUM / ScanNet mapper backward (no
+      // per-neighbour MLP) ran at 18 % of peak at 50 000 samples where the F_theta variant reaches 28 %.
+      if constexpr (!PTSG) {
+        if (featg) {
+          f32x4 dxf[2];
 #pragma unroll
+          for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxf[jt][r] = wgt * dc[jt][r];
+          scatter_pair_rows(sXe + wave * TILE * C, o.g_col, dxf, dst);
+        }
+      } else if (featg && dst >= 0) {   // pose AND feature gradients in one call (drop-in callers only; the tracker trains no
+#pragma unroll                         // features): the scalar form keeps this instantiation inside its 128 registers
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) atomic_add_f32(&o.g_col[(size_t)dst * C + jt * 16 + 4 * g + r], wgt * dc[jt][r]);
@@ -841,19 +854,22 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 //  wl_block0 on build the work list of the iteration's lazy Adam, which the ray kernel used to carry)
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
-                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0) {
+                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0, int interleave) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x >= wl_block0) {
     worklist_role_wave(wl, ((int)blockIdx.x - wl_block0) * (int)blockDim.x + (int)threadIdx.x);
     return;
   }
   BlkTrace bt(a);
-  if (COLOR && (int)blockIdx.x < color_tiles) {
-    color_tile_bwd<PTSG>(a, o, WB, smem, blockIdx.x * TILE, rf);
+  const int b = (int)blockIdx.x;      // workgroup -> (role, tile) as in the forward kernel
+  const bool is_color = COLOR && (interleave ? ((b & 1) == 0) : (b < color_tiles));
+  const int tile = !COLOR ? b : (interleave ? (b >> 1) : (is_color ? b : b - color_tiles));
+  if (is_color) {
+    color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf);
   } else {
     if (threadIdx.x >= 64) return;
-    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem));
-    else geo_tile_bwd<false>(a, o, WB, ((int)blockIdx.x - color_tiles) * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
+    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem));
+    else geo_tile_bwd<false>(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
   }
   bt.done(a);
 }
@@ -891,11 +907,12 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   const int grid_c = 2 * tiles + wl_blocks;
   { int rc = blk_trace_begin(a, color ? grid_c : tiles, s); if (rc) return rc; }
   if (color) {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
-    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
+    const int il = decode_interleave(tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, il);
+    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, il);
   } else {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
-    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, 0);
+    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, 0);
   }
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? grid_c : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }

@@ -500,15 +500,22 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 // idle wavefronts of a geometry workgroup exit at once.  COLOR = false is the stage-'geometry' launch (64-thread
 // workgroups, geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
-__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles,
+                                                                                   int interleave) {
   if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
-  if (COLOR && (int)blockIdx.x < color_tiles) {
-    color_tile(a, WF, smem, blockIdx.x * TILE);
+  // workgroup -> (role, tile).  Default: the colour tiles first, then the geometry tiles.  interleave (large launches): colour
+  // tile t at 2 t, geometry tile t at 2 t + 1, so that the one-wave geometry workgroups run NEXT TO colour tiles on every CU
+  // instead of as a tail of their own after the last colour tile (see launch_decode_fwd2)
+  const int b = (int)blockIdx.x;
+  const bool is_color = COLOR && (interleave ? ((b & 1) == 0) : (b < color_tiles));
+  const int tile = !COLOR ? b : (interleave ? (b >> 1) : (is_color ? b : b - color_tiles));
+  if (is_color) {
+    color_tile(a, WF, smem, tile * TILE);
   } else {
     if (threadIdx.x >= 64) return;
-    const int p0 = ((int)blockIdx.x - color_tiles) * TILE;
+    const int p0 = tile * TILE;
     geo_tile<COLOR ? 3 : 4>(a, WF, p0, !COLOR, !COLOR);
   }
   bt.done(a);
@@ -602,9 +609,9 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
   const bool color = a.flags & PSL_STAGE_COLOR;
   { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color)
-    PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
+    PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles, decode_interleave(tiles));
   else
-    PSL_KLAUNCH(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
+    PSL_KLAUNCH(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0, 0);
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, "fwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on) {

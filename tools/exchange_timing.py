@@ -43,7 +43,7 @@ def main():
     dist.init_process_group(a.backend, rank=0, world_size=1)    # nccl = RCCL: the decoder all-reduce is a device collective
     cfg = default_config()
     cam = syn.intrinsics(640, 480)
-    npc = HipNeuralPointCloud(cfg, max_points=a.points + 400_000, device="cuda:0")
+    npc = HipNeuralPointCloud(cfg, max_points=a.points + 400_000 + 12_000 * a.repeats, device="cuda:0")
     base = syn.seed_cloud(cam, a.points, n_views=64, seed=1219).to(dev)
     g = torch.Generator(device="cpu").manual_seed(5)
     npc.set_points(base, torch.randn(a.points, 32, generator=g).to(dev), torch.randn(a.points, 32, generator=g).to(dev))
