@@ -1,6 +1,5 @@
 // Shared between the decode forward / backward translation units.
 #pragma once
-#include <cstdlib>
 #include "psl_common.h"
 #include "psl_device.h"
 
@@ -150,14 +149,6 @@ struct GeoIterRays {
   int n_rays;
 };
 
-// grid order of a colour-stage decode launch: 1 = colour / geometry workgroups alternate (PSL_DECODE_INTERLEAVE: 0 never,
-// 1 always, default = launches of at least kInterleaveTiles tiles)
-constexpr int kInterleaveTiles = 1024;
-inline int decode_interleave(int tiles) {
-  static int mode = -2;
-  if (mode == -2) { const char* e = getenv("PSL_DECODE_INTERLEAVE"); mode = e ? atoi(e) : -1; }
-  return mode < 0 ? (tiles >= kInterleaveTiles ? 1 : 0) : (mode ? 1 : 0);
-}
 int blk_trace_begin(DecodeArgs& a, int grid, hipStream_t s);                                  // psl_api.hip
 int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_tiles, int threads);
 #define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)

@@ -854,7 +854,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 //  wl_block0 on build the work list of the iteration's lazy Adam, which the ray kernel used to carry)
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
-                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0, int interleave) {
+                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x >= wl_block0) {
     worklist_role_wave(wl, ((int)blockIdx.x - wl_block0) * (int)blockDim.x + (int)threadIdx.x);
@@ -862,8 +862,8 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(
   }
   BlkTrace bt(a);
   const int b = (int)blockIdx.x;      // workgroup -> (role, tile) as in the forward kernel
-  const bool is_color = COLOR && (interleave ? ((b & 1) == 0) : (b < color_tiles));
-  const int tile = !COLOR ? b : (interleave ? (b >> 1) : (is_color ? b : b - color_tiles));
+  const bool is_color = COLOR && b < color_tiles;
+  const int tile = is_color ? b : b - color_tiles;
   if (is_color) {
     color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf);
   } else {
@@ -907,12 +907,11 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
   const int grid_c = 2 * tiles + wl_blocks;
   { int rc = blk_trace_begin(a, color ? grid_c : tiles, s); if (rc) return rc; }
   if (color) {
-    const int il = decode_interleave(tiles);
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, il);
-    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, il);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
+    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
   } else {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, 0);
-    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, 0);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
+    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
   }
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? grid_c : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }

@@ -500,17 +500,17 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
 // idle wavefronts of a geometry workgroup exit at once.  COLOR = false is the stage-'geometry' launch (64-thread
 // workgroups, geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
-__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles,
-                                                                                   int interleave) {
+__global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
   if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
-  // workgroup -> (role, tile).  Default: the colour tiles first, then the geometry tiles.  interleave (large launches): colour
-  // tile t at 2 t, geometry tile t at 2 t + 1, so that the one-wave geometry workgroups run NEXT TO colour tiles on every CU
-  // instead of as a tail of their own after the last colour tile (see launch_decode_fwd2)
+  // workgroup -> (role, tile): the colour tiles first, then the geometry tiles.  (Alternating the two roles in the grid, so
+  // that the one-wave geometry workgroups run next to colour tiles instead of after them, was measured in round 4: slower at
+  // every launch size -- base mix 93.2 -> 79.5 frames/s, TUM yaml 8.85 -> 7.13, ScanNet 13.7 -> 10.9, Replica 35.4 -> 30.4: a
+  // resident geometry wave holds 128 registers of one SIMD and keeps a second colour tile off the CU.)
   const int b = (int)blockIdx.x;
-  const bool is_color = COLOR && (interleave ? ((b & 1) == 0) : (b < color_tiles));
-  const int tile = !COLOR ? b : (interleave ? (b >> 1) : (is_color ? b : b - color_tiles));
+  const bool is_color = COLOR && b < color_tiles;
+  const int tile = is_color ? b : b - color_tiles;
   if (is_color) {
     color_tile(a, WF, smem, tile * TILE);
   } else {
@@ -609,9 +609,9 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
   const bool color = a.flags & PSL_STAGE_COLOR;
   { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color)
-    PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles, decode_interleave(tiles));
+    PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);
   else
-    PSL_KLAUNCH(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0, 0);
+    PSL_KLAUNCH(k_decode_fwd2<false>, dim3(tiles), dim3(64), 0, s, a, (const float*)ctx->wf, 0);
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, "fwd2", color ? 2 * tiles : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }
   if (dbg_on) {
