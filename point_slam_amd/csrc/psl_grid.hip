@@ -501,6 +501,7 @@ __device__ __forceinline__ void flat_row_range(const GridMeta& m, const int* __r
 }
 
 // one pass over the rows [row0, row0 + nrows) of the table that wave_knn_flat has filled
+template <int U>
 __device__ __forceinline__ void knn_scan_flat(const float4* __restrict__ spos, float qx, float qy, float qz, u64& mine, u64& thr,
                                               unsigned long long& cand, FlatLds& L, int row0, int nrows, bool need_full) {
   const int lane = threadIdx.x & 63;
@@ -540,8 +541,7 @@ __device__ __forceinline__ void knn_scan_flat(const float4* __restrict__ spos, f
   int cur = 0, row_end = 0;
   if (j0 < T) { cur = L.beg[tr] + (j0 - L.off[tr]); row_end = L.beg[tr] + L.cnt[tr]; }
   int left = min(q, max(T - j0, 0));
-  // ---- eight records per lane in flight (repeated for passes of more than 512 candidates)
-  constexpr int U = 8;
+  // ---- U records per lane in flight (repeated for passes of more than 64 U candidates)
   for (int it = 0; it < q; it += U) {
     float4 c[U];
     bool v[U];
@@ -569,6 +569,7 @@ __device__ __forceinline__ void knn_scan_flat(const float4* __restrict__ spos, f
   }
 }
 
+template <int U>
 __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* __restrict__ spos,
                                               const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
                                               float r2, u64& mine, unsigned long long& cand, const int* __restrict__ coarse,
@@ -626,7 +627,7 @@ __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* _
       const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
       mine = sentinel;
       u64 thr = sentinel;
-      knn_scan_flat(spos, qx, qy, qz, mine, thr, cand, L, base[k], base[k + 1] - base[k], last);
+      knn_scan_flat<U>(spos, qx, qy, qz, mine, thr, cand, L, base[k], base[k + 1] - base[k], last);
       ++passes;
       closed = last || thr != sentinel;
     }
@@ -634,7 +635,11 @@ __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* _
 }
 
 // ray mode, small launches: one wave per SAMPLE with the flat enumeration; outputs as k_knn_rays
-__global__ __launch_bounds__(256) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
+// <U, MINW>: records in flight per lane and the wavefronts per SIMD the register budget is cut for.  <8, 5> (81 VGPRs, six resident) is the
+// latency shape of the small launches; <4, 8> (64 VGPRs: a third more queries resident per CU) is there for the launches that
+// fill the chip several times over (PSL_KNN_FLAT_LARGE, see knn_rays)
+template <int U, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                        const int* __restrict__ cell_start,
                                                        const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                        const float* __restrict__ depth, const float* __restrict__ z_vals,
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(256) void k_knn_rays_flat(const GridMeta* __restric
   u64 mine;
   unsigned long long n_cand = 0;
   int n_pass = 0;
-  wave_knn_flat(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass, lds[(threadIdx.x >> 6) & 3]);
+  wave_knn_flat<U>(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass, lds[(threadIdx.x >> 6) & 3]);
   const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
   const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
@@ -1099,10 +1104,18 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
-    PSL_KLAUNCH(k_knn_rays_flat, dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
-                       (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
+    static int large_from = -2;     // queries from which the high-occupancy instantiation is used (PSL_KNN_FLAT_LARGE; < 0 = never)
+    if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : -1; }
+    if (large_from >= 0 && n_rays * S >= large_from)
+      PSL_KLAUNCH((k_knn_rays_flat<4, 8>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
+                         (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
+    else
+      PSL_KLAUNCH((k_knn_rays_flat<8, 5>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
+                         (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }
