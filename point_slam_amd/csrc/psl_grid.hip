@@ -636,8 +636,8 @@ __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* _
 
 // ray mode, small launches: one wave per SAMPLE with the flat enumeration; outputs as k_knn_rays
 // <U, MINW>: records in flight per lane and the wavefronts per SIMD the register budget is cut for.  <8, 5> (81 VGPRs, six resident) is the
-// latency shape of the small launches; <4, 8> (64 VGPRs: a third more queries resident per CU) is there for the launches that
-// fill the chip several times over (PSL_KNN_FLAT_LARGE, see knn_rays)
+// latency shape of the small launches; <4, 8> (64 VGPRs: a third more queries resident per CU) is the default from 5 000
+// queries on, where the chip is filled several times over (PSL_KNN_FLAT_LARGE, see knn_rays)
 template <int U, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                        const int* __restrict__ cell_start,
@@ -1104,8 +1104,11 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
-    static int large_from = -2;     // queries from which the high-occupancy instantiation is used (PSL_KNN_FLAT_LARGE; < 0 = never)
-    if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : -1; }
+    // queries from which the high-occupancy instantiation is used (PSL_KNN_FLAT_LARGE; < 0 = never).  Measured [MI355X, round 4]:
+    // 25 000 queries (TUM / ScanNet tracker) 74.6 -> 64.1 us, TUM yaml +2.7 %, ScanNet +1 %, Replica (7 500 queries) +1.5 %; at
+    // the base mix's 1 000 queries (4 wavefronts per CU: no occupancy to gain, fewer loads in flight per trip) -0.5 %
+    static int large_from = -2;
+    if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : 5000; }
     if (large_from >= 0 && n_rays * S >= large_from)
       PSL_KLAUNCH((k_knn_rays_flat<4, 8>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                          rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),

@@ -181,9 +181,9 @@ def test_track_map_track_closed_loop_matches_oracle():
             kw = dict(coef=cfg["rendering"]["sigmoid_coef_tracker"])
             ls, cams, best, _, _ = O.tracker_loop(cfg, P, cloud, geo, col, cam0, pix, fb, of["depth"], of["color"], of["r_query"],
                                                   cam, eh, ew, **kw)
-            # yardstick (tests/test_hip_slam.py:78): the same oracle loop from an initial pose moved by ONE ulp, up and down
+            # yardstick (tests/test_hip_slam.py:78): the same oracle loop from an initial pose moved by ONE ulp
             noise = 0.0
-            for target in (10.0, -10.0):
+            for target in (10.0,):
                 cam0_ulp = torch.nextafter(cam0, torch.full_like(cam0, target))
                 _, _, best_ulp, _, _ = O.tracker_loop(cfg, P, cloud, geo, col, cam0_ulp, pix, fb, of["depth"], of["color"], of["r_query"],
                                                       cam, eh, ew, **kw)
@@ -258,7 +258,7 @@ def test_track_map_track_closed_loop_matches_oracle():
     # The lowest-loss pose of 20 Adam steps is NOT a parity quantity: next to the optimum the signs of Adam's +-lr steps are decided by
     # gradient components at the rounding level, and the oracle separates from ITSELF by 1e-5 .. 1.3e-2 (6 steps) when its
     # initial pose moves by one ulp (first measured run: HIP-vs-oracle 1e-4 .. 1.0e-2 on the same frames).  What can be
-    # asserted is that the two spreads are of one size -- over the six tracked frames, against twelve perturbed oracle runs:
+    # asserted is that the two spreads are of one size -- over the six tracked frames, against six perturbed oracle runs:
     worst_pose = max(r["pose_abs"] for r in per_frame[1:])
     worst_noise = max(r["oracle_self_noise_1ulp"] for r in per_frame[1:])
     assert worst_pose <= max(0.25 * step, 4 * worst_noise), (worst_pose, worst_noise)
