@@ -195,11 +195,17 @@ __device__ __forceinline__ SampleGeom sample_geom(const DecodeArgs& a, int p) {
   SampleGeom g;
   int ray = p / S, si = p - ray * S;
   g.ray = ray;
-  g.zval = a.zv ? a.zv[p] : sample_z(a.depth[ray], si, a.near_s, a.far_s);
-  sample_point(a.rays_o[ray * 3], a.rays_o[ray * 3 + 1], a.rays_o[ray * 3 + 2], a.rays_d[ray * 3],
-               a.rays_d[ray * 3 + 1], a.rays_d[ray * 3 + 2], g.zval, g.x, g.y, g.z);
-  if (a.r_query) { float r = a.r_query[ray]; g.r2 = __fmul_rn(r, r); }
-  else g.r2 = a.r2_fixed;
+  // every load of the set-up is requested before the first use (round 4).  Written with `cond ? load : load` and `if (ptr)`,
+  // hipcc put each load into its own basic block with a full wait behind it: depth -> wait -> rays -> radius -> wait, two
+  // serial cache round trips in front of EVERY tile of every decode kernel before its neighbour lists were even requested.
+  const float* dptr = a.zv ? a.zv + p : a.depth + ray;                 // one address, one load
+  const float* rptr = a.r_query ? a.r_query + ray : dptr;              // (a valid dummy address when the radius is fixed)
+  const float dval = *dptr, rq = *rptr;
+  const float ox = a.rays_o[ray * 3], oy = a.rays_o[ray * 3 + 1], oz = a.rays_o[ray * 3 + 2];
+  const float dx = a.rays_d[ray * 3], dy = a.rays_d[ray * 3 + 1], dz = a.rays_d[ray * 3 + 2];
+  g.zval = a.zv ? dval : sample_z(dval, si, a.near_s, a.far_s);
+  sample_point(ox, oy, oz, dx, dy, dz, g.zval, g.x, g.y, g.z);
+  g.r2 = a.r_query ? __fmul_rn(rq, rq) : a.r2_fixed;
   return g;
 }
 

@@ -74,28 +74,53 @@ constexpr GSteps kGeo = make_geo_steps();
 // (lanes = 2 x 32 consecutive channels, two 128-byte lines): an eighth of the line operations at the L2 atomic units, the
 // same products, the same (unordered) sums.
 struct ScatterLds { float dc[TILE * C]; float w[TILE * K]; int row[TILE * K]; };      // 3 KB per wavefront
+// Round 4: the loop is software-pipelined by hand.  As one `for` over the 64 pair slots (rounds 2-3) hipcc emitted, per slot,
+// [ds_read row -> wait -> branch -> ds_read w, dc -> wait -> atomic -> branch -> byte store]: 128 serial LDS round trips,
+// 14 k cycles of the one-launch geometry iteration's 58 k (its phase stamps).  Now a lane owns one channel and the FOUR
+// neighbour slots 4 half .. 4 half + 3 of every sample: the rows / weights of a sample's slots are one 16-byte LDS read each,
+// four samples (12 reads) are requested together, and the sixteen atomics of the group issue back to back.
 __device__ __forceinline__ void scatter_interp_rows(ScatterLds& L, float* __restrict__ g_feat, unsigned char* __restrict__ touched,
                                                     const f32x4 (&dc)[2], const float (&w)[K], const int (&dst)[K]) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   *reinterpret_cast<f32x4*>(L.dc + rl * C + 4 * g) = dc[0];
   *reinterpret_cast<f32x4*>(L.dc + rl * C + 16 + 4 * g) = dc[1];
   if (g == 0) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) { L.w[rl * K + k] = w[k]; L.row[rl * K + k] = dst[k]; }
+    *reinterpret_cast<float4*>(L.w + rl * K) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4*>(L.w + rl * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
+    *reinterpret_cast<int4*>(L.row + rl * K) = make_int4(dst[0], dst[1], dst[2], dst[3]);
+    *reinterpret_cast<int4*>(L.row + rl * K + 4) = make_int4(dst[4], dst[5], dst[6], dst[7]);
   }
   wave_lds_sync();
   const int ch = lane & 31, half = lane >> 5;
-#pragma unroll 8
-  for (int pi = 0; pi < TILE * K; pi += 2) {
-    const int pair = pi + half;
-    const int row = L.row[pair];
-    if (row >= 0) {
-      atomic_add_f32(&g_feat[(size_t)row * C + ch], L.w[pair] * L.dc[(pair >> 3) * C + ch]);
-      if (touched && ch == 0) touched[row] = 1;
+#pragma unroll
+  for (int s0 = 0; s0 < TILE; s0 += 4) {
+    int4 rows[4];
+    float4 ws[4];
+    float dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rows[j] = *reinterpret_cast<const int4*>(L.row + (s0 + j) * K + 4 * half);
+      ws[j] = *reinterpret_cast<const float4*>(L.w + (s0 + j) * K + 4 * half);
+      dv[j] = L.dc[(s0 + j) * C + ch];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pin(dv[j]);      // keeps the reads of dC up here (sunk into the first branch that uses them otherwise)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r4[4] = {rows[j].x, rows[j].y, rows[j].z, rows[j].w};
+      const float w4[4] = {ws[j].x, ws[j].y, ws[j].z, ws[j].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (r4[k] >= 0) {
+          atomic_add_f32(&g_feat[(size_t)r4[k] * C + ch], w4[k] * dv[j]);
+          if (touched && ch == 0) touched[r4[k]] = 1;
+        }
+      }
     }
   }
 }
-// per-pair rows: lane (pair rl, g) holds dX[pair][16 jt + 4 g + r]; dst = gradient row of the lane's pair (-1: none)
+// per-pair rows: lane (pair rl, g) holds dX[pair][16 jt + 4 g + r]; dst = gradient row of the lane's pair (-1: none).
+// The row lookups (a cross-lane read each) and tile reads of four pairs are requested before their atomics.
 __device__ __forceinline__ void scatter_pair_rows(float* tile /*[16][32] per-wave LDS*/, float* __restrict__ g_feat, const f32x4 (&dx)[2],
                                                   int dst) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
@@ -104,10 +129,18 @@ __device__ __forceinline__ void scatter_pair_rows(float* tile /*[16][32] per-wav
   wave_lds_sync();
   const int ch = lane & 31, half = lane >> 5;
 #pragma unroll
-  for (int pi = 0; pi < TILE; pi += 2) {
-    const int pair = pi + half;
-    const int row = __shfl(dst, pair);                  // lanes 0..15 (g = 0) hold the 16 pairs' rows
-    if (row >= 0) atomic_add_f32(&g_feat[(size_t)row * C + ch], tile[pair * C + ch]);
+  for (int j0 = 0; j0 < TILE / 2; j0 += 4) {             // four at a time: eight registers (the pose-gradient instantiation has none to spare)
+    int row[4];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pair = 2 * (j0 + j) + half;
+      row[j] = __shfl(dst, pair);                       // lanes 0..15 (g = 0) hold the 16 pairs' rows
+      v[j] = tile[pair * C + ch];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (row[j] >= 0) atomic_add_f32(&g_feat[(size_t)row[j] * C + ch], v[j]);
   }
   wave_lds_sync();
 }

@@ -428,11 +428,21 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
     const int p = min(p0 + s, a.P - 1);
-    const SampleGeom sg = sample_geom(a, p);
-    const int i = a.ws.I[(size_t)p * K + k];
+    // list entry, saved weight and count are requested before the sample geometry (see sample_geom) -- in the mapper's
+    // instantiation; the pose-gradient one keeps the old order: hoisted, it needs four registers more than its 128
+    int i, cnt_p;
+    float w_saved;
+    SampleGeom sg;
+    if constexpr (PTSG) {
+      sg = sample_geom(a, p);
+      i = a.ws.I[(size_t)p * K + k]; w_saved = a.ws.w[(size_t)p * K + k]; cnt_p = a.ws.cnt[p];
+    } else {
+      i = a.ws.I[(size_t)p * K + k]; w_saved = a.ws.w[(size_t)p * K + k]; cnt_p = a.ws.cnt[p];
+      sg = sample_geom(a, p);
+    }
     const float4 q = a.pos[max(i, 0)];
     sI[t] = i;
-    sW[t] = a.ws.w[(size_t)p * K + k];
+    sW[t] = w_saved;
     sRel[t * 3 + 0] = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f;
     sRel[t * 3 + 1] = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f;
     sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
@@ -440,7 +450,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     if (k == 0) {
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
       // samples past the end of the batch behave as "no neighbours, zero gradient"
-      sHas[s] = (p0 + s < a.P && a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
+      sHas[s] = (p0 + s < a.P && cnt_p >= a.min_nn) ? 1 : 0;
     }
   } else if (t < TILE * K + TILE) {
     // ---- d(logits): sigmoid and exposure-affine backward (decoder.py:432-448), one thread per sample

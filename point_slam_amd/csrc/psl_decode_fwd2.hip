@@ -63,16 +63,18 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
   const float* __restrict__ M = a.master;
   f32x4 W0[kGeo.n], W1[kGeo.n];
   PSL_STAMP(32);
-  const SampleGeom sg = sample_geom(a, p);
   // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171); no control flow:
-  // absent neighbours (index -1) read point 0 and get weight 0
+  // absent neighbours (index -1) read point 0 and get weight 0.  The lists are requested before the sample geometry: the
+  // positions they name are the next dependent round trip
   int nb[K];
   {
     const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K);
     const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K + 4);
     nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
   }
-  const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150); loaded with the lists, kept as a lane mask
+  const int cnt_p = a.ws.cnt[p];
+  const SampleGeom sg = sample_geom(a, p);
+  const bool has = cnt_p >= a.min_nn;     // has_neighbors (decoder.py:150); loaded with the lists, kept as a lane mask
   float w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -235,8 +237,9 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
     const int p = min(p0 + s, a.P - 1);
+    const int i = a.ws.I[(size_t)p * K + k];          // requested before the sample geometry (see sample_geom)
+    const int cnt_p = a.ws.cnt[p];
     const SampleGeom sg = sample_geom(a, p);
-    const int i = a.ws.I[(size_t)p * K + k];
     const float4 q = a.pos[max(i, 0)];
     const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
     float w = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
@@ -249,7 +252,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     sRel[t * 3 + 2] = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
     if (k == 0) {
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
-      sHas[s] = (a.ws.cnt[p] >= a.min_nn) ? 1 : 0;
+      sHas[s] = (cnt_p >= a.min_nn) ? 1 : 0;
     }
   }
   lds_barrier_dma();

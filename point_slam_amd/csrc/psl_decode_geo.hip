@@ -39,14 +39,16 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   const float* __restrict__ M = a.master;
   f32x4 W0[kGeo.n], W1[kGeo.n];
   PSL_STAMP(0);
-  const SampleGeom sg = sample_geom(a, p);
-  // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171)
+  // ---- neighbours, inverse-distance weights (decoder.py:152-160), interpolation (:162-171).  The lists (and the count) are
+  // requested FIRST: they depend on nothing but the sample index, and the positions they name are the next dependent trip
   int nb[K];
   {
     const int4 i0 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K);
     const int4 i1 = *reinterpret_cast<const int4*>(a.ws.I + (size_t)p * K + 4);
     nb[0] = i0.x; nb[1] = i0.y; nb[2] = i0.z; nb[3] = i0.w; nb[4] = i1.x; nb[5] = i1.y; nb[6] = i1.z; nb[7] = i1.w;
   }
+  const int cnt_p = a.ws.cnt[p];
+  const SampleGeom sg = sample_geom(a, p);
   float w[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -58,7 +60,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   const float inv = fmaxf(wsum, 1e-12f);
 #pragma unroll
   for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
-  const bool has = a.ws.cnt[p] >= a.min_nn;     // has_neighbors (decoder.py:150)
+  const bool has = cnt_p >= a.min_nn;     // has_neighbors (decoder.py:150)
   PSL_STAMP(1);
   f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
