@@ -1,4 +1,4 @@
-// Adam arithmetic shared by the optimiser launches (psl_ray.hip) and the row role of the dW kernel (psl_dw.hip).
+// Adam arithmetic of the optimiser launches (psl_ray.hip).
 #pragma once
 #include "psl_common.h"
 #include "psl_device.h"
@@ -40,22 +40,30 @@ __device__ __forceinline__ void adam_replay(float& p, float& m, float& v, float 
 //      de-duplicated work list (k_adam_worklist), or
 //  (c) dense pass (list == null): the next lists are not known yet (end of a k-NN prefetch block) or the call ends.
 // upto[row] = number of this call's iterations already applied; -1 = never had a gradient (m = v = 0, every missed
-// step is exactly +0).  32 lanes per row, one channel each: the replay is a serial chain per channel and the slowest
-// row of a launch sets its duration.
-// the feature-row part of a lazy Adam launch for workgroup blk0 of nb_rows (group `is_col`): shared by k_map_adam_lazy and by
-// the extra workgroups of the dW kernel (colour stage: the rows do not depend on the parameter gradients, so they are stepped
-// while the dW GEMM runs and the Adam launch that follows holds the parameter segment only)
+// step is exactly +0).  The replay is a serial chain per channel and the slowest row of a launch sets its duration.
+// the feature-row part of a lazy Adam launch for workgroup blk0 of nb_rows (group `is_col`).
+// LPR lanes per row, 32 / LPR channels per lane (one 4-, 8- or 16-byte access per stream and lane): a 256-thread workgroup
+// steps 256 / LPR rows per trip.  The launch is a chain of dependent memory round trips, not a bandwidth problem (45 MB in
+// 25 us with one channel per lane): fewer, wider trips shorten the chain, while the replay of the missed steps becomes
+// 32 / LPR independent serial chains per lane (and a wavefront waits for the longest replay of 64 / LPR rows).
+// Every load that does not need the list's length is requested before the length is known: the first list entry of the
+// workgroup (the list is allocated to its capacity; entries past the length are never dereferenced) and the constants table.
+template <int LPR>
 __device__ __forceinline__ void adam_lazy_rows_block(const AdamRowsSeg& sg, bool is_col, int blk0, int nb_rows, float b1, float b2,
                                                      float eps, const AdamLazy& lz, float2* stab) {
+  static_assert(LPR == 8 || LPR == 16 || LPR == 32, "lanes per row");
+  constexpr int V = 32 / LPR;                             // channels per lane
+  constexpr int RPT = 256 / LPR;                          // rows per workgroup trip
+  const int sub = threadIdx.x / LPR, e = (threadIdx.x % LPR) * V;
+  int row_first = -1;
+  if (lz.list && (long long)blk0 * RPT + sub < lz.list_cap) row_first = lz.list[(long long)blk0 * RPT + sub];
   const int n_work = lz.list ? *lz.count : sg.n_rows;
   // per-iteration constants since the last dense pass, staged once per workgroup (a global load per replayed step
   // made each step a full memory round trip)
   const int nt = lz.it - lz.base + 1;
-  if ((long long)blk0 * 8 < n_work) {
-    for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
-      const float4 v = lz.tab[lz.base + t];
-      stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
-    }
+  for (int t = threadIdx.x; t < nt && t < kAdamTabLds; t += blockDim.x) {
+    const float4 v = lz.tab[lz.base + t];
+    stab[t] = is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
   }
   __syncthreads();
   auto consts = [&](int t) -> float2 {
@@ -64,14 +72,13 @@ __device__ __forceinline__ void adam_lazy_rows_block(const AdamRowsSeg& sg, bool
     const float4 v = lz.tab[t];
     return is_col ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
   };
-  const int e = threadIdx.x & 31;
   unsigned long long done = 0;
   // the grid is a fixed number of workgroups per group: each walks the work list with a stride (a grid sized to the
   // list's CAPACITY -- 10^4 workgroups per group, most of them past its length -- cost more to dispatch than to run)
-  for (long long blk = blk0; blk * 8 < n_work; blk += nb_rows) {
-    const long long ridx = blk * 8 + (threadIdx.x >> 5);
+  for (long long blk = blk0; blk * RPT < n_work; blk += nb_rows) {
+    const long long ridx = blk * RPT + sub;
     int row = -1;
-    if (ridx < n_work) row = lz.list ? lz.list[ridx] : (int)ridx;
+    if (ridx < n_work) row = !lz.list ? (int)ridx : (blk == blk0 ? row_first : lz.list[ridx]);
     bool has_g = false, work = false;
     int u = -1;
     if (row >= 0) {
@@ -86,17 +93,20 @@ __device__ __forceinline__ void adam_lazy_rows_block(const AdamRowsSeg& sg, bool
     float* gp = reinterpret_cast<float*>(sg.g) + k;
     float* mp = reinterpret_cast<float*>(sg.m) + k;
     float* vp = reinterpret_cast<float*>(sg.v) + k;
-    float pp = *pptr, mm = *mp, vv = *vp;
-    float gg = 0.f;
-    if (has_g) { gg = *gp; *gp = 0.f; }
+    using vec = float __attribute__((ext_vector_type(V)));
+    vec pp = *reinterpret_cast<vec*>(pptr), mm = *reinterpret_cast<vec*>(mp), vv = *reinterpret_cast<vec*>(vp), gg = 0.f;
+    if (has_g) { gg = *reinterpret_cast<vec*>(gp); *reinterpret_cast<vec*>(gp) = 0.f; }
     for (int t = u; t < lz.it; ++t) {                     // replay of the steps without a gradient
       const float2 ab = consts(t);
-      adam_replay(pp, mm, vv, ab.x, __builtin_amdgcn_rcpf(ab.y), b1, b2, eps);
+      const float ib = __builtin_amdgcn_rcpf(ab.y);
+#pragma unroll
+      for (int c = 0; c < V; ++c) { float p1 = pp[c], m1 = mm[c], v1 = vv[c]; adam_replay(p1, m1, v1, ab.x, ib, b1, b2, eps); pp[c] = p1; mm[c] = m1; vv[c] = v1; }
     }
     const float2 ab = consts(lz.it);
-    adam_update(pp, gg, mm, vv, ab.x, ab.y, b1, b2, eps);
-    *pptr = pp; *mp = mm; *vp = vv;
-    // the 32 lanes of a row sit in one wavefront and have all read touched/upto above
+#pragma unroll
+    for (int c = 0; c < V; ++c) { float p1 = pp[c], m1 = mm[c], v1 = vv[c]; adam_update(p1, gg[c], m1, v1, ab.x, ab.y, b1, b2, eps); pp[c] = p1; mm[c] = m1; vv[c] = v1; }
+    *reinterpret_cast<vec*>(pptr) = pp; *reinterpret_cast<vec*>(mp) = mm; *reinterpret_cast<vec*>(vp) = vv;
+    // the lanes of a row sit in one wavefront and have all read touched/upto above
     if (e == 0) { sg.upto[row] = lz.it + 1; if (has_g) sg.touched[row] = 0; ++done; }
   }
   if (lz.rows_done) {                                     // one atomic per wavefront, spread over 256 cache lines

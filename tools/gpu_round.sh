@@ -11,7 +11,7 @@
 #   sweep                         tools/roofline_sweep.py -> <tag>_roofline_sweep.json
 #   phases                        tools/phase_probe.py (PSL_DEBUG_PHASES) -> <tag>_phases.log
 #   blocks                        per-workgroup trace of the decode launches -> <tag>_block_trace.txt
-#   trace[:<args>]                rocprofv3 --kernel-trace --stats of bench.py <args> -> <tag>_kernel_trace_stats.csv (+ timeline)
+#   trace[:<args>[:<ENV=V,..>]]   rocprofv3 --kernel-trace --stats of bench.py <args> -> <tag>_kernel_trace_stats.csv (+ timeline)
 #   pmc:<mix>                     PMC passes (FETCH_SIZE / WRITE_SIZE / SQ groups) on tools/pmc_probe.py --mix <mix>
 #                                 -> <tag>_pmc_<mix>/*.csv and profiles-ready <tag>_pmc_traffic_<mix>.json
 #   x8[:<steps>[:<points>]]       bench.py --gpus 8 with all ranks sharing the one GPU (gloo) -> <tag>_bench_frame_parallel_x8_shared_gpu.json
@@ -64,8 +64,8 @@ EOF
       python tools/block_trace.py $O/${TAG}_blocks.raw > $O/${TAG}_block_trace.txt 2>&1; rm -f $O/${TAG}_blocks.raw
       grep -A3 "P=5000 flags=0x1000d" $O/${TAG}_block_trace.txt | tail -8 ;;
     trace)
-      timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- python bench.py $(sp "$a1") > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
-      python tools/rocpd_stats.py $O/prof_$TAG/${TAG}_results.db --csv $O/${TAG}_kernel_trace_stats.csv | head -16
+      env $(sp "$a2") timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- python bench.py $(sp "$a1") > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
+      python tools/rocpd_stats.py $O/prof_$TAG/${TAG}_results.db --csv $O/${TAG}_kernel_trace_stats.csv --by-grid adam_lazy | grep -E "by-grid|^kernel|^[^,]*,[0-9]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+$" | head -26
       python tools/rocpd_timeline.py $O/prof_$TAG/${TAG}_results.db 0.5 > $O/${TAG}_timeline.txt 2>&1
       rm -rf $O/prof_$TAG ;;
     pmc)
