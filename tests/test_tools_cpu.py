@@ -19,7 +19,7 @@ DW = "_ZN3psl4k_dwENS_6DwArgsE.kd"
 def _trace_db(path):
     db = sqlite3.connect(path)
     db.execute("create table rocpd_info_kernel_symbol (id integer primary key, kernel_name text)")
-    db.execute("create table rocpd_kernel_dispatch (id integer primary key, kernel_id integer, start integer, end integer)")
+    db.execute("create table rocpd_kernel_dispatch (id integer primary key, kernel_id integer, start integer, end integer, grid_size_x integer default 0)")
     for i, n in enumerate((FWD, BWD, BWD_T, DW)):
         db.execute("insert into rocpd_info_kernel_symbol values (?, ?)", (i, n))
     t = 1_000_000
@@ -50,6 +50,26 @@ def test_rocpd_stats_keeps_the_backward_instantiations_apart(tmp_path):
     bwd_t = next(v for k, v in rows.items() if "bwd2ILb1ELb1E" in k)
     assert int(bwd_t[1]) == 1
     assert open(tmp_path / "s.csv").read().strip() == out.strip()
+
+
+def test_rocpd_stats_splits_a_kernel_by_grid_size(tmp_path):
+    """--by-grid: the Adam launches of the geometry stage (one row group) and of the colour stage (two groups + decoder parameters)
+    are one symbol with two grid sizes; the split is what profiles/r04_adam_lanes_per_row.txt records."""
+    db = str(tmp_path / "t_results.db")
+    _trace_db(db)
+    con = sqlite3.connect(db)
+    con.execute("insert into rocpd_info_kernel_symbol values (9, '_ZN3psl15k_map_adam_lazyILi16EEEvNS_11AdamRowsSegE.kd')")
+    for i in range(6):
+        g, dur = ((524288, 13_000) if i % 3 else (1919744, 21_000))
+        con.execute("insert into rocpd_kernel_dispatch (kernel_id, start, end, grid_size_x) values (9, ?, ?, ?)", (10**9 + i * 10**5, 10**9 + i * 10**5 + dur, g))
+    con.commit(); con.close()
+    out = _run("rocpd_stats.py", db, "--by-grid", "adam_lazy")
+    by = [l for l in out.splitlines() if l.startswith("by-grid")]
+    assert len(by) == 2
+    small = next(l for l in by if "grid_x=524288" in l).split(",")
+    big = next(l for l in by if "grid_x=1919744" in l).split(",")
+    assert int(small[1]) == 4 and abs(float(small[3]) - 13.0) < 1e-6
+    assert int(big[1]) == 2 and abs(float(big[3]) - 21.0) < 1e-6
 
 
 def test_rocpd_timeline_and_gaps(tmp_path):
