@@ -53,6 +53,11 @@ def parse():
                     help="BASELINE config 1: tracking only on a FIXED cloud (no mapping, no point growth); every frame starts "
                          "from the constant-speed extrapolation of the tracker's own previous estimates (Tracker.py:259-270). "
                          "Quoted with --points 50000 --width 1200 --height 680 --mix replica --steps 200")
+    ap.add_argument("--depth-noise", type=float, default=None,
+                    help="multiplicative Gaussian sensor-depth noise (sigma as a fraction of the depth); default: 0.005 for --mix tum "
+                         "(SURVEY.md 8d: the TUM-like stream, 'sigma = 0.5 % d + 2 % dropout'), 0 otherwise")
+    ap.add_argument("--depth-dropout", type=float, default=None,
+                    help="fraction of pixels whose sensor depth is dropped to 0 (holes); default: 0.02 for --mix tum, 0 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -103,6 +108,13 @@ def build_world(args, rank, world, dev):
         torch.cuda.synchronize()
         args._trained_keyframes = n_train
     every = cfg["mapping"]["every_frame"]
+    # BASELINE config 3 ("TUM fr1_desk ... noisy-depth path"): the TUM-like stream of SURVEY.md 8d -- depth noise of 0.5 % of the
+    # depth and 2 % of the pixels dropped to 0 -- so that the timed loop runs the sensor-hole filters (depth > 0 compaction of
+    # the tracker / mapper batches, the add step's depth filter, the frustum selection's hole rule) and the depth-outlier mask
+    noise = args.depth_noise if args.depth_noise is not None else (0.005 if args.mix == "tum" else 0.0)
+    dropout = args.depth_dropout if args.depth_dropout is not None else (0.02 if args.mix == "tum" else 0.0)
+    args._depth_noise, args._depth_dropout = noise, dropout
+    g_noise = torch.Generator(device=dev).manual_seed(4242 + rank)
     n_total = args.warmup + args.steps * (1 if args.no_kernel_timing else 2)
     # frame-parallel partition: local step i is global frame rank + world*i
     frames, cams0 = [], []
@@ -112,7 +124,7 @@ def build_world(args, rank, world, dev):
         t = float(rank + world * max(i, 0)) * getattr(args, "_unit_per_frame", 2.0) if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
         t = t + 200.0 if i >= 0 else t + 170.0
         c2w = syn.pose(t, dev)
-        depth, color = syn.render_frame(cam, c2w)
+        depth, color = syn.render_frame(cam, c2w, noise=noise, dropout=dropout, gen=g_noise)
         r_add, r_q = syn.dynamic_radii(color, cfg)
         fr = Frame(i, depth, color, r_add, r_q, c2w)
         if i < 0:
@@ -481,13 +493,21 @@ def main():
         run_step(i, slam, frames, cams0, every, cfg, world, args, state)
     from point_slam_amd import _lib
 
+    mark = torch.zeros(1, device=dev) if os.environ.get("PSL_BENCH_MARK") == "1" else None
+
     def timed(first):
         barrier()
+        if mark is not None:        # a kernel no other code launches: tools/rocpd_window.py cuts the rocprofv3 trace at these
+            torch.erfinv_(mark)
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(first, first + args.steps):
             run_step(i, slam, frames, cams0, every, cfg, world, args, state)
         barrier()
         d = time.perf_counter() - t0
+        if mark is not None:
+            torch.erfinv_(mark)
+            torch.cuda.synchronize()
         if world > 1:
             tt = torch.tensor([d], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -565,7 +585,9 @@ def main():
             "config": {"workload": f"synthetic {args.width}x{args.height} RGB-D room, {args.points} seeded neural points, "
                                    f"{args.mix} iteration mix: track {tr['pixels']}px x {tr['iters']}it per frame, map "
                                    f"{mp['pixels']}px x {mp['iters']}it + {mp['pixels_adding']} add-pixels every "
-                                   f"{mp['every_frame']} frames, window {mp['mapping_window_size']}",
+                                   f"{mp['every_frame']} frames, window {mp['mapping_window_size']}"
+                                   + (f"; sensor depth noise {args._depth_noise:g} x depth, {args._depth_dropout:g} of the pixels dropped to 0"
+                                      if (args._depth_noise or args._depth_dropout) else ""),
                        "engine": args.engine, "points_start": points_start, "points_end": points_end,
                        "points_added_per_mapped_frame": round(state["added"] / mapped_total, 1),
                        "mapped_frames": state["mapped"],

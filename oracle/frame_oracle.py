@@ -75,3 +75,11 @@ def keyframe_overlap(rays_o, rays_d, gt_depth, c2w_list, H, W, fx, fy, cx, cy, n
         m = m & (zz[:, :, 0] < 0)
         out.append(m.reshape(-1).sum() / uv.shape[0])
     return np.array(out)
+
+
+def keyframe_selection(percent_inside, k, rng=np.random):
+    """src/Mapper.py:229-235: keyframes sorted by percent_inside (descending, stable), those with any overlap, a random
+    permutation of them (np.random -- the caller seeds it), the first k."""
+    order = sorted(range(len(percent_inside)), key=lambda i: percent_inside[i], reverse=True)
+    sel = [i for i in order if percent_inside[i] > 0.0]
+    return [int(i) for i in rng.permutation(np.array(sel))[:k]]

@@ -8,7 +8,12 @@ exist on the GPU box, so nothing that runs there may call ``load()``.
 Stubs (sys.modules) for dependencies that are absent from the image:
   faiss            -> exact k-NN index (oracle.knn_exact): the FAISS seam is
                       parity-unpinned, see the oracle header.
-  skimage, cv2, wandb, colorama, open3d, torchmetrics, pytorch_msssim,
+  cv2              -> ``remap`` + ``INTER_LINEAR`` only (numpy, see _cv2_remap): the one cv2 call on the
+                      path, the depth lookup of Mapper.get_mask_from_c2w (src/Mapper.py:149-155).  With it the
+                      UNMODIFIED method runs here and pins its projection, dtype chain, edge crop, hole rule
+                      and depth + 0.5 test (oracle/gen_golden_frame.py); the interpolation inside remap itself
+                      stays a restatement of OpenCV's published algorithm (CV2_REMAP_RULE selects it).
+  skimage, wandb, colorama, open3d, torchmetrics, pytorch_msssim,
   src.utils.datasets, src.utils.Visualizer, src.utils.Logger -> inert shells
                       (none of them is on the hot path).
 Two CPU-only failures of the reference are wrapped, not edited:
@@ -26,6 +31,7 @@ import torch
 
 REF = os.environ.get("POINTSLAM_REFERENCE", "/root/reference")
 _loaded = None
+CV2_REMAP_RULE = "cv2"        # "cv2": INTER_LINEAR as OpenCV computes it (1/32-pixel fixed point); "exact": plain bilinear
 
 
 def available() -> bool:
@@ -56,6 +62,42 @@ class _ExactIndex:
         return O.knn_exact(self._pts, q.detach().float().cpu(), k)
 
 
+def _cv2_remap(src, map1, map2, interpolation=1, **kw):
+    """Stand-in for cv2.remap(src, map1, map2, interpolation=cv2.INTER_LINEAR) with float32 maps and the default
+    BORDER_CONSTANT 0, in numpy.  1-D maps are n x 1 images, as cv2 treats them (the caller takes [:, 0]).
+    CV2_REMAP_RULE == "cv2": OpenCV's remap() for CV_32FC1 maps (imgproc/src/imgwarp.cpp): sx = cvRound(x * 32),
+    integer part sx >> 5 saturated to int16, weights from the fractional 5 bits, taps summed row by row;
+    "exact": bilinear interpolation at the unquantised coordinate."""
+    import numpy as np
+    assert interpolation == 1 and not kw
+    img = np.asarray(src, dtype=np.float32)
+    H, W = img.shape
+    x = np.asarray(map1, dtype=np.float32).reshape(-1)
+    y = np.asarray(map2, dtype=np.float32).reshape(-1)
+    near = (np.abs(x) < 1.0e6) & (np.abs(y) < 1.0e6)              # NaN compares false
+    xs, ys = np.where(near, x, np.float32(0)), np.where(near, y, np.float32(0))
+    if CV2_REMAP_RULE == "cv2":
+        sx = np.rint(xs * np.float32(32)).astype(np.int64)      # cvRound: round half to even
+        sy = np.rint(ys * np.float32(32)).astype(np.int64)
+        ix, iy = np.clip(sx >> 5, -32768, 32767), np.clip(sy >> 5, -32768, 32767)
+        ax = (sx & 31).astype(np.float32) * np.float32(1.0 / 32.0)
+        ay = (sy & 31).astype(np.float32) * np.float32(1.0 / 32.0)
+    else:
+        fx_, fy_ = np.floor(xs), np.floor(ys)
+        ix, iy = fx_.astype(np.int64), fy_.astype(np.int64)
+        ax, ay = xs - fx_, ys - fy_
+    out = np.zeros(x.shape, dtype=np.float32)
+    one = np.float32(1)
+    for ky, wy in ((0, one - ay), (1, ay)):
+        for kx, wx in ((0, one - ax), (1, ax)):
+            xx, yy = ix + kx, iy + ky
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            val = np.where(ok, img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], np.float32(0))
+            out = out + val * (wy * wx)
+    out = np.where(near, out, np.float32(0)).astype(np.float32)
+    return out.reshape(-1, 1)
+
+
 def _install_stubs():
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -72,7 +114,7 @@ def _install_stubs():
     sk = mod("skimage")
     sk.color = mod("skimage.color", rgb2gray=None)
     sk.filters = mod("skimage.filters")
-    mod("cv2")
+    mod("cv2", remap=_cv2_remap, INTER_LINEAR=1)
     mod("wandb")
     mod("open3d")
     mod("colorama", Fore=types.SimpleNamespace(MAGENTA="", GREEN="", RED=""),

@@ -164,6 +164,28 @@ def test_keyframe_overlap_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_keyframe_selection_overlap_matches_reference_fixture():
+    """psl_keyframe_overlap_sync + the host permutation against the UNMODIFIED Mapper.keyframe_selection_overlap
+    (src/Mapper.py:170-235; tests/golden/keyframe_overlap_ref.npz from oracle/gen_golden_frame.py): percent_inside of the
+    eight keyframes (a sample within float32 rounding of the 20-pixel border may fall on either side: <= 2 of 920), the same
+    keyframes with and without overlap, and -- np.random seeded as the generator seeded it -- the very list returned."""
+    from point_slam_amd import frame_ops as FO
+    from tests.helpers import load_npz
+    dev = torch.device("cuda:0")
+    k = load_npz("keyframe_overlap_ref")
+    cam = dict(H=k["H"], W=k["W"], fx=k["fx"], fy=k["fy"], cx=k["cx"], cy=k["cy"])
+    kfs = [c for c in k["kf_c2w"]]
+    want = k["percent_inside"].numpy()
+    ro, rd, gd = k["rays_o"].to(dev), k["rays_d"].to(dev), k["ray_depth"].to(dev)
+    got = FO.keyframe_overlap(ro, rd, gd, kfs, cam)
+    n = ro.shape[0] * 8
+    assert np.abs(got - want).max() <= 2.0 / n + 1e-7
+    assert np.array_equal(got > 0, want > 0)
+    sel = FO.keyframe_selection_overlap(ro, rd, gd, kfs, cam, k=k["k"], rng=np.random.RandomState(k["seed"]))
+    assert [int(i) for i in sel] == k["selected"].tolist()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("size", [(640, 480), (333, 201)])
 def test_image_metrics_match_oracle(size):
     from oracle import eval_oracle as E

@@ -233,6 +233,34 @@ def test_loss_parity_vs_oracle_at_1m_points(world, oracle_world, kind, n_pix):
             assert rep["g_params_rel_l2"] < 1e-3 and rep["g_params_cos"] > 0.99999
 
 
+@pytest.mark.parametrize("kind,n_pix", [("tracker", 5000), ("map_color", 10000)])
+def test_loss_parity_on_the_noisy_depth_stream(world, oracle_world, kind, n_pix):
+    """BASELINE config 3 ("TUM fr1_desk ... noisy-depth path with 5k pixels/iter"): the TUM-like stream of SURVEY.md 8d --
+    sensor depth with 0.5 % multiplicative noise and 2 % of the pixels dropped to 0 -- at the TUM pixel budgets on the 1 M-point
+    map.  The holes go through the depth > 0 compaction, the noisy depths move the five samples of a ray off the map's
+    surfaces (fewer neighbours inside the radius, more invalid rays); same bounds as the clean stream."""
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.slam import Frame
+    from tests import parity_probe as PP
+    w = world
+    g = torch.Generator(device=w["dev"]).manual_seed(17)
+    fr0 = w["frame"]
+    depth, color = syn.render_frame(w["cam"], fr0.c2w, noise=0.005, dropout=0.02, gen=g)
+    fr = Frame(0, depth, color, fr0.r_add, fr0.r_query, fr0.c2w)
+    holes = float((depth == 0).float().mean())
+    rep = PP.probe(w["slam"], w["cfg"], w["cam"], fr, kind, n_pix, seed=300 + n_pix, state=oracle_world)
+    report(test="fullsize_loss_parity_noisy_depth", holes=holes, **rep)
+    assert 0.015 < holes < 0.025
+    assert rep["points"] >= 1_000_000 and 0.95 * n_pix < rep["rays"] < 0.995 * n_pix        # the holes are gone from the batch
+    assert rep["mask_mismatch"] == 0 and rep["valid_mismatch"] == 0
+    assert rep["loss_rel"] <= 1e-4 and rep["geo_loss_rel"] <= 1e-4 and rep["col_loss_rel"] <= 1e-4
+    assert rep["depth_rel_max"] < 2e-4 and rep["rgb_abs_max"] < 5e-3
+    if kind == "tracker":
+        assert rep["g_rays_o_rel_l2"] < 2e-3 and rep["g_rays_d_rel_l2"] < 2e-3
+    else:
+        assert rep["g_geo_rel_l2"] < 1e-3 and rep["g_col_rel_l2"] < 1e-3 and rep["g_params_rel_l2"] < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[4]: synthetic 1280x960 stream, 2 M seeded neural points (the grid index works with <= 2^22 cells:
 # untested at that density before round 3)

@@ -160,6 +160,37 @@ def test_frustum_select_matches_oracle(remap):
     assert torch.equal(got, torch.sort(got).values)
 
 
+@pytest.mark.parametrize("rule", ["cv2", "exact"])
+def test_frustum_select_matches_reference_fixture(rule):
+    """psl_frustum_select_sync against the rows the UNMODIFIED Mapper.get_mask_from_c2w selected (src/Mapper.py:120-168;
+    tests/golden/frustum_ref.npz from oracle/gen_golden_frame.py, one run per cv2.remap interpolation rule).  The reference
+    projects in float64 through a float32 inverse pose; the kernel works in float32, so a point within float32 rounding of the
+    depth + 0.5 test or of the edge crop may fall on either side: at most 3 of 9 200 rows (2 300 of them were placed within a
+    centimetre of the depth test)."""
+    from point_slam_amd import _lib
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    fx = load_npz("frustum_ref")
+    cfg = base_cfg()
+    cfg["mapping"]["frustum_edge"] = fx["edge"]
+    cam = dict(H=fx["H"], W=fx["W"], fx=fx["fx"], fy=fx["fy"], cx=fx["cx"], cy=fx["cy"])
+    s = _slam(cfg, cam, "native", dev)
+    s.seed_points(fx["cloud"].to(dev))
+    fr = Frame(0, fx["depth"].to(dev), torch.zeros(fx["H"], fx["W"], 3, device=dev), None, None, fx["c2w"].to(dev))
+    L = _lib.lib()
+    try:
+        _lib.check(L.psl_debug_option(b"remap_cv2", 1 if rule == "cv2" else 0))
+        sel, _ = s.frustum_select(fr, fr.c2w)
+    finally:
+        _lib.check(L.psl_debug_option(b"remap_cv2", 1))
+    got, ref = set(sel.cpu().tolist()), set(fx["sel_" + rule].tolist())
+    other = set(fx["sel_exact" if rule == "cv2" else "sel_cv2"].tolist())
+    report(test="frustum_reference_fixture", rule=rule, n_sel=len(got), n_ref=len(ref), sym_diff=len(got ^ ref),
+           sym_diff_vs_other_rule=len(got ^ other))
+    assert len(got ^ ref) <= 3
+    assert len(got ^ other) > len(got ^ ref) + 5
+
+
 def test_frustum_select_uses_the_per_point_depth_maximum():
     """Mapper.py:161-162: points whose bilinear depth lookup is 0 (sensor holes) take np.max over the PER-POINT lookups, not
     the image maximum.  A frame whose depth image holds a far outlier region that no map point projects into tells the two

@@ -86,6 +86,30 @@ def test_rocpd_timeline_and_gaps(tmp_path):
     assert "kernels 121" in gaps.splitlines()[0]
 
 
+def test_rocpd_window_cuts_the_trace_at_the_bench_markers(tmp_path):
+    """tools/rocpd_window.py: the kernels between bench.py's marker launches (PSL_BENCH_MARK=1), device-busy union, holes and
+    their attribution, per pass."""
+    db = str(tmp_path / "t_results.db")
+    _trace_db(db)
+    con = sqlite3.connect(db)
+    con.execute("insert into rocpd_info_kernel_symbol values (7, 'void at::native::erfinv_kernel_something(int).kd')")
+    # markers: before iteration 0, after iteration 19 (pass 1), before iteration 20, after the last kernel (pass 2)
+    per_it = 48_000 + 49_000 + 26_000 + 3_000
+    t_mid = 1_000_000 + 20 * per_it + 2 * 60_000
+    for st in (999_000, t_mid - 900, t_mid - 600, 1_000_000 + 40 * per_it + 4 * 60_000 + 26_000):
+        con.execute("insert into rocpd_kernel_dispatch (kernel_id, start, end) values (7, ?, ?)", (st, st + 100))
+    con.commit(); con.close()
+    js = str(tmp_path / "w.json")
+    out = _run("rocpd_window.py", db, "--json", js)
+    res = json.load(open(js))
+    assert len(res) == 2 and res[0]["kernels"] == 60 and res[1]["kernels"] == 61
+    assert abs(res[0]["busy_ms"] - 20 * 0.123) < 1e-6
+    # pass 1: one 61-us host stall inside (after iteration 9; the one after iteration 19 lies behind the last kernel)
+    assert sum(h["n"] for h in res[0]["holes"] if h["lo_us"] >= 30) == 1
+    assert "k_decode_fwd2<1>" in res[0]["long_holes_by_next"] and "psl4k_dw" in "".join(res[0]["long_holes_by_prev"])
+    assert "== pass 2" in out
+
+
 def test_pmc_traffic_classes_and_fetch_correction(tmp_path):
     def table(counter, rows):
         p = tmp_path / f"{counter}.csv"

@@ -64,9 +64,10 @@ EOF
       python tools/block_trace.py $O/${TAG}_blocks.raw > $O/${TAG}_block_trace.txt 2>&1; rm -f $O/${TAG}_blocks.raw
       grep -A3 "P=5000 flags=0x1000d" $O/${TAG}_block_trace.txt | tail -8 ;;
     trace)
-      env $(sp "$a2") timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- python bench.py $(sp "$a1") > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
+      env PSL_BENCH_MARK=1 $(sp "$a2") timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- python bench.py $(sp "$a1") > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
       python tools/rocpd_stats.py $O/prof_$TAG/${TAG}_results.db --csv $O/${TAG}_kernel_trace_stats.csv --by-grid adam_lazy | grep -E "by-grid|^kernel|^[^,]*,[0-9]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+$" | head -26
       python tools/rocpd_timeline.py $O/prof_$TAG/${TAG}_results.db 0.5 > $O/${TAG}_timeline.txt 2>&1
+      python tools/rocpd_window.py $O/prof_$TAG/${TAG}_results.db --json $O/${TAG}_window.json > $O/${TAG}_window.txt 2>&1; grep "== pass" $O/${TAG}_window.txt
       rm -rf $O/prof_$TAG ;;
     pmc)
       mix=${a1:-base}; P=$O/${TAG}_pmc_$mix; mkdir -p $P
