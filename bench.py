@@ -498,7 +498,7 @@ def main():
     def timed(first):
         barrier()
         if mark is not None:        # a kernel no other code launches: tools/rocpd_window.py cuts the rocprofv3 trace at these
-            torch.erfinv_(mark)
+            mark.erfinv_()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(first, first + args.steps):
@@ -506,7 +506,7 @@ def main():
         barrier()
         d = time.perf_counter() - t0
         if mark is not None:
-            torch.erfinv_(mark)
+            mark.erfinv_()
             torch.cuda.synchronize()
         if world > 1:
             tt = torch.tensor([d], device=dev, dtype=torch.float64)

@@ -348,7 +348,10 @@ int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_d, const fl
  * neural points").  The reference has no distributed code (no NCCL / torch.distributed call anywhere in it); frames are
  * partitioned one per GPU and the replicas exchange record blocks.  librccl is resolved with dlopen at the first call.
  *   psl_comm_unique_id : rank 0 obtains the 128-byte ncclUniqueId; the host hands it to every rank (any side channel)
- *   psl_comm_init      : ncclCommInitRank on the ctx's device; the communicator lives in the ctx
+ *   psl_comm_reserve   : (ABI 6) everything psl_comm_init does that can fail on one rank alone (dlopen of librccl, the
+ *                        device ints of the counts phase): a host calls it on every rank and lets the ranks agree on the
+ *                        outcome before anybody enters the rendezvous of ncclCommInitRank
+ *   psl_comm_init      : psl_comm_reserve, then ncclCommInitRank on the ctx's device; the communicator lives in the ctx
  *   psl_allgather_new_points : all-gather-v of per-rank record blocks [n_local][rec_floats] f32 (new points: xyz +
  *                        32 geometry + 32 colour features + add-radius = 68 floats; touched feature rows: row id + 64
  *                        changes) in rank order into rec_all [sum][rec_floats]; counts_host[world] receives the per-rank row
@@ -359,6 +362,7 @@ int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_d, const fl
  *                        any rank), i.e. by every rank alike and before the records collective: all ranks may grow their
  *                        buffers from counts_host (valid on that return) and call again. */
 int psl_comm_unique_id(void* id_out_128_bytes);
+int psl_comm_reserve(psl_ctx* ctx, int world);
 int psl_comm_init(psl_ctx* ctx, const void* id_128_bytes, int rank, int world);
 int psl_comm_destroy(psl_ctx* ctx);
 int psl_allgather_new_points(psl_ctx* ctx, void* nccl_comm, int world, const float* rec_local, int n_local, int rec_floats,

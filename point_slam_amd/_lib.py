@@ -17,10 +17,10 @@ class PslError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
+ABI_VERSION = 6     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
 #                     full-image pixel indices in psl_track_args, step0_params in psl_map_args; v4: psl_dedupe_count / psl_dedupe_blocks,
 #                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields;
-#                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math
+#                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math; v6: psl_comm_reserve
 EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 
 
@@ -110,6 +110,7 @@ _SIGS = {
     "psl_dedupe_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "psl_dedupe_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "psl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "psl_comm_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "psl_comm_destroy": (C.c_int, [C.c_void_p]),
     "psl_allgather_new_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -164,15 +165,27 @@ def lib():
             raise PslError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
+        missing = []
         for name, (res, args) in _SIGS.items():
             try:
                 fn = getattr(L, name)   # AttributeError if the symbol is missing
             except AttributeError:
                 if os.environ.get("PSL_LIB"):     # an older build loaded for an A/B run: newer entry points are absent
+                    missing.append(name)
                     continue
                 raise
             fn.restype = res
             fn.argtypes = args
+        ver = int(L.psl_abi_version())
+        if ver != ABI_VERSION or missing:
+            # struct layouts and signatures belong to ONE ABI version: a silent mismatch measures garbage (advisor, round 4)
+            msg = (f"{LIB_PATH}: psl_abi_version() = {ver}, this binding is ABI {ABI_VERSION}"
+                   + (f"; entry points absent from the library: {', '.join(missing)}" if missing else ""))
+            if not os.environ.get("PSL_LIB") or os.environ.get("PSL_LIB_ALLOW_ABI_MISMATCH") != "1":
+                raise PslError(msg + " (an A/B run of an older build: set PSL_LIB_ALLOW_ABI_MISMATCH=1 once the struct layouts "
+                                     "of the calls it makes are known to be unchanged)")
+            import sys
+            print("[point_slam_amd._lib] WARNING " + msg, file=sys.stderr, flush=True)
         _lib = L
     return _lib
 

@@ -184,7 +184,7 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
 using namespace psl;
 
 extern "C" const char* psl_last_error(void) { return g_err; }
-extern "C" int psl_abi_version(void) { return 5; }
+extern "C" int psl_abi_version(void) { return 6; }
 
 extern "C" int psl_param_count(void) { return kNumParams; }
 extern "C" int psl_param_color_count(void) { return kNumColorParams; }

@@ -80,16 +80,23 @@ extern "C" int psl_comm_unique_id(void* id_out) {
   return PSL_OK;
 }
 
+// Everything psl_comm_init needs that can fail on ONE rank alone: librccl and the device ints of the counts phase.  A host
+// calls it on every rank and lets the ranks agree on the outcome BEFORE anybody enters ncclCommInitRank (a rank that failed
+// here would otherwise leave the others blocked in the communicator's rendezvous; advisor, round 4).
+extern "C" int psl_comm_reserve(psl_ctx* ctx, int world) {
+  if (!ctx || world < 1 || world > kMaxCommWorld) { set_error("psl_comm_reserve: bad argument"); return PSL_ERR_ARG; }
+  int rc = rccl_load(); if (rc) return rc;
+  PSL_HIP(hipSetDevice(ctx->device));
+  return comm_counts_reserve(ctx, world);
+}
+
 extern "C" int psl_comm_init(psl_ctx* ctx, const void* id_in, int rank, int world) {
   if (!ctx || !id_in || world < 1 || rank < 0 || rank >= world) { set_error("psl_comm_init: bad argument"); return PSL_ERR_ARG; }
   if (ctx->comm) { set_error("psl_comm_init: this context already has a communicator"); return PSL_ERR_STATE; }
-  int rc = rccl_load(); if (rc) return rc;
-  PSL_HIP(hipSetDevice(ctx->device));
+  int rc = psl_comm_reserve(ctx, world); if (rc) return rc;    // rank-local failures first, the collective last
   RcclId id; memcpy(&id, id_in, sizeof(id));
   void* comm = nullptr;
   PSL_NCCL(g_rccl.CommInitRank(&comm, world, id, rank));
-  rc = comm_counts_reserve(ctx, world);
-  if (rc) { (void)g_rccl.CommDestroy(comm); return rc; }       // no communicator is left behind on a failed init
   ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
   return PSL_OK;
 }

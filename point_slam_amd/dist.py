@@ -27,11 +27,20 @@ scales with the size of the map:
  4. COLOUR DECODER.  The same rule on the trainable colour-decoder blob (all-reduce of the per-rank changes, 109 k
     floats): features gathered from rank k were trained against rank k's decoder, so the decoders must not drift apart.
 
-Transport: on the "nccl" backend (= RCCL on ROCm; what a multi-GPU node runs) the all-gather-v's go through
-`psl_allgather_new_points` inside libpointslam_hip.so on the library's own RCCL communicator (`psl_comm_init`; the
-128-byte ncclUniqueId travels over torch.distributed once); on gloo (CPU tests, ranks sharing one GPU) through
-torch.distributed collectives.  `transport="native"|"torch"` / PSL_NATIVE_RCCL=1|0 force either.  Unmeasured on xGMI: no
-multi-GPU node has been available to any session so far.
+Transport: the all-gather-v's go through torch.distributed collectives by default -- on the "nccl" backend that IS RCCL
+over xGMI (what a multi-GPU node runs), on gloo the CPU tests / ranks sharing one GPU.  The same exchange inside
+libpointslam_hip.so (`psl_allgather_new_points` on the library's own RCCL communicator, `psl_comm_init`; the 128-byte
+ncclUniqueId travels over torch.distributed once) is OPT-IN: `transport="native"` / PSL_NATIVE_RCCL=1.  It has only ever run
+on a one-rank communicator (no multi-GPU node has been available to any session), so it is not the path a first 8-GPU run
+takes by default (advisor, round 4); tests/test_hip_dist.py::test_exchange_two_gpus_nccl runs BOTH transports with two
+ranks wherever two GPUs are visible.  Before any rank enters ncclCommInitRank the ranks agree (all-reduce over
+torch.distributed) that every one of them could load librccl and reserve its device buffers: a rank-local failure can no
+longer leave the others blocked inside the communicator's rendezvous.
+
+Merge rule for the features of points several ranks trained (`merge=`): "mean" (default) = snapshot + mean of the per-rank
+changes; "owner" = SURVEY.md 8e's owner-writes policy: the rank that CREATED the point wins if it changed the row (points of
+the seed map and rows their creator did not touch: the lowest contributing rank).  Both are deterministic and
+rank-invariant; bench.py --merge reports the render loss after the exchange under either.
 """
 from __future__ import annotations
 
@@ -80,20 +89,36 @@ class _NativeTransport:
         self._lib, self.npc, self.group = _lib, npc, group
         self.world, rank = dist.get_world_size(group), dist.get_rank(group)
         L = _lib.lib()
+        dev = npc.get_geo_feats().device
+        flag_dev = dev if dev.type == "cuda" and dist.get_backend(group) == "nccl" else "cpu"
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], device=flag_dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+        # pre-init agreement (advisor r4): EVERY rank does everything psl_comm_init does in front of ncclCommInitRank -- dlopen of
+        # librccl + its symbols (ncclGetUniqueId on a scratch id exercises both) and the device buffers of the counts phase
+        # (psl_comm_reserve) -- and the ranks compare notes BEFORE anybody enters the communicator's rendezvous
+        scratch = C.create_string_buffer(128)
+        rc0 = L.psl_comm_unique_id(scratch)
+        if rc0 >= 0:
+            rc0 = L.psl_comm_reserve(npc.handle, self.world)
+        if not all_ok(rc0 >= 0):
+            raise RuntimeError("native RCCL transport: librccl / device buffers unavailable on some rank"
+                               + (": " + L.psl_last_error().decode() if rc0 < 0 else ""))
         ident = C.create_string_buffer(128)
         box = [None]
         if rank == 0:
             if L.psl_comm_unique_id(ident) >= 0:
                 box = [bytes(ident.raw)]
             else:
-                box = [None]                                     # e.g. librccl not found: tell the others instead of leaving them waiting
+                box = [None]                                     # tell the others instead of leaving them waiting
         dist.broadcast_object_list(box, src=0, group=group)      # the only use of torch.distributed on the data path set-up
         if box[0] is None:
             raise RuntimeError("psl_comm_unique_id failed on rank 0: " + (L.psl_last_error().decode() if rank == 0 else "(see rank 0)"))
         ident = C.create_string_buffer(box[0], 128)
         rc = L.psl_comm_init(npc.handle, ident, rank, self.world)
-        dev = npc.get_geo_feats().device
-        ok = torch.tensor([1 if rc >= 0 else 0], device=dev if dev.type == "cuda" else "cpu", dtype=torch.int32)
+        ok = torch.tensor([1 if rc >= 0 else 0], device=flag_dev, dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 0:
             if rc >= 0:
@@ -123,16 +148,13 @@ class _NativeTransport:
 
 
 def make_transport(npc, group=None, kind: Optional[str] = None):
-    """`kind` None: the library's own RCCL all-gather-v when the process group runs on the "nccl" (= RCCL) backend -- the path
-    a multi-GPU node takes --, torch.distributed collectives otherwise (gloo: CPU tests, ranks sharing one GPU).
-    PSL_NATIVE_RCCL=1 / 0 forces either."""
+    """`kind` None: torch.distributed collectives (backend "nccl" = RCCL over xGMI on a multi-GPU node; gloo in the CPU tests
+    and for ranks sharing one GPU).  "native" / PSL_NATIVE_RCCL=1: the library's own RCCL all-gather-v -- opt-in until it has
+    run with more than one rank (module docstring)."""
     forced = kind is not None
     if kind is None:
         env = os.environ.get("PSL_NATIVE_RCCL")
-        if env in ("0", "1"):
-            kind, forced = ("native" if env == "1" else "torch"), True
-        else:
-            kind = "native" if dist.get_backend(group) == "nccl" else "torch"
+        kind, forced = ("native", True) if env == "1" else ("torch", env == "0")
     if kind == "native":
         try:
             return _NativeTransport(npc, group)
@@ -147,11 +169,17 @@ def make_transport(npc, group=None, kind: Optional[str] = None):
     return _TorchTransport(group)
 
 
+def transport_name(tr) -> str:
+    return "native (psl_allgather_new_points on the library's RCCL communicator)" if isinstance(tr, _NativeTransport) \
+        else f"torch.distributed all_gather ({dist.get_backend(tr.group)})"
+
+
 # ------------------------------------------------------------------------------------------------------- new points
-def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transport=None) -> List[int]:
+def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transport=None, creators: Optional[list] = None) -> List[int]:
     """Exchange the points `npc` gained since it had n_base points and rebuild the replica in global rank order
     (steps 1-2 of the module docstring).  Returns the number of points every rank CONTRIBUTED; the number admitted
-    after the cross-rank dedupe is npc.pts_num() - n_base."""
+    after the cross-rank dedupe is npc.pts_num() - n_base.  creators: a list that receives ONE int16 tensor, the
+    contributing rank of every admitted point in append order (the owner-writes merge rule needs it)."""
     tr = transport or _TorchTransport(group)
     n_now = npc.pts_num()
     n_new = n_now - n_base
@@ -185,6 +213,10 @@ def merge_new_points(npc, n_base: int, group=None, dedupe: bool = True, transpor
         keep_loc = keep_loc.bool()
         keep = keep_loc[:, None].expand(-1, 3).reshape(-1)
     kept = allrec[keep]
+    if creators is not None:
+        blk = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int16, device=dev),
+                                      torch.tensor(counts, device=dev))
+        creators.append(blk[keep])
     npc.truncate(n_base)
     # ONE append and ONE index rebuild for all blocks (also when nothing was kept: truncate left the index stale)
     npc.append_points(kept[:, :3].contiguous(), kept[:, 3:35].contiguous(), kept[:, 35:67].contiguous(),
@@ -198,8 +230,12 @@ class FrameParallelSync:
     (`note_rows`) and of the colour-decoder blob."""
 
     def __init__(self, npc, theta: Optional[torch.Tensor] = None, n_color: int = 0, group=None,
-                 transport: Optional[str] = None):
+                 transport: Optional[str] = None, merge: str = "mean"):
+        if merge not in ("mean", "owner"):
+            raise ValueError("merge must be 'mean' or 'owner'")
         self.group = group
+        self.merge = merge
+        self._owner = None          # int16 [capacity]: rank that created a point, -1 = the seed map (owner-writes rule)
         self.n_color = n_color
         self.transport = make_transport(npc, group, transport)
         self.snap_theta = theta[:n_color].clone() if theta is not None else None
@@ -252,6 +288,7 @@ class FrameParallelSync:
         if sum(counts):
             ids = allrec[:, 0].contiguous().view(torch.int32).long()
             uniq, inv = torch.unique(ids, return_inverse=True)       # sorted: the same order on every rank
+            delta_all = allrec[:, 1:]
             allrec[:, 0] = 1.0                                       # column 0 now counts the contributors of a row
             tot = torch.zeros(uniq.shape[0], REC_ROW, device=dev)
             off, mine = 0, None
@@ -266,7 +303,24 @@ class FrameParallelSync:
             base = torch.cat([geo[uniq], col[uniq]], 1)              # rows this rank did not change still hold the snapshot
             if mine is not None:
                 base[mine] = snap_c
-            new = base + tot[:, 1:] / tot[:, :1]
+            if self.merge == "owner":
+                # SURVEY.md 8e owner-writes: the change of the rank that created the point if it is among the contributors,
+                # else the lowest contributing rank's (seed-map points have no creator) -- one contributor's change, whole
+                own = self._owner[uniq] if self._owner is not None else torch.full_like(uniq, -1, dtype=torch.int16)
+                best = torch.full((uniq.shape[0],), 1 << 20, dtype=torch.int64, device=dev)
+                win = torch.zeros(uniq.shape[0], 64, device=dev)
+                off = 0
+                for k, c in enumerate(counts):
+                    if c:
+                        sl = inv[off:off + c]
+                        prio = torch.where(own[sl] == k, torch.full_like(sl, -1), torch.full_like(sl, k))
+                        better = prio < best[sl]
+                        best[sl[better]] = prio[better]
+                        win[sl[better]] = delta_all[off:off + c][better]
+                    off += c
+                new = base + win
+            else:
+                new = base + tot[:, 1:] / tot[:, :1]
             geo[uniq] = new[:, :32]
             col[uniq] = new[:, 32:]
         if self._rows:
@@ -283,7 +337,17 @@ class FrameParallelSync:
             dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
             theta[:self.n_color] = self.snap_theta + d / dist.get_world_size(self.group)
         # 1-2. new points
-        counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport)
+        creators: list = []
+        counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport, creators)
+        if creators and creators[0].numel():
+            geo = npc.get_geo_feats()
+            cap = max(getattr(npc, "_max_points", 0) or 0, geo.shape[0], self.n_base + int(creators[0].numel()))
+            if self._owner is None or self._owner.shape[0] < cap:
+                old = self._owner
+                self._owner = torch.full((cap,), -1, dtype=torch.int16, device=geo.device)
+                if old is not None:
+                    self._owner[:old.shape[0]] = old
+            self._owner[self.n_base:self.n_base + creators[0].numel()] = creators[0]
         if theta is not None:
             self.snap_theta = theta[:self.n_color].clone()
         self.n_base = npc.pts_num()

@@ -227,3 +227,54 @@ def test_exchange_world4_empty_ranks_and_a_block_deduped_away():
     geo, bg = res[0][6], res[0][7]
     d = geo[:4, 0] - bg[:4, 0]
     assert torch.allclose(d, torch.tensor([1.0, 4.0, 0.0, 0.0]))                    # row 1: mean of +2 and +6
+
+
+def _worker_owner(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from point_slam_amd.dist import FrameParallelSync
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(6, 3, generator=g) + 5.0
+    cloud = FakeCloud(base.clone(), torch.zeros(6, 32), torch.zeros(6, 32))
+    sync = FrameParallelSync(cloud, None, merge="owner")
+    # interval 1: every rank creates one location far from the others' (three points each) -> rows 6..8 belong to rank 0,
+    # 9..11 to rank 1, 12..14 to rank 2 on every replica
+    cloud.append_points(_triplets(torch.tensor([[1.0 + rank, 1.0, 1.0]])), torch.zeros(3, 32), torch.zeros(3, 32))
+    sync.exchange(cloud)
+    owner = sync._owner[:cloud.pts_num()].clone()
+    # interval 2: row 10 (created by rank 1) is changed by ranks 0, 1, 2 -> rank 1's change wins;
+    #             row 13 (created by rank 2) by ranks 0 and 1 only -> the lowest contributor (rank 0) wins;
+    #             row 2 (seed map) by ranks 1 and 2 -> rank 1 wins; row 7 by its creator alone
+    rows = {0: [10, 13, 7], 1: [10, 13, 2], 2: [10, 2]}[rank]
+    sync.note_rows(cloud, torch.tensor(rows))
+    for r in rows:
+        cloud.geo[r] += float(10 ** rank) * (1 + r)         # 1x, 10x, 100x (1 + row)
+        cloud.col[r] -= float(10 ** rank)
+    sync.exchange(cloud)
+    q.put((rank, _np(owner), _np(cloud.geo[:, 0].clone()), _np(cloud.col[:, 0].clone())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owner_writes_merge_rule_world3():
+    """merge='owner' (SURVEY.md 8e): the creating rank's change wins when it is among the contributors, otherwise the lowest
+    contributing rank's; creators are learnt at the exchange that admits the points; replicas identical."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_owner, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([tuple(_t(x) for x in q.get(timeout=300)) for _ in range(3)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res[1:]:
+        assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2]) and torch.equal(r[3], res[0][3])
+    owner, geo, col = res[0][1], res[0][2], res[0][3]
+    assert owner.tolist() == [-1] * 6 + [0] * 3 + [1] * 3 + [2] * 3
+    assert geo[10] == 10.0 * 11 and col[10] == -10.0          # creator (rank 1) among three contributors
+    assert geo[13] == 1.0 * 14 and col[13] == -1.0            # creator absent: lowest contributor (rank 0)
+    assert geo[2] == 10.0 * 3 and col[2] == -10.0             # seed-map row: lowest contributor (rank 1)
+    assert geo[7] == 1.0 * 8                                  # its creator alone
+    assert float(geo[[0, 1, 3, 4, 5, 6, 8, 9, 11, 12, 14]].abs().sum()) == 0.0

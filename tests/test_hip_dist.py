@@ -24,26 +24,31 @@ def _t(x):
     return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", transport=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: both ranks on cuda:0 (RCCL refuses two ranks on one device); nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda:0" if backend == "gloo" else f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from point_slam_amd import synthetic as syn
         from point_slam_amd.dist import FrameParallelSync
         from point_slam_amd.neural_point import HipNeuralPointCloud
         from tests.helpers import base_cfg
-        dev = torch.device("cuda:0")
         cfg = base_cfg()
-        cfg["mapping"] = dict(cfg["mapping"], device="cuda:0")
+        cfg["mapping"] = dict(cfg["mapping"], device=str(dev))
         cam = syn.intrinsics(320, 240)
-        npc = HipNeuralPointCloud(cfg, max_points=200000, device="cuda:0")
+        npc = HipNeuralPointCloud(cfg, max_points=200000, device=str(dev))
         base = syn.seed_cloud(cam, 30000, n_views=4, seed=3)
         g = torch.Generator().manual_seed(9)
         npc.set_points(base.to(dev), torch.randn(base.shape[0], 32, generator=g).to(dev),
                        torch.randn(base.shape[0], 32, generator=g).to(dev))
         theta = torch.arange(16, dtype=torch.float32, device=dev)
-        sync = FrameParallelSync(npc, theta, n_color=12)
+        sync = FrameParallelSync(npc, theta, n_color=12, transport=transport)
         # two neighbouring frames (as frame t and t+1 of the frame-parallel split): heavily overlapping surfaces
         c2w = syn.pose(400.0 + 0.5 * rank, dev)
         depth, color = syn.render_frame(cam, c2w)
@@ -75,11 +80,26 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_exchange_two_gpus_nccl(transport):
+    """The same exchange with ONE GPU PER RANK on the nccl (= RCCL) backend, through torch.distributed's collectives and through
+    the library's own communicator (psl_comm_reserve -> agreement -> psl_comm_init -> psl_allgather_new_points with two
+    ranks: unequal blocks, the padded records collective, per-rank compaction).  Needs two visible GPUs; the boxes the GPU
+    tests have run on so far have one, so this is the test the first multi-GPU node runs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _run_two_ranks("nccl", transport)
+
+
 def test_exchange_on_real_point_cloud_two_ranks():
+    _run_two_ranks("gloo", None)
+
+
+def _run_two_ranks(backend, transport):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([tuple(_t(x) for x in q.get(timeout=600)) for _ in range(2)], key=lambda x: x[0])

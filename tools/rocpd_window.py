@@ -62,11 +62,24 @@ def analyse(rows, top=30):
             if en > cur_e:
                 cur_e, last = en, short(n)
     busy += (cur_e - cur_s) / 1e3
+    # outliers: launches that took more than 8x the median of their symbol (and more than 100 us), with what ran around them
+    by_sym = defaultdict(list)
+    for i, (n, st, en) in enumerate(rows):
+        by_sym[short(n)].append((en - st) / 1e3)
+    med = {k: sorted(v)[len(v) // 2] for k, v in by_sym.items()}
+    outliers = []
+    for i, (n, st, en) in enumerate(rows):
+        k, d = short(n), (en - st) / 1e3
+        if d > 100.0 and d > 8.0 * med[k]:
+            conc = sorted({short(m) for (m, s2, e2) in rows[max(0, i - 40):i + 40] if s2 < en and e2 > st and (m, s2, e2) != (n, st, en)})
+            outliers.append(dict(kernel=k, us=round(d, 1), median_us=round(med[k], 1), at_ms=round((st - rows[0][1]) / 1e6, 3),
+                                 prev=short(rows[i - 1][0]) if i else None, concurrent=conc[:6]))
     total = sum(dur.values())
     out = dict(span_ms=span / 1e3, busy_ms=busy / 1e3, idle_ms=(span - busy) / 1e3, kernel_sum_ms=total / 1e3,
                overlapped_ms=(total - busy) / 1e3, kernels=len(rows),
                by_kernel={k: dict(calls=cnt[k], total_ms=round(dur[k] / 1e3, 3), avg_us=round(dur[k] / cnt[k], 2))
                           for k in sorted(dur, key=lambda k: -dur[k])[:top]},
+               outliers=outliers[:40],
                holes=[dict(lo_us=lo, hi_us=(hi if hi < 1e11 else None), n=n, total_ms=round(s / 1e3, 3))
                       for (lo, hi), s, n in zip(bins, hole_sum, hole_n)],
                long_holes_by_next={k: dict(n=v[1], total_ms=round(v[0] / 1e3, 3)) for k, v in
@@ -100,6 +113,8 @@ def main():
         print("kernel,calls,total_ms,avg_us,pct_of_span")
         for k, v in r["by_kernel"].items():
             print(f"  {k},{v['calls']},{v['total_ms']},{v['avg_us']},{100 * v['total_ms'] / r['span_ms']:.1f}")
+        for o in r["outliers"]:
+            print(f"  OUTLIER {o['kernel']}: {o['us']} us (median {o['median_us']}) at +{o['at_ms']} ms, after {o['prev']}, concurrent with {o['concurrent']}")
         print("idle holes: range_us,n,total_ms")
         for h in r["holes"]:
             print(f"  {h['lo_us']}..{h['hi_us']},{h['n']},{h['total_ms']}")
