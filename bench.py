@@ -51,13 +51,27 @@ def parse():
                          "exchange inside the timed region (at its last mapped frame), so that its cost is in `value`")
     ap.add_argument("--track-only", action="store_true",
                     help="BASELINE config 1: tracking only on a FIXED cloud (no mapping, no point growth); every frame starts "
-                         "from the constant-speed extrapolation of the tracker's own previous estimates (Tracker.py:259-270). "
+                         "from the constant-speed extrapolation of the tracker's own previous estimates (Tracker.py:283-290). "
                          "Quoted with --points 50000 --width 1200 --height 680 --mix replica --steps 200")
     ap.add_argument("--depth-noise", type=float, default=None,
                     help="multiplicative Gaussian sensor-depth noise (sigma as a fraction of the depth); default: 0.005 for --mix tum "
                          "(SURVEY.md 8d: the TUM-like stream, 'sigma = 0.5 % d + 2 % dropout'), 0 otherwise")
     ap.add_argument("--depth-dropout", type=float, default=None,
                     help="fraction of pixels whose sensor depth is dropped to 0 (holes); default: 0.02 for --mix tum, 0 otherwise")
+    ap.add_argument("--open-loop", action="store_true",
+                    help="rounds 1-4: every frame starts from the ground-truth pose + noise.  Default since round 5: CLOSED loop -- "
+                         "frame i starts from the constant-speed extrapolation of the tracker's own two previous estimates "
+                         "(Tracker.py:283-290), the mapper maps at the tracker's estimate; config.ate_rmse_cm in the line")
+    ap.add_argument("--different-frames", action="store_true",
+                    help="rounds 1-4: the event-timed pass runs on the NEXT --steps frames.  Default since round 5: the map, the "
+                         "poses and the RNGs are snapshotted after the warm-up and restored, so that `value` (plain pass) and the "
+                         "kernel classes (event-carrying pass) are measured on the SAME frames")
+    ap.add_argument("--expandable-segments", action="store_true",
+                    help="N > 1: PYTORCH_HIP_ALLOC_CONF=expandable_segments:True for every rank (removes the rare 60-75 ms exchange "
+                         "stalls measured on one GPU, profiles/r04_exchange_timing_*; not the default because it has never run next "
+                         "to RCCL across GPUs and the first multi-GPU run should not depend on it)")
+    ap.add_argument("--merge", default="mean", choices=["mean", "owner"],
+                    help="N > 1: rule for feature rows several ranks trained (point_slam_amd/dist.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -115,7 +129,7 @@ def build_world(args, rank, world, dev):
     dropout = args.depth_dropout if args.depth_dropout is not None else (0.02 if args.mix == "tum" else 0.0)
     args._depth_noise, args._depth_dropout = noise, dropout
     g_noise = torch.Generator(device=dev).manual_seed(4242 + rank)
-    n_total = args.warmup + args.steps * (1 if args.no_kernel_timing else 2)
+    n_total = args.warmup + args.steps * (2 if (not args.no_kernel_timing and (args.different_frames or world > 1)) else 1)
     # frame-parallel partition: local step i is global frame rank + world*i
     frames, cams0 = [], []
     g = torch.Generator().manual_seed(1000 + rank)
@@ -132,11 +146,18 @@ def build_world(args, rank, world, dev):
                 continue                                             # fixed cloud, no keyframes
             # earlier keyframes: their views were MAPPED when they were taken, i.e. points were added where they saw
             # uncovered surface (untimed set-up; otherwise half of their samples would query empty space for ever)
-            slam.add_points(fr, c2w)
+            if args.open_loop:
+                slam.add_points(fr, c2w)
+            else:
+                # closed loop: ... and their features TRAINED, as a run that reached this frame would have left them (a
+                # tracker that starts on random features has nothing to localise against and the loop runs away)
+                slam.map(fr, c2w)
             slam.keyframes.append(fr)
         else:
             frames.append(fr)
-            # initial pose = ground truth + a perturbation of the size the constant-speed model leaves
+            fr.gt_c2w = c2w
+            fr.gt_cam = camera_tensor_from_c2w(c2w).to(dev)
+            # open loop: initial pose = ground truth + a perturbation of the size the constant-speed model leaves
             cam0 = camera_tensor_from_c2w(c2w) + torch.randn(7, generator=g) * torch.tensor([1e-3] * 4 + [5e-3] * 3)
             cams0.append(cam0.to(dev))
     return cfg, cam, slam, frames, cams0, every
@@ -152,28 +173,40 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         fr.r_add, fr.r_query = frame_ops.dynamic_radius_maps(fr.color, cfg)
     if getattr(args, "track_only", False):
         # closed loop on the tracker's own estimates, no host copy of a pose anywhere: frames 0 and 1 take the ground truth
-        # (Tracker.py:254-255), frame i >= 2 starts from delta @ pre_c2w, delta = pre_c2w @ inv(c2w[i-2]) (:259-266)
-        est = state.setdefault("est", [])
-        if len(est) < 2:
-            est.append(fr.c2w.clone())
+        # (Tracker.py:278-279), frame i >= 2 starts from delta @ pre_c2w, delta = pre_c2w @ inv(c2w[i-2]) (:283-288) --
+        # psl_pose_const_speed, camera tensors in and out
+        hist = state.setdefault("cam_hist", [])
+        if len(hist) < 2:
+            hist.append(fr.gt_cam.clone())
             return
-        cam0 = H.camera_tensor_from_c2w_device(H.const_speed_init(est[-1], est[-2]))
-        best = slam.track(fr, cam0)
-        c34 = H.get_camera_from_tensor(best)
-        if "row4" not in state:
-            state["row4"] = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=c34.device)
-        est.append(torch.cat([c34, state["row4"]], 0))
-        state.setdefault("traj", []).append((i, est[-1][:3, 3]))
-        est.pop(0)
+        best = slam.track(fr, slam.init_pose_device(hist[-1], hist[-2]))
+        hist.append(best.clone())
+        hist.pop(0)
+        state.setdefault("traj", []).append((i, hist[-1][4:7]))
         return
-    best = slam.track(fr, cams0[i])
+    if args.open_loop:
+        cam0 = cams0[i]
+    else:
+        # closed loop (Tracker.py:278-290): the first two frames of a rank start from the ground truth, every later one from the
+        # constant-speed extrapolation of the tracker's OWN two previous estimates -- one launch on the device, no pose copy
+        hist = state.setdefault("cam_hist", [])
+        cam0 = fr.gt_cam if len(hist) < 2 else slam.init_pose_device(hist[-1], hist[-2])
+    best = slam.track(fr, cam0)
+    if not args.open_loop:
+        hist.append(best.clone())
+        if len(hist) > 2:
+            hist.pop(0)
+        state.setdefault("traj", []).append((i, hist[-1][4:7]))
     if i % every == 0:
         c2w34 = H.get_camera_from_tensor(best)
-        c2w = torch.cat([c2w34, torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=c2w34.device)], 0)
+        if "row4" not in state:
+            state["row4"] = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=c2w34.device)
+        c2w = torch.cat([c2w34, state["row4"]], 0)
         n_base = slam.npc.pts_num()
         slam.map(fr, c2w)
         state["mapped"] += 1
         state["added"] += slam.npc.pts_num() - n_base
+        state.setdefault("map_log", []).append(dict(slam.last_map, frame=i))
         if world > 1 and (state["mapped"] % state["exchange_every"] == 0 or i in state.get("force_exchange_at_all", ())):
             # new points (cross-rank dedupe), features of shared rows and the colour decoder are reconciled
             import time as _t
@@ -414,6 +447,56 @@ def cpu_baseline(cfg, cam, n_points):
                        f"{mp['iters']}/{mp['every_frame']} map iters ({r:.0%} geometry stage) per frame")
 
 
+def take_snapshot(slam, state, dev):
+    """Everything a timed pass changes, so that the event-carrying pass can run on the SAME frames as the plain one: the map
+    (point count, both feature stores, surface-point lists), the decoder blob and exposure state, the keyframe list with the
+    poses / latents of its frames, the tracker's pose history and the random generators."""
+    import torch
+    npc = slam.npc
+    N = npc.pts_num()
+    return dict(N=N, geo=npc.get_geo_feats()[:N].clone(), col=npc.get_col_feats()[:N].clone(), theta=slam.theta.clone(),
+                keyframes=list(slam.keyframes), kf=[(f, f.c2w, f.exposure) for f in slam.keyframes], n_mapped=slam.n_mapped,
+                map_step=dict(slam.map_step), n_in=(len(npc._input_pos), len(npc._input_rgb)),
+                exposure=(slam.exposure_feat.clone(), slam.exposure_mlp.clone()) if slam.encode_exposure else None,
+                hist=[c.clone() for c in state.get("cam_hist", [])], traj=len(state.get("traj", [])),
+                counts=(state["mapped"], state["added"]), map_log=len(state.get("map_log", [])),
+                rng=(torch.get_rng_state(), torch.cuda.get_rng_state(dev)))
+
+
+def restore_snapshot(slam, state, snap, dev):
+    import torch
+    npc = slam.npc
+    npc.truncate(snap["N"])
+    npc.get_geo_feats().copy_(snap["geo"])
+    npc.get_col_feats().copy_(snap["col"])
+    npc._build()
+    del npc._input_pos[snap["n_in"][0]:], npc._input_rgb[snap["n_in"][1]:]
+    slam.theta.copy_(snap["theta"])
+    slam.keyframes[:] = snap["keyframes"]
+    for f, c2w, ex in snap["kf"]:
+        f.c2w, f.exposure = c2w, ex
+    slam.n_mapped, slam.map_step = snap["n_mapped"], dict(snap["map_step"])
+    if snap["exposure"] is not None:
+        slam.exposure_feat, slam.exposure_mlp = snap["exposure"][0].clone(), snap["exposure"][1].clone()
+    state["cam_hist"] = [c.clone() for c in snap["hist"]]
+    del state.setdefault("traj", [])[snap["traj"]:]
+    state["mapped"], state["added"] = snap["counts"]
+    torch.set_rng_state(snap["rng"][0])
+    torch.cuda.set_rng_state(snap["rng"][1], dev)
+    torch.cuda.synchronize()
+
+
+def ate_of(traj, frames):
+    """Translation error (cm) of the closed loop's estimates against the ground truth: rmse, max, n."""
+    import torch
+    if not traj:
+        return None
+    est_t = torch.stack([t for _, t in traj]).cpu()
+    gt_t = torch.stack([frames[k].gt_c2w[:3, 3] for k, _ in traj]).cpu()
+    err = (est_t - gt_t).norm(dim=1) * 100.0
+    return dict(rmse_cm=round(float((err ** 2).mean().sqrt()), 4), max_cm=round(float(err.max()), 4), frames=len(traj))
+
+
 def self_launch(n):
     import socket
     import subprocess
@@ -421,13 +504,45 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    if "--expandable-segments" in sys.argv:
+        env.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
+def held_out_render_loss(slam, cfg, cam, frame, n_pix=4000, seed=5):
+    """Mean |depth error| (m) and mean |colour error| of a render of `frame` at its ground-truth pose through the product path
+    (HipRenderer.render_batch_ray -> psl_render_fwd): what the map looks like after an exchange, under either merge rule."""
+    import torch
+    from point_slam_amd import host_ops as H
+    dev = frame.depth.device
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    idx = torch.randint(cam["H"] * cam["W"], (n_pix,), generator=g).to(dev)
+    u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
+    ro, rd = H.get_rays_from_uv(u, v, frame.gt_c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    ui, vi = u.long(), v.long()
+    gd, gc = frame.depth[vi, ui].contiguous(), frame.color[vi, ui]
+    rq = frame.r_query[vi, ui].contiguous() if frame.r_query is not None else None
+    slam.sync_decoders_from_theta()
+    r = slam.renderer
+    old = (r.fixed_fallback, r.sigmoid_coefficient)
+    r.fixed_fallback = (torch.zeros(32, device=dev), torch.zeros(32, device=dev))
+    r.sigmoid_coefficient = cfg["rendering"]["sigmoid_coef_mapper"]
+    with torch.no_grad():
+        d, _, c, valid = r.render_batch_ray(slam.npc, slam.decoders, rd.contiguous(), ro.contiguous(), dev, "color", gt_depth=gd,
+                                            npc_geo_feats=slam.npc.get_geo_feats(), npc_col_feats=slam.npc.get_col_feats(),
+                                            dynamic_r_query=rq)
+    r.fixed_fallback, r.sigmoid_coefficient = old
+    m = valid & (gd > 0)
+    return dict(depth_l1_m=round(float((d - gd).abs()[m].mean()), 6), colour_l1=round(float((c - gc).abs()[m].mean()), 6),
+                valid_frac=round(float(m.float().mean()), 4))
+
+
 def main():
     args = parse()
+    if args.expandable_segments and (int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -465,7 +580,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if args.track_only and (args.warmup < 2 or world > 1):
-        raise SystemExit("--track-only: one GPU, and --warmup >= 2 (frames 0 and 1 take the ground-truth pose, Tracker.py:254-255)")
+        raise SystemExit("--track-only: one GPU, and --warmup >= 2 (frames 0 and 1 take the ground-truth pose, Tracker.py:278-279)")
     cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
     state = dict(mapped=0, added=0)
     mpc = cfg["mapping"]
@@ -480,7 +595,7 @@ def main():
     if world > 1:
         from point_slam_amd import params as P_
         from point_slam_amd.dist import FrameParallelSync
-        state["sync"] = slam.sync = FrameParallelSync(slam.npc, slam.theta, n_color=P_.color_floats())
+        state["sync"] = slam.sync = FrameParallelSync(slam.npc, slam.theta, n_color=P_.color_floats(), merge=args.merge)
 
     def barrier():
         torch.cuda.synchronize()
@@ -515,18 +630,30 @@ def main():
         return d
 
     # (1) the timed region proper: EXACTLY `steps` frames, no instrumentation -> `value`
+    same_frames = world == 1 and not args.different_frames and not args.no_kernel_timing
+    snap = take_snapshot(slam, state, dev) if same_frames else None
+    n_log0, n_traj0 = len(state.get("map_log", [])), len(state.get("traj", []))
     dt = timed(args.warmup)
-    # (2) the same `steps` frames of work again with a HIP start/stop event pair on every kernel launch of the hot
-    #     classes (hipExtLaunchKernelGGL stamps the pair with the dispatch's own begin/end -- the timestamps rocprofv3
-    #     reports) -> `roofline`.  Kept apart from (1): event-carrying launches cost ~30 % of wall time here (marker
-    #     pairs -- hipEventRecord before/after -- cost 44 % and charged short kernels their neighbours' markers: Adam read
-    #     32 us against 18 us in the rocprofv3 trace).  The profiled wall time is reported as profiled_ms_per_step.
-    prof, dt_prof = {}, None
+    pass1 = dict(map_log=state.get("map_log", [])[n_log0:], ate=ate_of(state.get("traj", [])[n_traj0:], frames),
+                 points_end=slam.npc.pts_num(), mapped=state["mapped"], added=state["added"])
+    # (2) the same work again with a HIP start/stop event pair on every kernel launch of the hot classes
+    #     (hipExtLaunchKernelGGL stamps the pair with the dispatch's own begin/end -- the timestamps rocprofv3 reports)
+    #     -> `roofline`.  Since round 5 on the SAME frames: the map, the poses and the RNGs are restored to what they
+    #     were in front of pass (1) (--different-frames: the next `steps` frames, as rounds 1-4 did).  Event-carrying
+    #     launches cost wall time; the profiled wall time is reported as profiled_ms_per_step.
+    prof, dt_prof, pass2 = {}, None, None
     if not args.no_kernel_timing:
+        first2 = args.warmup + (0 if same_frames else args.steps)
+        if same_frames:
+            restore_snapshot(slam, state, snap, dev)
+            snap = None
+        n_log0, n_traj0 = len(state.get("map_log", [])), len(state.get("traj", []))
         _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, max(1, args.event_stride)))
-        dt_prof = timed(args.warmup + args.steps)
+        dt_prof = timed(first2)
         prof = kernel_profile(slam)
         _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 0))
+        pass2 = dict(map_log=state.get("map_log", [])[n_log0:], ate=ate_of(state.get("traj", [])[n_traj0:], frames),
+                     first_frame=first2)
 
     points_end = slam.npc.pts_num()
     mapped_total = max(state["mapped"], 1)
@@ -537,9 +664,17 @@ def main():
         state["sync"].exchange(slam.npc, slam.theta)
         torch.cuda.synchronize()
         t_ex = time.perf_counter() - t0
-        mine = dict(rank=rank, points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
+        ex_ms = sorted(round(x * 1e3, 3) for x in state.get("exchange_s", []))
+        try:
+            loss_after = held_out_render_loss(slam, cfg, cam, frames[args.warmup + args.steps - 1])
+        except Exception as e:
+            loss_after = {"error": repr(e)}
+        mine = dict(rank=rank, device=str(dev), points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
                     added=state["added"], mapped=state["mapped"], final_exchange_ms=round(t_ex * 1e3, 3),
                     exchange_ms=[round(x * 1e3, 3) for x in state.get("exchange_s", [])],
+                    exchange_ms_p50=ex_ms[len(ex_ms) // 2] if ex_ms else None, exchange_ms_p100=ex_ms[-1] if ex_ms else None,
+                    ate_rmse_cm=(ate_of(state.get("traj", []), frames) or {}).get("rmse_cm"),
+                    render_loss_after_final_exchange=loss_after,
                     feat_checksum=float(slam.npc.get_geo_feats().double().sum()))
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -559,7 +694,7 @@ def main():
         t_track = (time.perf_counter() - t0) / len(ids)
         t0 = time.perf_counter()
         for i in ids[:2]:
-            slam.map(frames[i], frames[i].c2w)
+            slam.map(frames[i], frames[i].gt_c2w)
         torch.cuda.synchronize()
         t_map = (time.perf_counter() - t0) / 2
         split = {"track_ms_per_frame": round(t_track * 1e3, 3), "track_only_fps": round(1.0 / t_track, 2),
@@ -569,13 +704,28 @@ def main():
     if rank == 0:
         pmc_key = "cfg5" if (args.points >= 2_000_000 and args.width >= 1280) else args.mix
         roof, per = roofline_of(prof, pmc_traffic(pmc_key), algorithmic_bytes(cfg))
+        def iters_of(log):
+            return dict(mapped_frames=len(log), map_iters=[m["n_iters"] for m in log], geo_iters=[m["n_geo"] for m in log],
+                        n_sel=[m["n_sel"] for m in log], locations_added=[m["added"] for m in log])
         if roof is not None:
-            # `value` comes from pass (1) (no instrumentation); the kernel classes -- and therefore `roofline` -- from pass (2),
-            # the NEXT `steps` frames with an event pair on every hot launch.  Both wall times are in the line.
-            roof["measured_on"] = (f"pass 2: frames {args.warmup + args.steps}..{args.warmup + 2 * args.steps - 1}, event-carrying launches, "
-                                   f"{round(dt_prof / args.steps * 1e3, 3) if dt_prof else None} ms/step; `value` is pass 1: frames "
-                                   f"{args.warmup}..{args.warmup + args.steps - 1}, {round(dt / args.steps * 1e3, 3)} ms/step")
-            roof["class_sum_ms_per_step"] = round(sum(v["total_ms"] for k, v in per.items() if k != "knn_side_stream") / args.steps, 3)
+            # `value` comes from pass (1) (no instrumentation); the kernel classes -- and therefore `roofline` -- from pass (2):
+            # the SAME frames from the restored snapshot (default), or the next `steps` frames (--different-frames, N > 1).
+            f2 = pass2["first_frame"]
+            roof["measured_on"] = (f"pass 2: frames {f2}..{f2 + args.steps - 1}" + (" (the SAME frames as pass 1: map, poses and RNGs restored "
+                                   "from a snapshot taken after the warm-up)" if same_frames else " (the frames AFTER pass 1)")
+                                   + f", event-carrying launches, {round(dt_prof / args.steps * 1e3, 3)} ms/step; `value` is pass 1: frames "
+                                   f"{args.warmup}..{args.warmup + args.steps - 1}, no instrumentation, {round(dt / args.steps * 1e3, 3)} ms/step")
+            # reconciliation of pass 2: wall time = sum of the classes on the main stream + what no class accounts for (device idle
+            # while the host works between launches and at its synchronising calls, launches of torch / the runtime that carry no
+            # event pair).  knn_side_stream runs on a second stream UNDER the decode launches: not part of the sum.
+            cls = sum(v["total_ms"] for k, v in per.items() if k != "knn_side_stream") / args.steps
+            wall2 = dt_prof / args.steps * 1e3
+            roof["class_sum_ms_per_step"] = round(cls, 3)
+            roof["unclassified_ms_per_step"] = round(wall2 - cls, 3)
+            roof["unclassified_frac_of_wall"] = round((wall2 - cls) / wall2, 4)
+            roof["instrumentation_overhead_ms_per_step"] = round(wall2 - dt / args.steps * 1e3, 3) if same_frames else None
+            roof["pass1_work"] = iters_of(pass1["map_log"])
+            roof["pass2_work"] = iters_of(pass2["map_log"])
         tr, mp = cfg["tracking"], cfg["mapping"]
         out = {
             "metric": f"mapping+tracking FPS @{args.width}x{args.height}, {args.points / 1e6:g}M neural points",
@@ -591,6 +741,14 @@ def main():
                        "engine": args.engine, "points_start": points_start, "points_end": points_end,
                        "points_added_per_mapped_frame": round(state["added"] / mapped_total, 1),
                        "mapped_frames": state["mapped"],
+                       # what the timed pass actually ran (the mapping iteration count is data dependent, Mapper.py:404-406)
+                       "timed_pass": dict(iters_of(pass1["map_log"]), points_end=pass1["points_end"]),
+                       "pose_loop": ("open: every frame starts from the ground-truth pose + noise (rounds 1-4)" if args.open_loop else
+                                     "closed: frame i starts from the constant-speed extrapolation of the tracker's own two previous "
+                                     "estimates (psl_pose_const_speed, Tracker.py:283-290); mapping at the tracker's estimate"),
+                       "ate_rmse_cm": pass1["ate"]["rmse_cm"] if pass1["ate"] else None,
+                       "ate_max_cm": pass1["ate"]["max_cm"] if pass1["ate"] else None,
+                       "ate_event_pass": pass2["ate"] if pass2 else None,
                        "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU",
                        "exchange_cadence": (f"every {state['exchange_every']} mapped frames of a rank"
                                             + (f" (= {args.exchange_every_keyframes} keyframes, BASELINE config 4)" if not args.exchange_every else "")
@@ -608,24 +766,25 @@ def main():
                         for k, v in per.items()},
         }
         if args.track_only:
-            # the trajectory the closed loop produced against the ground truth (translation, cm)
-            ids_ = [k for k, _ in state.get("traj", [])]
-            if ids_:
-                est_t = torch.stack([t for _, t in state["traj"]]).cpu()
-                gt_t = torch.stack([frames[k].c2w[:3, 3] for k in ids_]).cpu()
-                err = (est_t - gt_t).norm(dim=1) * 100.0
-                out["config"]["ate_rmse_cm"] = round(float((err ** 2).mean().sqrt()), 4)
-                out["config"]["ate_max_cm"] = round(float(err.max()), 4)
-                out["config"]["tracked_frames"] = len(ids_)
+            # the trajectory the closed loop produced against the ground truth (translation, cm), both passes
+            a = ate_of(state.get("traj", []), frames)
+            if a:
+                out["config"]["ate_rmse_cm"], out["config"]["ate_max_cm"], out["config"]["tracked_frames"] = a["rmse_cm"], a["max_cm"], a["frames"]
             out["metric"] = (f"tracking FPS @{args.width}x{args.height}, fixed {args.points / 1e3:g}k-point cloud "
                              f"(BASELINE config 1: tracking only)")
             out["config"]["workload"] = (f"synthetic {args.width}x{args.height} RGB-D room, FIXED cloud of {args.points} neural points, "
                                          f"features trained beforehand (untimed) by mapping {getattr(args, '_trained_keyframes', 0)} keyframes at their "
                                          f"true poses, no point adding; tracking only: {tr['pixels']}px x {tr['iters']}it per frame ({args.mix} mix), every frame "
                                          f"initialised by constant-speed extrapolation of the tracker's own two previous estimates")
-            for k in ("points_added_per_mapped_frame", "mapped_frames", "keyframes_kept"):
+            for k in ("points_added_per_mapped_frame", "mapped_frames", "keyframes_kept", "timed_pass", "ate_event_pass"):
                 out["config"].pop(k, None)
         if per_rank is not None:
+            from point_slam_amd.dist import transport_name
+            out["config"]["rccl_ranks"] = world if dist.get_backend() == "nccl" else 0
+            out["config"]["process_group_backend"] = dist.get_backend()
+            out["config"]["exchange_transport"] = transport_name(state["sync"].transport)
+            out["config"]["merge_rule"] = args.merge
+            out["config"]["allocator"] = os.environ.get("PYTORCH_HIP_ALLOC_CONF", "default")
             out["config"]["per_rank"] = per_rank
             out["config"]["replicas_identical_after_exchange"] = (
                 len({r["points_after_final_exchange"] for r in per_rank}) == 1 and

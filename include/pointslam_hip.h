@@ -305,6 +305,12 @@ typedef struct psl_map_args {
 int64_t psl_map_ws_floats(int n_rays, int n_frames);
 int psl_map_iters(psl_ctx* ctx, const psl_map_args* m, void* stream);
 
+/* Initial pose of the next frame (src/Tracker.py:283-290, const_speed_assumption): camera tensor [quat wxyz, T] of
+ * delta @ pre_c2w with delta = pre_c2w @ inv(c2w[idx-2]), from the tracker's two previous camera tensors ON THE DEVICE
+ * (cam_prev2 NULL: cam_prev itself, Tracker.py:288-289).  ABI 6.  One launch on `stream`, no synchronisation: a closed
+ * track -> track loop never copies a pose to the host (the reference goes through numpy / scipy once per frame). */
+int psl_pose_const_speed(const float* cam_prev, const float* cam_prev2, float* cam_out, void* stream);
+
 /* Mapper.get_mask_from_c2w (src/Mapper.py:120-168): frustum feature selection.  c2w_host: [16] row-major 4x4
  * (host memory).  Writes the ascending index list sel_out[<=N] and row_map_out[N]; synchronises and returns
  * the count.  Points whose bilinear lookup is 0 take depth_max (:161-162: np.max over the PER-POINT lookups): pass a negative

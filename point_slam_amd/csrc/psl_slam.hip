@@ -819,6 +819,53 @@ static int64_t rays_floats(int n) {   // size of carve_rays' layout: carved from
   float* p = base; (void)carve_rays(p, n); return (int64_t)(p - base);
 }
 
+// Initial pose of the next frame (src/Tracker.py:283-290, const_speed_assumption): delta = pre_c2w @ inv(c2w[idx-2]),
+// estimate = delta @ pre_c2w, handed back as a camera tensor (get_tensor_from_camera, src/common.py:270-295) -- on the device,
+// from the tracker's own two previous camera tensors, so that a closed loop never copies a pose to the host.  The poses are
+// rigid: inv([R t]) = [R^T, -R^T t] (the reference inverts the 4x4 numerically; the two agree to fp32 rounding).  Quaternion
+// by Shepperd's method (largest of trace / diagonal terms), w >= 0 (q and -q are the same rotation).
+__global__ void k_pose_const_speed(const float* __restrict__ prev, const float* __restrict__ prev2, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float R1[3][3], t1[3] = {prev[4], prev[5], prev[6]};
+  quat_to_rot(prev, R1);
+  float Re[3][3], te[3];
+  if (prev2) {
+    float R0[3][3], t0[3] = {prev2[4], prev2[5], prev2[6]}, Rd[3][3], td[3];
+    quat_to_rot(prev2, R0);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rd[i][j] = (R1[i][0] * R0[j][0] + R1[i][1] * R0[j][1]) + R1[i][2] * R0[j][2];      // R1 R0^T
+    for (int i = 0; i < 3; ++i) td[i] = t1[i] - ((Rd[i][0] * t0[0] + Rd[i][1] * t0[1]) + Rd[i][2] * t0[2]);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Re[i][j] = (Rd[i][0] * R1[0][j] + Rd[i][1] * R1[1][j]) + Rd[i][2] * R1[2][j];
+      te[i] = ((Rd[i][0] * t1[0] + Rd[i][1] * t1[1]) + Rd[i][2] * t1[2]) + td[i];
+    }
+  } else {
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Re[i][j] = R1[i][j]; te[i] = t1[i]; }
+  }
+  const float m00 = Re[0][0], m11 = Re[1][1], m22 = Re[2][2], tr = (m00 + m11) + m22;
+  float q[4];
+  if (tr >= m00 && tr >= m11 && tr >= m22) {
+    q[0] = 1.f + tr; q[1] = Re[2][1] - Re[1][2]; q[2] = Re[0][2] - Re[2][0]; q[3] = Re[1][0] - Re[0][1];
+  } else if (m00 >= m11 && m00 >= m22) {
+    q[0] = Re[2][1] - Re[1][2]; q[1] = 1.f + m00 - m11 - m22; q[2] = Re[0][1] + Re[1][0]; q[3] = Re[0][2] + Re[2][0];
+  } else if (m11 >= m22) {
+    q[0] = Re[0][2] - Re[2][0]; q[1] = Re[0][1] + Re[1][0]; q[2] = 1.f - m00 + m11 - m22; q[3] = Re[1][2] + Re[2][1];
+  } else {
+    q[0] = Re[1][0] - Re[0][1]; q[1] = Re[0][2] + Re[2][0]; q[2] = Re[1][2] + Re[2][1]; q[3] = 1.f - m00 - m11 + m22;
+  }
+  const float nrm = sqrtf(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+  const float sgn = (q[0] < 0.f) ? -1.f : 1.f;
+  for (int i = 0; i < 4; ++i) out[i] = sgn * q[i] / nrm;
+  out[4] = te[0]; out[5] = te[1]; out[6] = te[2];
+}
+
+extern "C" int psl_pose_const_speed(const float* cam_prev, const float* cam_prev2, float* cam_out, void* stream) {
+  if (!cam_prev || !cam_out) { set_error("psl_pose_const_speed: missing argument"); return PSL_ERR_ARG; }
+  hipLaunchKernelGGL(k_pose_const_speed, dim3(1), dim3(64), 0, (hipStream_t)stream, cam_prev, cam_prev2, cam_out);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
 extern "C" int64_t psl_track_ws_floats(int n_pix) {
   if (n_pix < 0) return PSL_ERR_ARG;
   return rays_floats(n_pix) + psl_render_ws_floats(n_pix, PSL_STAGE_COLOR | PSL_PTS_GRAD) + 64 +

@@ -83,7 +83,7 @@ def mapper_loss(depth, rgb, valid_ray, gt_depth, gt_color, stage, w_color=0.1):
 
 
 def const_speed_init(prev_c2w: torch.Tensor, prev_prev_c2w: torch.Tensor = None) -> torch.Tensor:
-    """Initial pose of the next frame (src/Tracker.py:259-266): delta = pre_c2w @ inv(c2w[idx-2]), estimate = delta @ pre_c2w
+    """Initial pose of the next frame (src/Tracker.py:283-290): delta = pre_c2w @ inv(c2w[idx-2]), estimate = delta @ pre_c2w
     (const_speed_assumption); the previous estimate itself when there is no frame idx-2."""
     prev = prev_c2w.float()
     if prev_prev_c2w is None:
@@ -96,7 +96,7 @@ def camera_tensor_from_c2w_device(c2w: torch.Tensor) -> torch.Tensor:
     pose.  The reference goes through scipy on the host; a frame loop that feeds the tracker's own estimates back as the next
     initial pose would stall on that copy once per frame.  Shepperd's method, the branch taken by selects; the sign of the
     quaternion is free (q and -q are the same rotation; the reference flips it towards the ground-truth hemisphere,
-    Tracker.py:272-273, which changes nothing in the optimisation)."""
+    Tracker.py:294-295, which changes nothing in the optimisation)."""
     R = c2w[:3, :3].float()
     m00, m11, m22 = R[0, 0], R[1, 1], R[2, 2]
     tr = m00 + m11 + m22

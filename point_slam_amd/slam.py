@@ -161,10 +161,21 @@ class HipSLAM:
 
     # ------------------------------------------------------------------ tracking
     def init_pose(self, est_c2w: list) -> torch.Tensor:
-        """Camera tensor the tracker starts frame len(est_c2w) from (Tracker.py:259-270): constant-speed extrapolation of
+        """Camera tensor the tracker starts frame len(est_c2w) from (Tracker.py:283-290): constant-speed extrapolation of
         the last two ESTIMATED poses."""
         c2w = H.const_speed_init(est_c2w[-1], est_c2w[-2] if len(est_c2w) >= 2 else None)
         return camera_tensor_from_c2w(c2w)
+
+    def init_pose_device(self, cam_prev: torch.Tensor, cam_prev2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same on the device, camera tensors in, camera tensor out (psl_pose_const_speed): one launch, no host copy of
+        a pose -- what a closed track -> track loop calls once per frame."""
+        out = torch.empty(7, device=self.device)
+        a = cam_prev.detach().float().contiguous()
+        b = cam_prev2.detach().float().contiguous() if cam_prev2 is not None else None
+        _lib.check(_lib.lib().psl_pose_const_speed(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()),
+                   "psl_pose_const_speed")
+        self._keep_pose = (a, b)
+        return out
 
     def track(self, frame: Frame, cam0: torch.Tensor, n_iters=None, n_pix=None) -> torch.Tensor:
         """Optimise the pose of `frame` from the initial camera tensor cam0 [7]; returns the lowest-loss
@@ -410,6 +421,8 @@ class HipSLAM:
         else:
             self._map_dropin(window, sel, n_iters, pix_per_frame)
         self.n_mapped += 1
+        self.last_map = dict(frame=frame.idx, added=int(added), n_sel=int(sel.shape[0]), n_iters=int(n_iters), n_geo=int(n_geo),
+                             window=len(window), points=self.npc.pts_num())
         return added, int(sel.shape[0])
 
     def refine(self, frame: Frame, c2w: torch.Tensor, n_outer=5, n_iters=None):

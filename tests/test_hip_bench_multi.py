@@ -16,12 +16,13 @@ from tests.test_hip_parity import report
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_self_launches_two_ranks():
+@pytest.mark.parametrize("merge", ["mean", "owner"])
+def test_bench_self_launches_two_ranks(merge):
     env = dict(os.environ)
     if torch.cuda.device_count() < 2:
         env["PSL_BENCH_SHARE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5", "--points", "200000",
-           "--exchange-every", "1", "--no-kernel-timing"]
+           "--exchange-every", "1", "--no-kernel-timing", "--merge", merge]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -37,5 +38,17 @@ def test_bench_self_launches_two_ranks():
     assert pr[0]["feat_checksum"] == pr[1]["feat_checksum"]
     assert out["config"]["replicas_identical_after_exchange"] is True
     assert out["value"] > 0
-    report(test="bench_two_ranks", value=out["value"], ms_per_step=out["ms_per_step"], per_rank=pr,
+    # the line describes the multi-rank run by itself: backend, transport actually used, merge rule, per-rank exchange times,
+    # the closed loop's trajectory error and the held-out render loss after the last exchange (identical replicas: same map,
+    # each rank renders its own last frame)
+    c = out["config"]
+    assert c["merge_rule"] == merge and c["process_group_backend"] in ("gloo", "nccl")
+    assert c["rccl_ranks"] == (2 if c["process_group_backend"] == "nccl" else 0)
+    assert "torch.distributed" in c["exchange_transport"]             # native RCCL is opt-in (PSL_NATIVE_RCCL=1)
+    for r in pr:
+        assert r["exchange_ms_p50"] is not None and r["exchange_ms_p100"] >= r["exchange_ms_p50"]
+        la = r["render_loss_after_final_exchange"]
+        assert "error" not in la and la["valid_frac"] > 0.5 and la["depth_l1_m"] < 0.1
+        assert r["ate_rmse_cm"] is not None and r["ate_rmse_cm"] < 10.0
+    report(test="bench_two_ranks", merge=merge, value=out["value"], ms_per_step=out["ms_per_step"], per_rank=pr,
            shared_gpu=env.get("PSL_BENCH_SHARE_GPU") == "1")

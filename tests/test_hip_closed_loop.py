@@ -3,7 +3,7 @@ against the pinned oracle composed the way the reference composes its loops, wit
 
 Every loop of the path is pinned in isolation elsewhere (tests/test_hip_loops.py: the reference's own optimize_map /
 tracker loop / add_neural_points fixtures).  What nothing else checks is the ORCHESTRATION between them
-(src/Tracker.py:259-270,379-380 <-> src/Mapper.py:263-330,404-406,642-783): the pose a tracked frame hands to the mapper, the
+(src/Tracker.py:283-290,379-380 <-> src/Mapper.py:263-330,404-406,642-783): the pose a tracked frame hands to the mapper, the
 points the mapper adds at THAT pose, the frustum rows it then selects, the data-dependent iteration count, the trained
 rows and decoder the next tracked frame renders against, the constant-speed initial pose built from two estimated poses.
 
@@ -136,7 +136,7 @@ def test_track_map_track_closed_loop_matches_oracle():
     for i, fr in enumerate(frames):
         out = dict(idx=i, state=PP.oracle_state(s), est=[e.cpu().clone() for e in est], kf=[f.idx for f in s.keyframes])
         if i == 0:
-            c2w = fr.c2w.clone()                                     # idx 0: ground-truth pose (Tracker.py:254-255)
+            c2w = fr.c2w.clone()                                     # idx 0: ground-truth pose (Tracker.py:278-279)
         else:
             cam0 = s.init_pose(est).to(dev)
             out["track_draw"] = len(rec.draws)
@@ -174,7 +174,7 @@ def test_track_map_track_closed_loop_matches_oracle():
         P, cloud, geo, col = st["P"], st["cloud"], st["geo"], st["col"]
         row = dict(idx=i, n_pts_before=int(cloud.shape[0]))
         if i > 0:
-            # ---- tracker stage: initial pose from the two poses the previous stages handed over (Tracker.py:259-270)
+            # ---- tracker stage: initial pose from the two poses the previous stages handed over (Tracker.py:283-290)
             c0 = H.const_speed_init(h["est"][-1], h["est"][-2] if len(h["est"]) >= 2 else None)
             cam0 = camera_tensor_from_c2w(c0)
             pix, fb = rec.draws[h["track_draw"]]

@@ -486,6 +486,36 @@ def test_depth_outlier_mask_native_matches_dropin():
     assert rel < 3e-4
 
 
+def test_pose_const_speed_matches_host_chain():
+    """psl_pose_const_speed (one launch, camera tensors in and out) against the host chain it replaces in a closed loop --
+    get_camera_from_tensor -> const_speed_init (Tracker.py:283-290: delta = pre_c2w @ inv(c2w[idx-2]), delta @ pre_c2w, numeric
+    4x4 inverse) -> get_tensor_from_camera: same pose to fp32 rounding, quaternions up to sign; un-normalised input
+    quaternions (the tracker's Adam does not keep them on the sphere); prev2 = NULL copies the previous pose."""
+    from point_slam_amd import host_ops as H, synthetic as syn
+    from point_slam_amd.slam import camera_tensor_from_c2w
+    dev = torch.device("cuda:0")
+    cfg = base_cfg()
+    s = _slam(cfg, syn.intrinsics(160, 120), "native", dev)
+    g = torch.Generator().manual_seed(4)
+    worst = 0.0
+    for t in (0.0, 11.0, 123.0, 200.5, 977.0, 1500.0):
+        a = camera_tensor_from_c2w(syn.pose(t)) * torch.tensor([1.0 + 0.01 * float(torch.randn(1, generator=g))] * 4 + [1.0] * 3)
+        b = camera_tensor_from_c2w(syn.pose(t + 2.0)) * torch.tensor([1.0 - 0.02 * float(torch.rand(1, generator=g))] * 4 + [1.0] * 3)
+        got = s.init_pose_device(b.to(dev), a.to(dev)).cpu()
+        row4 = torch.tensor([[0.0, 0.0, 0.0, 1.0]])
+        A = torch.cat([H.get_camera_from_tensor(a), row4]).double()
+        B = torch.cat([H.get_camera_from_tensor(b), row4]).double()
+        want = camera_tensor_from_c2w((B @ torch.linalg.inv(A) @ B).float())
+        if float((got[:4] * want[:4]).sum()) < 0:
+            want = torch.cat([-want[:4], want[4:]])
+        worst = max(worst, float((got - want).abs().max()))
+        assert abs(float(got[:4].norm()) - 1.0) < 1e-6 and float(got[0]) >= 0
+        same = s.init_pose_device(b.to(dev), None).cpu()
+        assert float((H.get_camera_from_tensor(same) - H.get_camera_from_tensor(b)).abs().max()) < 1e-6
+    report(test="pose_const_speed", worst_abs=worst)
+    assert worst < 5e-6
+
+
 def test_checkpoint_roundtrip(tmp_path):
     """Logger.log schema out, get_mesh_tsdf_fusion.load_neural_point_cloud in: same render afterwards."""
     from point_slam_amd import checkpoint as CK
