@@ -62,6 +62,10 @@ def parse():
                     help="rounds 1-4: every frame starts from the ground-truth pose + noise.  Default since round 5: CLOSED loop -- "
                          "frame i starts from the constant-speed extrapolation of the tracker's own two previous estimates "
                          "(Tracker.py:283-290), the mapper maps at the tracker's estimate; config.ate_rmse_cm in the line")
+    ap.add_argument("--pretrain-keyframes", type=int, default=8,
+                    help="closed loop: keyframes mapped at their true poses before the run starts (untimed set-up), one every "
+                         "mapping.every_frame frames back along the trajectory -- the map a run that reached the first frame would "
+                         "hold.  (Open loop: the four earlier keyframes of rounds 1-4, points added, features untrained.)")
     ap.add_argument("--different-frames", action="store_true",
                     help="rounds 1-4: the event-timed pass runs on the NEXT --steps frames.  Default since round 5: the map, the "
                          "poses and the RNGs are snapshotted after the warm-up and restored, so that `value` (plain pass) and the "
@@ -133,10 +137,16 @@ def build_world(args, rank, world, dev):
     # frame-parallel partition: local step i is global frame rank + world*i
     frames, cams0 = [], []
     g = torch.Generator().manual_seed(1000 + rank)
-    for i in range(-4, n_total):
+    upf = getattr(args, "_unit_per_frame", 2.0)
+    n_early = 4 if (args.open_loop or track_only) else max(args.pretrain_keyframes, 2)
+    for i in range(-n_early, n_total):
         # 2 trajectory units per frame = ~5.6 cm and ~0.4 degrees ("5 cm / 1 deg per frame"): every mapped frame sees new surface
-        t = float(rank + world * max(i, 0)) * getattr(args, "_unit_per_frame", 2.0) if i >= 0 else float(-3 * (i + 5))   # i<0: earlier keyframes
-        t = t + 200.0 if i >= 0 else t + 170.0
+        if i >= 0:
+            t = 200.0 + float(rank + world * i) * upf
+        elif args.open_loop or track_only:
+            t = 170.0 + float(-3 * (i + 5))                  # rounds 1-4: four earlier keyframes ~1 m back
+        else:
+            t = 200.0 + float(i) * upf * every * world       # closed loop: the frames a run would have mapped on its way here
         c2w = syn.pose(t, dev)
         depth, color = syn.render_frame(cam, c2w, noise=noise, dropout=dropout, gen=g_noise)
         r_add, r_q = syn.dynamic_radii(color, cfg)
@@ -160,6 +170,20 @@ def build_world(args, rank, world, dev):
             # open loop: initial pose = ground truth + a perturbation of the size the constant-speed model leaves
             cam0 = camera_tensor_from_c2w(c2w) + torch.randn(7, generator=g) * torch.tensor([1e-3] * 4 + [5e-3] * 3)
             cams0.append(cam0.to(dev))
+    if world > 1 and not args.open_loop:
+        # the set-up trained the early keyframes on every rank with the same draws, but float atomics make the trained rows
+        # differ in their last bits from rank to rank: the replicas START identical (rank 0's), as the exchange keeps them
+        import torch.distributed as dist
+        N = slam.npc.pts_num()
+        n_all = torch.tensor([N], device=dev)
+        dist.all_reduce(n_all, op=dist.ReduceOp.MAX)
+        if int(n_all.item()) != N:
+            raise SystemExit(f"rank {rank}: {N} points after the set-up, another rank has {int(n_all.item())}")
+        for t_ in (slam.npc.get_geo_feats(), slam.npc.get_col_feats(), slam.theta):
+            dist.broadcast(t_, src=0)
+        if slam.encode_exposure:
+            dist.broadcast(slam.exposure_mlp, src=0); dist.broadcast(slam.exposure_feat, src=0)
+        torch.cuda.synchronize()
     return cfg, cam, slam, frames, cams0, every
 
 

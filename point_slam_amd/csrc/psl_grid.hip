@@ -211,16 +211,6 @@ int grid_build(psl_ctx* ctx, hipStream_t s) {
 // ------------------------------------------------------------------------ k-NN
 typedef unsigned long long u64;
 
-__device__ __forceinline__ void topk_insert(u64 (&b)[K], u64 kk) {
-  // precondition kk < b[K-1]; b sorted ascending
-#pragma unroll
-  for (int j = K - 1; j > 0; --j) {
-    u64 lo = b[j - 1], cur = b[j];
-    b[j] = (kk < lo) ? lo : ((kk < cur) ? kk : cur);
-  }
-  b[0] = (kk < b[0]) ? kk : b[0];
-}
-
 struct CellBox { int lo[3], hi[3]; };
 
 __device__ __forceinline__ void box_of(const GridMeta& m, float x, float y, float z, float r, CellBox& bx) {
@@ -280,8 +270,7 @@ __device__ __forceinline__ void lane_list_insert(u64& mine, u64& thr, u64 kk) {
 // Same keys, same order: bit-identical answers to knn_scan_rows / wave_knn.
 __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const float4* __restrict__ spos,
                                                    const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                                   float re, u64& mine, u64& thr, unsigned long long& cand,
-                                                   int wsub = 0, int nsub = 1) {
+                                                   float re, u64& mine, u64& thr, unsigned long long& cand) {
   const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
   CellBox bx;
   box_of(m, qx, qy, qz, re, bx);
@@ -296,11 +285,10 @@ __device__ __forceinline__ void knn_scan_rows_lane(const GridMeta& m, const floa
       end = cell_start[rowbase + bx.hi[0] + 1];
     }
   };
-  const int step = 4 * nsub;                     // nsub wavefronts share a query: this one takes rows 4 wsub .. of every step
   int beg, end, nbeg, nend;
-  row_range(4 * wsub + grp, beg, end);
-  for (int rb = 4 * wsub; rb < nrows; rb += step) {
-    row_range(rb + step + grp, nbeg, nend);
+  row_range(grp, beg, end);
+  for (int rb = 0; rb < nrows; rb += 4) {
+    row_range(rb + 4 + grp, nbeg, nend);
     int j = beg + l16;
     // two chunks of every row in flight: rows hold ~45 candidates, i.e. three dependent loads with one-deep prefetch
     float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -348,105 +336,6 @@ __device__ __forceinline__ void wave_knn_lane(const GridMeta& m, const float4* _
     if (last || thr != sentinel) break;
     rho *= 2.0f;
   }
-}
-
-// one pass of the expanding search for one wavefront: scans rows wsub*4 .. of every nsub*4 rows of the cube
-// [q - re, q + re] (nsub wavefronts share a query), inserting keys below best[K-1] into `best`
-__device__ __forceinline__ void knn_scan_rows(const GridMeta& m, const float4* __restrict__ spos,
-                                              const int* __restrict__ cell_start, float qx, float qy, float qz, float re,
-                                              u64 (&best)[K], int wsub, int nsub, unsigned long long& cand) {
-  const int lane = threadIdx.x & 63, grp = lane >> 4, l16 = lane & 15;
-  CellBox bx;
-  box_of(m, qx, qy, qz, re, bx);
-  const int ny_b = bx.hi[1] - bx.lo[1] + 1;
-  const int nrows = (bx.hi[2] - bx.lo[2] + 1) * ny_b;
-  // The rows of the cube ((cz, cy) pairs: x-runs of cells = contiguous ranges of `spos`) hold ~10..40 points each:
-  // they are walked FOUR AT A TIME, 16 lanes per row, and the [begin, end) pairs of the next four are requested
-  // before the current four are scanned -- a quarter of the serial memory round trips of a 64-lanes-per-row walk,
-  // and no idle lanes on short rows.
-  auto row_range = [&](int row, int& beg, int& end) {
-    beg = 0; end = 0;
-    if (row < nrows) {
-      const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
-      const int rowbase = (cz * m.ny + cy) * m.nx;
-      beg = cell_start[rowbase + bx.lo[0]];
-      end = cell_start[rowbase + bx.hi[0] + 1];
-    }
-  };
-  const int step = 4 * nsub;
-  int beg, end, nbeg, nend;
-  row_range(4 * wsub + grp, beg, end);
-  for (int rb = 4 * wsub; rb < nrows; rb += step) {
-    row_range(rb + step + grp, nbeg, nend);
-    int j = beg + l16;
-    float4 c = (j < end) ? spos[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    while (__ballot(j < end)) {
-      const bool valid = j < end;
-      const int jn = j + 16;
-      const float4 cn = (jn < end) ? spos[jn] : make_float4(0.f, 0.f, 0.f, 0.f);     // next chunk of this row, in flight
-      cand += (unsigned long long)__popcll(__ballot(valid));
-      const unsigned idx = __float_as_uint(c.w);
-      const float d2 = dist2(c.x, c.y, c.z, qx, qy, qz);
-      const u64 key = ((u64)__float_as_uint(d2) << 32) | idx;
-      u64 mask = __ballot(valid && key < best[K - 1]);
-      while (mask) {
-        const int l = __builtin_ctzll(mask);
-        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(key >> 32), l);
-        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(key & 0xFFFFFFFFull), l);
-        topk_insert(best, ((u64)khi << 32) | klo);
-        mask &= mask - 1;
-        if (mask) mask &= __ballot(valid && key < best[K - 1]);
-      }
-      j = jn; c = cn;
-    }
-    beg = nbeg; end = nend;
-  }
-}
-
-__device__ __forceinline__ void wave_knn(const GridMeta& m, const float4* __restrict__ spos,
-                                         const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
-                                         float r2, u64 (&best)[K], unsigned long long* n_cand = nullptr,
-                                         const int* __restrict__ coarse = nullptr, int* n_pass = nullptr) {
-  float rho = m.cell;
-  unsigned long long cand = 0;
-  int passes = 0;
-  if (coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {
-    const u64 sentinel = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = sentinel;
-    if (n_cand) *n_cand = 0;
-    return;
-  }
-  for (;;) {
-    const bool last = rho >= r;
-    const float re = last ? r : rho;
-    const float t2 = last ? r2 : __fmul_rn(rho, rho);
-    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
-#pragma unroll
-    for (int j = 0; j < K; ++j) best[j] = sentinel;
-    knn_scan_rows(m, spos, cell_start, qx, qy, qz, re, best, 0, 1, cand);
-    ++passes;
-    if (last || best[K - 1] != sentinel) break;
-    rho *= 2.0f;
-  }
-  if (n_cand) *n_cand = cand;
-  if (n_pass) *n_pass = passes;
-}
-
-__device__ __forceinline__ void knn_emit(const u64 (&best)[K], float r2, int lane, unsigned& ib_out, unsigned& db_out,
-                                         int& cnt_out) {
-  // after an early exit the sentinel threshold was rho^2 <= r2: every kept entry has d2 <= rho^2 <= r2
-  const unsigned r2b = __float_as_uint(r2);
-  u64 mine = 0xFFFFFFFFull; int cnt = 0;
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    if (lane == j) mine = best[j];
-    unsigned db = (unsigned)(best[j] >> 32), ib = (unsigned)(best[j] & 0xFFFFFFFFull);
-    cnt += (ib != 0xFFFFFFFFu && db < r2b) ? 1 : 0;
-  }
-  ib_out = (unsigned)(mine & 0xFFFFFFFFull);
-  db_out = (unsigned)(mine >> 32);
-  cnt_out = cnt;
 }
 
 // PSL_KNN_TRACE=1: per-query cost distribution of the one-wavefront-per-sample kernel (shader cycles, candidates, passes),
@@ -677,108 +566,6 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
     atomicAdd(&g_knn_trace.hist_cyc[log2_bucket(cyc)], 1ull); atomicAdd(&g_knn_trace.hist_cand[log2_bucket(n_cand + 1)], 1ull);
     atomicAdd(&g_knn_trace.hist_pass[min(n_pass, 3)], 1ull);
   }
-}
-
-// ray mode: one wave per SAMPLE (5 per ray); I_out [R*5][8] int32, cnt_out [R*5]
-__global__ __launch_bounds__(256) void k_knn_rays(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
-                                                  const int* __restrict__ cell_start,
-                                                  const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                  const float* __restrict__ depth, const float* __restrict__ z_vals,
-                                                  const float* __restrict__ r_query,
-                                                  float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
-                                                  int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                  unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse,
-                                                  int trace) {
-  const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (p >= n_rays * S) return;
-  const unsigned long long t0 = trace ? clock64() : 0ull;
-  const int ray = p / S, si = p - ray * S;
-  const int lane = threadIdx.x & 63;
-  const GridMeta m = *meta;
-  const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
-  float r, r2;
-  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
-  float qx, qy, qz;
-  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
-               rays_d[ray * 3 + 2], zq, qx, qy, qz);
-  u64 mine;
-  unsigned long long n_cand = 0;
-  int n_pass = 0;
-  wave_knn_lane(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass);
-  // after an early exit the sentinel threshold was rho^2 <= r2: every kept entry has d2 <= rho^2 <= r2
-  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
-  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
-  if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-  if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand); }
-  if (trace && lane == 0) {
-    const unsigned long long cyc = clock64() - t0;
-    atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
-    atomicAdd(&g_knn_trace.sum_cand, n_cand); atomicMax(&g_knn_trace.max_cand, n_cand);
-    atomicAdd(&g_knn_trace.sum_pass, (unsigned long long)n_pass);
-    atomicAdd(&g_knn_trace.hist_cyc[log2_bucket(cyc)], 1ull); atomicAdd(&g_knn_trace.hist_cand[log2_bucket(n_cand + 1)], 1ull);
-    atomicAdd(&g_knn_trace.hist_pass[min(n_pass, 3)], 1ull);
-  }
-}
-
-// ray mode for SMALL launches (the tracker: 200 rays = 1000 queries, one wavefront each would leave every SIMD with a
-// single wavefront that waits out ~30 dependent memory round trips): FOUR wavefronts per sample share the rows of every
-// pass, merge their four top-8 lists through LDS and decide together whether the search radius must grow.  Same keys,
-// same order, same answer as k_knn_rays.
-__global__ __launch_bounds__(256) void k_knn_rays_w4(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
-                                                     const int* __restrict__ cell_start,
-                                                     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                     const float* __restrict__ depth, const float* __restrict__ z_vals,
-                                                     const float* __restrict__ r_query,
-                                                     float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
-                                                     int* __restrict__ I_out, int* __restrict__ cnt_out,
-                                                     unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse) {
-  __shared__ u64 sbest[4][K];
-  const int p = blockIdx.x;
-  if (p >= n_rays * S) return;
-  const int ray = p / S, si = p - ray * S;
-  const int lane = threadIdx.x & 63, wsub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const GridMeta m = *meta;
-  const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
-  float r, r2;
-  if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
-  float qx, qy, qz;
-  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
-               rays_d[ray * 3 + 2], zq, qx, qy, qz);
-  if (wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r)) {      // same answer in all four wavefronts
-    if (wsub == 0) { if (lane < K) I_out[p * K + lane] = -1; if (lane == 0) cnt_out[p] = 0; }
-    return;
-  }
-  u64 mine, thr;
-  unsigned long long n_cand = 0;
-  float rho = m.cell;
-  for (;;) {
-    const bool last = rho >= r;
-    const float re = last ? r : rho;
-    const float t2 = last ? r2 : __fmul_rn(rho, rho);
-    const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
-    mine = sentinel; thr = sentinel;
-    knn_scan_rows_lane(m, spos, cell_start, qx, qy, qz, re, mine, thr, n_cand, wsub, 4);
-    if (lane < K) sbest[wsub][lane] = mine;
-    __syncthreads();
-    // every wavefront merges the other three lists into its own: the four row sets are disjoint, so are the keys
-    for (int o = 1; o < 4; ++o) {
-      const int w2 = (wsub + o) & 3;
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const u64 kk = sbest[w2][j];
-        if (kk < thr) lane_list_insert(mine, thr, kk);
-      }
-    }
-    __syncthreads();
-    if (last || thr != sentinel) break;
-    rho *= 2.0f;
-  }
-  if (lane == 0 && cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand);
-  if (wsub != 0) return;
-  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
-  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
-  if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
-  if (lane == 0) cnt_out[p] = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1020,10 +807,13 @@ __global__ __launch_bounds__(256) void k_knn_queries(const GridMeta* __restrict_
   const GridMeta m = *meta;
   float r, r2;
   if (r_per_query) { r = r_per_query[qi]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
-  u64 best[K];
-  wave_knn(m, spos, cell_start, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], r, r2, best, nullptr, coarse);
-  unsigned ib, db; int cnt;
-  knn_emit(best, r2, lane, ib, db, cnt);
+  u64 mine;
+  unsigned long long n_cand = 0;
+  int n_pass = 0;
+  wave_knn_lane(m, spos, cell_start, q[qi * 3 + 0], q[qi * 3 + 1], q[qi * 3 + 2], r, r2, mine, n_cand, coarse, n_pass);
+  // after an early exit the sentinel threshold was rho^2 <= r2: every kept entry has d2 <= rho^2 <= r2
+  const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
+  const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) {
     bool empty = ib == 0xFFFFFFFFu;
     if (I_out) I_out[(long long)qi * K + lane] = empty ? -1ll : (long long)ib;
@@ -1079,73 +869,49 @@ __global__ __launch_bounds__(256) void k_dedupe_count(const GridMeta* __restrict
   if (lane == 0) cnt_out[qi] = cnt;
 }
 
-int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch (default), 1 / 3 / 4 = a per-sample kernel, 2 = per ray
 static inline float r2_of(float r) { return (float)((double)r * (double)r); }   // python: radius**2 in double, then f32
+
+int g_knn_version = -1;      // PSL_KNN / psl_debug_option("knn", v): 0 = by launch (default), 4 = per sample (flat), 2 = per ray
 
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals,
              const float* r_query, int n_rays, int* I_out, int* cnt_out, hipStream_t s, int max_blocks) {
   if (n_rays <= 0) return PSL_OK;
-  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0; }
-  // 0 = by launch: the THROTTLED side-stream prefetch of the mapper (max_blocks > 0: a persistent grid whose wavefronts
-  // walk several rays each) takes the per-ray kernel (2), whose five samples share one scan of the union box (173
-  // candidates per query against 522); every unthrottled launch takes the per-sample kernel.  Round 2 switched to the
-  // per-ray kernel from 1 024 rays on; measured in round 3 with the flat enumeration (4) and the candidate counter spread
-  // over 256 cache lines (one same-address atomic per query had serialised the 25 000-query launches): tracker launches
-  // of 1 500 rays 131 -> 39 us, of 5 000 rays 199 -> 80 us (TUM / ScanNet yamls +12 % frames/s), the mapper's main-stream
-  // prefetch of 64 x 1 000 rays 996 -> 890 us.  PSL_KNN_SMALL_MAX=<rays> restores a size threshold.
-  // 1 = one wavefront per sample, row walk.  3 = four wavefronts per sample sharing the rows of every pass: measured no
-  // faster than (1) on the tracker's 200-ray launches (profiles/r02_knn_small_ab.txt); an option (PSL_KNN_SMALL=3).
-  // 4 = one wavefront per sample with the FLAT candidate enumeration (two dependent memory trips per pass): the default.
-  static int small_ver = -1;
-  if (small_ver < 0) { const char* e = getenv("PSL_KNN_SMALL"); small_ver = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; if (small_ver == 2) small_ver = 4; }
-  static int small_max = -1;     // launches below this many rays take the per-sample kernel
-  if (small_max < 0) { const char* e = getenv("PSL_KNN_SMALL_MAX"); small_max = e ? atoi(e) : 0x7fffffff; }
-  const int ver = g_knn_version ? g_knn_version : ((n_rays >= small_max || max_blocks > 0) ? 2 : small_ver);
+  if (g_knn_version < 0) { const char* e = getenv("PSL_KNN"); g_knn_version = (e && (e[0] == '2' || e[0] == '4')) ? e[0] - '0' : 0; }
+  // Two kernels, the same keys and therefore bit-identical answers:
+  //  * k_knn_rays_flat (4): one wavefront per SAMPLE, flat candidate enumeration (two dependent memory trips per pass) --
+  //    every unthrottled launch: tracker launch (200 rays) 25 us, 1 500 rays 39 us, 5 000 rays 64-80 us;
+  //  * k_knn_rays2 (2): one wavefront per RAY, the five samples share one scan of the union box (173 candidates per query
+  //    against 522) -- the THROTTLED side-stream prefetch of the mapper (max_blocks > 0: a persistent grid whose wavefronts
+  //    walk several rays each, next to the decode kernels of the previous block).
+  // Rounds 2-4 carried two more per-sample kernels (row walk; four wavefronts per sample, "measured equal"): deleted in
+  // round 5, the flat enumeration replaced both everywhere (DESIGN_HISTORY.md).
+  const int ver = (g_knn_version == 2 || g_knn_version == 4) ? g_knn_version : (max_blocks > 0 ? 2 : 4);
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
-    // queries from which the high-occupancy instantiation is used (PSL_KNN_FLAT_LARGE; < 0 = never).  Measured [MI355X, round 4]:
-    // 25 000 queries (TUM / ScanNet tracker) 74.6 -> 64.1 us, TUM yaml +2.7 %, ScanNet +1 %, Replica (7 500 queries) +1.5 %; at
-    // the base mix's 1 000 queries (4 wavefronts per CU: no occupancy to gain, fewer loads in flight per trip) -0.5 %
+    // queries from which the high-occupancy instantiation <4 records in flight, 8 wavefronts per SIMD> is used (it is held to
+    // 64 VGPRs and spills two registers to scratch, profiles/r04_kernel_resources.json; PSL_KNN_FLAT_LARGE, < 0 = never).
+    // Measured [MI355X, round 4]: 25 000 queries (TUM / ScanNet tracker) 74.6 -> 64.1 us, TUM yaml +2.7 %, ScanNet +1 %,
+    // Replica (7 500 queries) +1.5 %; at the base mix's 1 000 queries (4 wavefronts per CU: no occupancy to gain) -0.5 %
     static int large_from = -2;
     if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : 5000; }
+    unsigned long long* cand = (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr;   // one atomic per query: only while measured
     if (large_from >= 0 && n_rays * S >= large_from)
       PSL_KLAUNCH((k_knn_rays_flat<4, 8>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                          rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
-                         (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4);
     else
       PSL_KLAUNCH((k_knn_rays_flat<8, 5>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                          rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
-                         (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr, ctx->coarse, trace4);
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4);
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }
-  if (ver == 3) {
-    PSL_KLAUNCH(k_knn_rays_w4, dim3(n_rays * S), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
-    PSL_LAUNCH_CHECK();
-    return PSL_OK;
-  }
-  if (ver >= 2) {
-    int blocks = (n_rays + 3) / 4;
-    if (max_blocks > 0) blocks = std::min(blocks, max_blocks);      // throttled: every wavefront walks several rays
-    PSL_KLAUNCH(k_knn_rays2, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                       rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
-    PSL_LAUNCH_CHECK();
-    return PSL_OK;
-  }
-  int blocks = (n_rays * S + 3) / 4;
-  static int trace = -1;
-  if (trace < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace = (e && e[0] == '1') ? 1 : 0; }
-  // (the candidate counter costs one same-address atomic per query: only while the bench's class timers are on)
-  PSL_KLAUNCH(k_knn_rays, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+  int blocks = (n_rays + 3) / 4;
+  if (max_blocks > 0) blocks = std::min(blocks, max_blocks);      // throttled: every wavefront walks several rays
+  PSL_KLAUNCH(k_knn_rays2, dim3(blocks), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                      rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out,
-                     (ctx->prof_on || trace) ? ctx->knn_cand : nullptr, ctx->coarse, trace);
+                     ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, ctx->knn_cand, ctx->coarse);
   PSL_LAUNCH_CHECK();
   return PSL_OK;
 }
@@ -1176,122 +942,9 @@ int knn_queries(psl_ctx* ctx, const float* q, const float* r_per_query, float r_
   return PSL_OK;
 }
 
-// ----------------------------------------------------------------- point growth
-__global__ __launch_bounds__(256) void k_append_raw(const float* __restrict__ src, int n, float4* pos, int base) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) pos[base + i] = make_float4(src[i * 3 + 0], src[i * 3 + 1], src[i * 3 + 2], 0.f);
-}
-
-__global__ __launch_bounds__(256) void k_download(const float4* __restrict__ pos, int n, float* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { float4 p = pos[i]; out[i * 3 + 0] = p.x; out[i * 3 + 1] = p.y; out[i * 3 + 2] = p.z; }
-}
-
-// surface points o + d*depth for rays with depth > 0 (neural_point.py:108-113); others get a far-away sentinel
-__global__ __launch_bounds__(256) void k_surface_pts(const float* __restrict__ ro, const float* __restrict__ rd,
-                                                     const float* __restrict__ dep, int n, float* q) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float d = dep[i];
-  float x, y, z;
-  sample_point(ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2], rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2], d, x, y, z);
-  q[i * 3] = x; q[i * 3 + 1] = y; q[i * 3 + 2] = z;
-}
-
-// single-block ordered compaction: keep[i] = depth>0 && cnt==0 ; appends 3 points per kept location in
-// ray order (neural_point.py:141-147: pts[mask].reshape(-1,3)).
-__global__ __launch_bounds__(1024) void k_append_kept(const float* __restrict__ ro, const float* __restrict__ rd,
-                                                      const float* __restrict__ dep, const int* __restrict__ cnt,
-                                                      int has_index, int n, float near_e, float far_e, float4* pos,
-                                                      int base, int capacity, unsigned char* keep_out,
-                                                      int* n_kept_out) {
-  __shared__ int wsum[16];
-  __shared__ int running;
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    int i = i0 + threadIdx.x;
-    bool keep = false;
-    float d = 0.f;
-    if (i < n) { d = dep[i]; keep = d > 0.f && (!has_index || cnt[i] == 0); }
-    u64 bal = __ballot(keep);
-    int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[w] = __popcll(bal);
-    __syncthreads();
-    int off = running;
-    for (int j = 0; j < w; ++j) off += wsum[j];
-    int rank = off + pre;
-    if (i < n) keep_out[i] = keep ? 1 : 0;
-    if (keep && base + 3 * rank + 2 < capacity) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        // z = near*d*(1-t) + far*d*t, t = linspace(0,1,3)  (neural_point.py:126-139)
-        float t = 0.5f * (float)a;
-        float z = __fadd_rn(__fmul_rn(__fmul_rn(near_e, d), 1.0f - t), __fmul_rn(__fmul_rn(far_e, d), t));
-        float x, y, zz;
-        sample_point(ro[i * 3], ro[i * 3 + 1], ro[i * 3 + 2], rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2], z, x, y, zz);
-        pos[base + 3 * rank + a] = make_float4(x, y, zz, 0.f);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int j = 0; j < 16; ++j) t += wsum[j]; running += t; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *n_kept_out = running;
-}
-
 }  // namespace psl
 
 using namespace psl;
-
-extern "C" int psl_points_reset(psl_ctx* ctx) {
-  if (!ctx) return PSL_ERR_ARG;
-  ctx->n_points = 0; ctx->index_points = -1;
-  return PSL_OK;
-}
-
-extern "C" int psl_points_append(psl_ctx* ctx, const float* pos, int n, void* stream) {
-  if (!ctx || n < 0) { set_error("psl_points_append: bad argument"); return PSL_ERR_ARG; }
-  if (n == 0) return PSL_OK;
-  if (ctx->n_points + n > ctx->cfg.max_points) {
-    set_error("psl_points_append: capacity %d exceeded (%d + %d)", ctx->cfg.max_points, ctx->n_points, n);
-    return PSL_ERR_CAPACITY;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_append_raw, dim3((n + 255) / 256), dim3(256), 0, s, pos, n, ctx->pos, ctx->n_points);
-  PSL_LAUNCH_CHECK();
-  ctx->n_points += n;
-  ctx->index_points = -1;
-  return PSL_OK;
-}
-
-extern "C" int psl_points_truncate(psl_ctx* ctx, int n) {
-  if (!ctx || n < 0 || n > ctx->n_points) { set_error("psl_points_truncate: bad count"); return PSL_ERR_ARG; }
-  if (n != ctx->n_points) { ctx->n_points = n; ctx->index_points = -1; }
-  return PSL_OK;
-}
-
-extern "C" int psl_points_count(psl_ctx* ctx) { return ctx ? ctx->n_points : PSL_ERR_ARG; }
-
-extern "C" int psl_points_download(psl_ctx* ctx, float* pos_out, int capacity_points, void* stream) {
-  if (!ctx || !pos_out) return PSL_ERR_ARG;
-  int n = min(ctx->n_points, capacity_points);
-  if (n > 0) hipLaunchKernelGGL(k_download, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->pos, n, pos_out);
-  PSL_LAUNCH_CHECK();
-  return n;
-}
-
-extern "C" int psl_points_download_range(psl_ctx* ctx, int first, int count, float* pos_out, void* stream) {
-  if (!ctx || first < 0 || count < 0 || first + count > ctx->n_points || (count > 0 && !pos_out)) {
-    set_error("psl_points_download_range: bad range [%d, %d) of %d", first, first + count, ctx ? ctx->n_points : -1);
-    return PSL_ERR_ARG;
-  }
-  if (count > 0)
-    hipLaunchKernelGGL(k_download, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, ctx->pos + first, count, pos_out);
-  PSL_LAUNCH_CHECK();
-  return count;
-}
 
 extern "C" int psl_index_build(psl_ctx* ctx, void* stream) {
   if (!ctx) return PSL_ERR_ARG;
@@ -1317,52 +970,6 @@ extern "C" int psl_dedupe_count(psl_ctx* ctx, const float* q, const float* r_per
   return PSL_OK;
 }
 
-// psl_dedupe_blocks: the cross-rank half of the merge's admission test.  Locations arrive in rank blocks; block b's
-// locations are tested against the points (three per location) of the locations of the blocks before it that are still
-// kept.  One launch per block, in block order, so the keep flags a block reads are final; one wavefront per location,
-// lanes stride over the earlier locations.  (dx*dx + dy*dy) + dz*dz unfused, as the grid search evaluates it.
-__global__ __launch_bounds__(256) void k_dedupe_block(const float* __restrict__ pts, int pts_stride, const float* __restrict__ rad,
-                                                      int rad_stride, int first, int last, unsigned char* __restrict__ keep) {
-  const int l = first + __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (l >= last || !keep[l]) return;
-  const int lane = threadIdx.x & 63;
-  const float* qp = pts + (size_t)(3 * l + 1) * pts_stride;       // the surface point is the middle one of the triplet
-  const float qx = qp[0], qy = qp[1], qz = qp[2];
-  const float r = rad[(size_t)(3 * l + 1) * rad_stride], r2 = __fmul_rn(r, r);
-  bool hit = false;
-  for (int j0 = 0; j0 < first && !hit; j0 += 64) {
-    const int j = j0 + lane;
-    bool h = false;
-    if (j < first && keep[j]) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const float* p = pts + (size_t)(3 * j + t) * pts_stride;
-        const float dx = __fsub_rn(qx, p[0]), dy = __fsub_rn(qy, p[1]), dz = __fsub_rn(qz, p[2]);
-        h |= __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)) < r2;
-      }
-    }
-    hit = __any(h);
-  }
-  if (hit && lane == 0) keep[l] = 0;
-}
-
-extern "C" int psl_dedupe_blocks(psl_ctx* ctx, const float* pts, int pts_stride, const float* radius, int radius_stride,
-                                 const int32_t* block_first, int n_blocks, uint8_t* keep, void* stream) {
-  if (!ctx || !pts || !radius || !block_first || !keep || n_blocks < 0 || pts_stride < 3 || radius_stride < 1) {
-    set_error("psl_dedupe_blocks: bad argument"); return PSL_ERR_ARG;
-  }
-  for (int b = 0; b < n_blocks; ++b)
-    if (block_first[b] < 0 || block_first[b + 1] < block_first[b]) { set_error("psl_dedupe_blocks: block offsets must ascend"); return PSL_ERR_ARG; }
-  for (int b = 1; b < n_blocks; ++b) {
-    const int first = block_first[b], last = block_first[b + 1];
-    if (last == first || first == 0) continue;
-    hipLaunchKernelGGL(k_dedupe_block, dim3((last - first + 3) / 4), dim3(256), 0, (hipStream_t)stream, pts, pts_stride, radius,
-                       radius_stride, first, last, keep);
-  }
-  PSL_LAUNCH_CHECK();
-  return PSL_OK;
-}
-
 extern "C" int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float* rays_d, int n_rays,
                                  const float* z_steps, const int32_t* step_row, int n_steps, float radius,
                                  uint8_t* hits, void* stream) {
@@ -1376,44 +983,5 @@ extern "C" int psl_near_pcl_hits(psl_ctx* ctx, const float* rays_o, const float*
   hipLaunchKernelGGL(k_near_pcl_hits, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ctx->meta,
                      ctx->spos, ctx->cell_start, rays_o, rays_d, z_steps, step_row, n_rays, n_steps, radius, r2_of(radius), hits);
   PSL_LAUNCH_CHECK();
-  return PSL_OK;
-}
-
-extern "C" int psl_add_points_sync(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth,
-                                   const float* radius_per_ray, float r_scalar, int n, float near_end, float far_end,
-                                   uint8_t* keep_out, int* n_kept_host, void* stream) {
-  if (!ctx || n < 0 || !keep_out || !n_kept_host) { set_error("psl_add_points_sync: bad argument"); return PSL_ERR_ARG; }
-  *n_kept_host = 0;
-  if (n == 0) return PSL_OK;
-  hipStream_t s = (hipStream_t)stream;
-  int has_index = ctx->n_points > 0;
-  if (has_index && ctx->index_points != ctx->n_points) {
-    set_error("psl_add_points_sync: index is stale, call psl_index_build"); return PSL_ERR_STATE;
-  }
-  if (ctx->scan_flags_cap < 4 * n) {
-    if (ctx->scan_flags) (void)hipFree(ctx->scan_flags);
-    PSL_HIP(hipMalloc(&ctx->scan_flags, sizeof(int) * 4 * (size_t)n)); psl::poison(ctx->scan_flags, sizeof(int) * 4 * (size_t)n);
-    ctx->scan_flags_cap = 4 * n;
-  }
-  float* qsurf = (float*)ctx->scan_flags;            // [n][3]
-  int* cnt = ctx->scan_flags + 3 * n;                // [n]
-  if (has_index) {
-    hipLaunchKernelGGL(k_surface_pts, dim3((n + 255) / 256), dim3(256), 0, s, rays_o, rays_d, depth, n, qsurf);
-    int rc = knn_queries(ctx, qsurf, radius_per_ray, r_scalar, n, nullptr, nullptr, cnt, s);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(k_append_kept, dim3(1), dim3(1024), 0, s, rays_o, rays_d, depth, cnt, has_index, n, near_end,
-                     far_end, ctx->pos, ctx->n_points, ctx->cfg.max_points, keep_out, ctx->d_counter);
-  PSL_LAUNCH_CHECK();
-  int kept = 0;
-  PSL_HIP(hipMemcpyAsync(&kept, ctx->d_counter, sizeof(int), hipMemcpyDeviceToHost, s));
-  PSL_HIP(hipStreamSynchronize(s));
-  if (ctx->n_points + 3 * kept > ctx->cfg.max_points) {
-    set_error("psl_add_points_sync: capacity %d exceeded", ctx->cfg.max_points);
-    return PSL_ERR_CAPACITY;
-  }
-  ctx->n_points += 3 * kept;
-  if (kept > 0) ctx->index_points = -1;
-  *n_kept_host = kept;
   return PSL_OK;
 }

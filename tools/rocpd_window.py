@@ -124,6 +124,13 @@ def main():
         print("holes >= 10 us by the kernel before them: kernel,n,total_ms")
         for k, v in r["long_holes_by_prev"].items():
             print(f"  {k},{v['n']},{v['total_ms']}")
+    # outliers over the WHOLE trace (set-up included): which launches took far longer than their symbol's median, and when
+    whole = analyse(rows, top)
+    t_first_mark = rows[marks[0]][1]
+    print(f"== whole trace: {len(rows)} kernels; outliers (offset relative to the first marker):")
+    for o in whole["outliers"]:
+        print(f"  OUTLIER {o['kernel']}: {o['us']} us (median {o['median_us']}) at {o['at_ms'] - (t_first_mark - rows[0][1]) / 1e6:+.1f} ms, "
+              f"after {o['prev']}, concurrent with {o['concurrent']}")
     if "--json" in a:
         json.dump(res, open(a[a.index("--json") + 1], "w"), indent=1)
 
