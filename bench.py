@@ -58,10 +58,16 @@ def parse():
                          "(SURVEY.md 8d: the TUM-like stream, 'sigma = 0.5 % d + 2 % dropout'), 0 otherwise")
     ap.add_argument("--depth-dropout", type=float, default=None,
                     help="fraction of pixels whose sensor depth is dropped to 0 (holes); default: 0.02 for --mix tum, 0 otherwise")
-    ap.add_argument("--open-loop", action="store_true",
-                    help="rounds 1-4: every frame starts from the ground-truth pose + noise.  Default since round 5: CLOSED loop -- "
-                         "frame i starts from the constant-speed extrapolation of the tracker's own two previous estimates "
-                         "(Tracker.py:283-290), the mapper maps at the tracker's estimate; config.ate_rmse_cm in the line")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="frame i starts from the constant-speed extrapolation of the tracker's OWN two previous estimates "
+                         "(Tracker.py:283-290, psl_pose_const_speed on the device), the mapper maps at the tracker's estimate; "
+                         "config.ate_rmse_cm in the line.  One GPU.  Default: open loop (ground-truth pose + a perturbation of the size "
+                         "the constant-speed model leaves) -- measured in round 5, the base yaml's tracker budget (200 px x 20 it, "
+                         "<= 4 cm of correction per frame) does not hold this stream's 5.6 cm / 0.4 deg per frame in closed loop (ATE "
+                         "76 cm after 40 frames, the run then maps junk), the Replica yaml's does (0.5 cm): see DESIGN.md")
+    ap.add_argument("--units-per-frame", type=float, default=None,
+                    help="trajectory units the camera advances per frame (default 2.0 = ~5.6 cm / 0.4 deg, SURVEY.md 8d; 0.5 = ~1.4 cm, "
+                         "a Replica-like camera speed; --track-only uses 0.5)")
     ap.add_argument("--pretrain-keyframes", type=int, default=8,
                     help="closed loop: keyframes mapped at their true poses before the run starts (untimed set-up), one every "
                          "mapping.every_frame frames back along the trajectory -- the map a run that reached the first frame would "
@@ -90,6 +96,7 @@ def build_world(args, rank, world, dev):
     from point_slam_amd.config import MIXES, default_config
     from point_slam_amd.slam import Frame, HipSLAM, camera_tensor_from_c2w
     cfg = MIXES[args.mix](default_config())
+    args.open_loop = not args.closed_loop
     cam = syn.intrinsics(args.width, args.height)
     torch.manual_seed(cfg["setup_seed"] + rank)
     slam = HipSLAM(cfg, cam, device=str(dev), max_points=int(args.points * 1.3) + 300_000, engine=args.engine)
@@ -137,7 +144,8 @@ def build_world(args, rank, world, dev):
     # frame-parallel partition: local step i is global frame rank + world*i
     frames, cams0 = [], []
     g = torch.Generator().manual_seed(1000 + rank)
-    upf = getattr(args, "_unit_per_frame", 2.0)
+    upf = args.units_per_frame if args.units_per_frame is not None else getattr(args, "_unit_per_frame", 2.0)
+    args.open_loop = not args.closed_loop
     n_early = 4 if (args.open_loop or track_only) else max(args.pretrain_keyframes, 2)
     for i in range(-n_early, n_total):
         # 2 trajectory units per frame = ~5.6 cm and ~0.4 degrees ("5 cm / 1 deg per frame"): every mapped frame sees new surface
@@ -220,7 +228,7 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         hist.append(best.clone())
         if len(hist) > 2:
             hist.pop(0)
-        state.setdefault("traj", []).append((i, hist[-1][4:7]))
+    state.setdefault("traj", []).append((i, best[4:7].clone()))      # translation of the pose the tracker settled on
     if i % every == 0:
         c2w34 = H.get_camera_from_tensor(best)
         if "row4" not in state:
@@ -603,6 +611,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.closed_loop and world > 1:
+        raise SystemExit("--closed-loop: one GPU (frame-parallel ranks see every N-th frame: a constant-speed extrapolation across "
+                         "the stride is not the reference's pose chain)")
     if args.track_only and (args.warmup < 2 or world > 1):
         raise SystemExit("--track-only: one GPU, and --warmup >= 2 (frames 0 and 1 take the ground-truth pose, Tracker.py:278-279)")
     cfg, cam, slam, frames, cams0, every = build_world(args, rank, world, dev)
@@ -770,6 +781,8 @@ def main():
                        "pose_loop": ("open: every frame starts from the ground-truth pose + noise (rounds 1-4)" if args.open_loop else
                                      "closed: frame i starts from the constant-speed extrapolation of the tracker's own two previous "
                                      "estimates (psl_pose_const_speed, Tracker.py:283-290); mapping at the tracker's estimate"),
+                       # translation error of the tracker's lowest-loss pose against the ground truth over the timed frames: the
+                       # trajectory error of the closed loop, or (open loop) what is left of the initial perturbation
                        "ate_rmse_cm": pass1["ate"]["rmse_cm"] if pass1["ate"] else None,
                        "ate_max_cm": pass1["ate"]["max_cm"] if pass1["ate"] else None,
                        "ate_event_pass": pass2["ate"] if pass2 else None,

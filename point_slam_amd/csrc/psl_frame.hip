@@ -124,13 +124,17 @@ __global__ __launch_bounds__(256) void k_keyframe_overlap(const float* __restric
                                                           const float* __restrict__ depth, int n_rays, int n_samples,
                                                           const float* __restrict__ w2c /*[n_kf][12]*/, psl_cam_intr cam,
                                                           float edge, float* __restrict__ percent) {
-  __shared__ int cnt[4];
+  __shared__ int cnt[4], cnt_all[4];
   const float* M = w2c + (size_t)blockIdx.x * 12;
-  int c = 0;
+  int c = 0, call = 0;
   const int total = n_rays * n_samples;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const int r = e / n_samples, k = e - r * n_samples;
     const float d = depth[r];
+    // get_samples(..., depth_filter=True) (Mapper.py:190-192, common.py:173-179): pixels without sensor depth carry no
+    // samples -- skipped here, so that the caller need not compact the batch (a host synchronisation per mapped frame)
+    if (!(d > 0.f)) continue;
+    ++call;
     // torch.linspace(0,1,N) on near = 0.8 d, far = d + 0.5:  z = near*(1-t) + far*t
     const float t = (n_samples > 1) ? (float)k / (float)(n_samples - 1) : 0.f;
     const float z = __fadd_rn(__fmul_rn(__fmul_rn(d, 0.8f), 1.0f - t), __fmul_rn(__fadd_rn(d, 0.5f), t));
@@ -148,10 +152,13 @@ __global__ __launch_bounds__(256) void k_keyframe_overlap(const float* __restric
     c += in ? 1 : 0;
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); call += __shfl_xor(call, o); }
+  if ((threadIdx.x & 63) == 0) { cnt[threadIdx.x >> 6] = c; cnt_all[threadIdx.x >> 6] = call; }
   __syncthreads();
-  if (threadIdx.x == 0) percent[blockIdx.x] = total > 0 ? (float)((double)(cnt[0] + cnt[1] + cnt[2] + cnt[3]) / (double)total) : 0.f;
+  if (threadIdx.x == 0) {
+    const int tot = cnt_all[0] + cnt_all[1] + cnt_all[2] + cnt_all[3];
+    percent[blockIdx.x] = tot > 0 ? (float)((double)(cnt[0] + cnt[1] + cnt[2] + cnt[3]) / (double)tot) : 0.f;
+  }
 }
 
 
@@ -338,16 +345,28 @@ extern "C" int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_
       w2c[(size_t)f * 12 + a * 4 + 3] = (float)(-(inv[a][0] * T[0] + inv[a][1] * T[1] + inv[a][2] * T[2]));
     }
   }
-  float* dev = nullptr;
-  PSL_HIP(hipMalloc(&dev, sizeof(float) * ((size_t)n_kf * 12 + n_kf)));
+  // scratch for the poses and the answers: kept per device and grown on demand (a hipMalloc + hipFree pair per call cost
+  // two device-wide synchronisations per mapped frame)
+  static float* g_dev[64] = {nullptr};
+  static size_t g_cap[64] = {0};
+  int devid = 0;
+  PSL_HIP(hipGetDevice(&devid));
+  if (devid < 0 || devid >= 64) { set_error("psl_keyframe_overlap_sync: device %d", devid); return PSL_ERR_ARG; }
+  const size_t need = (size_t)n_kf * 13;
+  if (g_cap[devid] < need) {
+    if (g_dev[devid]) (void)hipFree(g_dev[devid]);
+    g_dev[devid] = nullptr; g_cap[devid] = 0;
+    PSL_HIP(hipMalloc(&g_dev[devid], sizeof(float) * (need + 13 * 64)));
+    g_cap[devid] = need + 13 * 64;
+  }
+  float* dev = g_dev[devid];
   float* dpct = dev + (size_t)n_kf * 12;
-  PSL_HIP(hipMemcpy(dev, w2c.data(), sizeof(float) * (size_t)n_kf * 12, hipMemcpyHostToDevice));   // synchronous: w2c is local
+  PSL_HIP(hipMemcpyAsync(dev, w2c.data(), sizeof(float) * (size_t)n_kf * 12, hipMemcpyHostToDevice, s));   // pageable source: staged before it returns
   hipLaunchKernelGGL(k_keyframe_overlap, dim3(n_kf), dim3(256), 0, s, rays_o, rays_d, depth, n_rays, n_samples, dev, cam,
                      edge, dpct);
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(percent_host, dpct, sizeof(float) * n_kf, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  if (e == hipSuccess) e = hipMemcpy(percent_host, dpct, sizeof(float) * n_kf, hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
   if (e != hipSuccess) { set_error("psl_keyframe_overlap_sync: %s", hipGetErrorString(e)); return PSL_ERR_HIP; }
   return PSL_OK;
 }

@@ -54,12 +54,18 @@ def get_selected_index_with_grad(npc, H0, H1, W0, W1, n, image, ratio=15, gt_dep
 
 
 def keyframe_overlap(rays_o, rays_d, gt_depth, keyframe_c2w, cam: dict, n_samples=8, edge=20):
-    """percent_inside per keyframe (src/Mapper.py:197-229). keyframe_c2w: list of [4,4] (or [3,4]) poses."""
+    """percent_inside per keyframe (src/Mapper.py:197-229). keyframe_c2w: list of [4,4] (or [3,4]) poses, tensors or host
+    float lists.  Rays with gt_depth <= 0 are skipped by the kernel (get_samples' depth_filter, Mapper.py:190-192): the
+    caller may pass the uncompacted draw."""
     n_kf = len(keyframe_c2w)
     if n_kf == 0:
         return np.zeros(0, dtype=np.float32)
     flat = []
     for c in keyframe_c2w:
+        if isinstance(c, (list, tuple)):       # 12 (3x4) or 16 host floats, row-major: Frame.c2w_host() -- no device copy
+            h = [float(x) for x in c]
+            flat += h[:12] + [0.0, 0.0, 0.0, 1.0]
+            continue
         m = torch.eye(4)
         cc = c.detach().float().cpu()
         m[:cc.shape[0], :] = cc

@@ -23,6 +23,30 @@ import torch
 from . import _lib
 
 
+def _kept_indices(keep_u8: torch.Tensor, n_kept: int) -> torch.Tensor:
+    """Indices of the set flags, their number known on the host: no device-to-host synchronisation."""
+    if n_kept == 0:
+        return torch.zeros(0, dtype=torch.int64, device=keep_u8.device)
+    try:
+        return torch.nonzero_static(keep_u8, size=n_kept).reshape(-1)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        return torch.nonzero(keep_u8).reshape(-1)
+
+
+class _HostCount(int):
+    """Return value of add_neural_points: the reference returns a 0-d tensor or an int (neural_point.py:91-92, callers use it
+    in arithmetic and int()); the count is already on the host, so it is an int that also answers .item() / int() / float()
+    without a device round trip."""
+
+    def __new__(cls, v, device=None):
+        o = super().__new__(cls, int(v))
+        o.device = device
+        return o
+
+    def item(self):
+        return int(self)
+
+
 class HipNeuralPointCloud(object):
     def __init__(self, cfg, max_points: int = 4_000_000, device=None):
         self.cfg = cfg
@@ -261,18 +285,20 @@ class HipNeuralPointCloud(object):
         # features ~ N(0, 0.1^2), geometry first then colour (neural_point.py:149-159)
         gnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
         cnew = torch.zeros([n_new, self.c_dim], device=self.device).normal_(mean=0, std=0.1)
-        kb = keep.bool()
-        rad_new = (rad[kb] if rad is not None else torch.full((kept.value,), float(r_scalar), device=ro.device))
+        # rows of the kept locations: the count is already on the host (psl_add_points_sync), so the index list is built
+        # without another synchronisation (boolean indexing would stall the host once per use: three times here)
+        kidx = _kept_indices(keep, kept.value)
+        rad_new = (rad.index_select(0, kidx) if rad is not None else torch.full((kept.value,), float(r_scalar), device=ro.device))
         self._append_feats(gnew, cnew, rad_new.repeat_interleave(3))
         # surface point and colour*255 of every kept location (neural_point.py:109,113,123-124; exported by
         # Mapper.py:757-758 and the checkpoint)
-        self._input_pos.append((ro + rd * dep[:, None])[kb])
-        self._input_rgb.append((batch_gt_color.detach().to(ro.device) * 255)[kb].float())
+        self._input_pos.append((ro + rd * dep[:, None]).index_select(0, kidx))
+        self._input_rgb.append((batch_gt_color.detach().to(ro.device) * 255).index_select(0, kidx).float())
         if kept.value:
             self._build()
         if return_new:
             return kept.value, keep.bool(), n_before
-        return torch.tensor(kept.value, device=self.device)
+        return _HostCount(kept.value, self.device)
 
     # ---- find_neighbors_faiss (neural_point.py:169-215) -----------------------------------
     def find_neighbors_faiss(self, pos, step='add', retrain=False, is_pts_grad=False, dynamic_radius=None):

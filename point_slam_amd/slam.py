@@ -43,6 +43,21 @@ class Frame:
         self.exposure = exposure  # [8] exposure latent of a keyframe (model.encode_exposure)
         self.grad_mag = None      # [H,W] f64 colour-gradient magnitude, filled on demand
 
+    def c2w_host(self) -> list:
+        """The pose as 12 host floats (row-major 3x4): ONE device-to-host copy per pose, shared by everything a mapped frame
+        needs it for on the host side (psl_frame_view of the mapping window, the frustum selection, the keyframe overlap test)
+        -- each of those used to copy it by itself, and every copy stalls the host on all the work queued so far.  The cache
+        holds a REFERENCE to the tensor it copied (an id() alone can be recycled by a new tensor at the same address, version 0
+        again) plus its version counter; tensors without one (inference mode) are copied every time."""
+        try:
+            ver = self.c2w._version
+        except Exception:
+            ver = None
+        if ver is None or getattr(self, "_c2w_ref", None) is not self.c2w or self._c2w_ver != ver:
+            self._c2w_host = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
+            self._c2w_ref, self._c2w_ver = self.c2w, ver
+        return self._c2w_host
+
     def view(self, pose: bool = True) -> _lib.psl_frame_view:
         """pose=False: the tracker reads the pose from its camera tensor on the device (psl_frame_view.c2w is "mapping
         only"); the device-to-host copy of c2w would stall the host on everything queued so far, once per frame."""
@@ -51,18 +66,9 @@ class Frame:
         v.color = self.color.data_ptr()
         v.r_query = self.r_query.data_ptr() if self.r_query is not None else None
         if pose and self.c2w is not None:
-            # one device-to-host copy per pose, not one per mapping call.  The cache holds a REFERENCE to the tensor it copied
-            # (an id() alone can be recycled by a new tensor at the same address, version 0 again) plus its version
-            # counter; tensors without one (inference mode) are copied every time.
-            try:
-                ver = self.c2w._version
-            except Exception:
-                ver = None
-            if ver is None or getattr(self, "_c2w_ref", None) is not self.c2w or self._c2w_ver != ver:
-                self._c2w_host = self.c2w[:3, :4].detach().float().cpu().reshape(-1).tolist()
-                self._c2w_ref, self._c2w_ver = self.c2w, ver
+            h = self.c2w_host()
             for i in range(12):
-                v.c2w[i] = self._c2w_host[i]
+                v.c2w[i] = h[i]
         return v
 
 
@@ -320,9 +326,11 @@ class HipSLAM:
         ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
         ui, vi = u.long(), v.long()
         gd, gc = frame.depth[vi, ui], frame.color[vi, ui]
-        keep = gd > 0                                            # depth_filter=True (Mapper.py:311-313)
-        rad = frame.r_add[vi, ui][keep] if self.cfg["use_dynamic_radius"] else None
-        return int(self.npc.add_neural_points(ro[keep].contiguous(), rd[keep].contiguous(), gd[keep], gc[keep],
+        # depth_filter=True (Mapper.py:311-313): the native admission test drops rays without sensor depth itself (keep =
+        # depth > 0 and no point inside the radius, in ray order), so the batch goes down uncompacted -- four boolean-index
+        # operations, each a host synchronisation, per batch
+        rad = frame.r_add[vi, ui] if self.cfg["use_dynamic_radius"] else None
+        return int(self.npc.add_neural_points(ro.contiguous(), rd.contiguous(), gd, gc,
                                               is_pts_grad=is_pts_grad, dynamic_radius=rad))
 
     def add_points(self, frame: Frame, c2w: torch.Tensor, n_pixels=None, first=False):
@@ -357,7 +365,11 @@ class HipSLAM:
         N = self.npc.pts_num()
         sel = torch.empty(N, dtype=torch.int32, device=self.device)
         row_map = torch.empty(N, dtype=torch.int32, device=self.device)
-        c2w_h = (C.c_float * 16)(*c2w.detach().float().cpu().reshape(-1).tolist())
+        if c2w is frame.c2w:
+            h = frame.c2w_host() + [0.0, 0.0, 0.0, 1.0]         # the copy the frame already holds (one per pose)
+        else:
+            h = c2w.detach().float().cpu().reshape(-1).tolist()
+        c2w_h = (C.c_float * 16)(*h)
         n_sel = C.c_int(0)
         _lib.check(L.psl_frustum_select_sync(self.npc.handle, c2w_h, self.cam_intr, _lib.ptr(frame.depth), -1.0,
                                              float(self.cfg["mapping"]["frustum_edge"]), _lib.ptr(sel),
@@ -384,9 +396,10 @@ class HipSLAM:
                     u, v = H.pixels_from_flat_index(idx, 0, cam["H"], 0, cam["W"])
                     ro, rd = H.get_rays_from_uv(u, v, c2w, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
                     gd = frame.depth[v.long(), u.long()]
-                    keep = gd > 0
-                    ids = frame_ops.keyframe_selection_overlap(ro[keep].contiguous(), rd[keep].contiguous(), gd[keep],
-                                                               [f.c2w for f in older], cam, k)
+                    # depth_filter=True (Mapper.py:190-192): pixels without sensor depth carry no samples -- the kernel skips
+                    # rays with depth <= 0 and counts over the others, no compaction (and no host sync) here
+                    ids = frame_ops.keyframe_selection_overlap(ro.contiguous(), rd.contiguous(), gd.contiguous(),
+                                                               [f.c2w_host() for f in older], cam, k)
                     win += [older[int(i)] for i in ids]
                 else:
                     perm = torch.randperm(len(older))[:k].tolist()
