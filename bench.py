@@ -82,6 +82,9 @@ def parse():
                          "to RCCL across GPUs and the first multi-GPU run should not depend on it)")
     ap.add_argument("--merge", default="mean", choices=["mean", "owner"],
                     help="N > 1: rule for feature rows several ranks trained (point_slam_amd/dist.py)")
+    ap.add_argument("--fps-window", type=int, default=0,
+                    help="long runs: frames/s of every window of this many frames of the timed pass (one device synchronisation per "
+                         "window), next to the device-memory high-water mark -- the steady-state evidence behind the 20-frame headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -465,9 +468,10 @@ def cpu_baseline(cfg, cam, n_points):
     per_frame = tr["iters"] * t_track + mp["iters"] / mp["every_frame"] * (r * t_geo + (1.0 - r) * t_col)
     calib = None
     try:      # the imported reference against this port, per iteration, measured in the build container (oracle/calibrate_cpu_baseline.py)
-        cj = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_calibration.json")))
+        cf = next(f for f in ("r05_cpu_calibration.json", "r03_cpu_calibration.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        cj = json.load(open(os.path.join(ROOT, "profiles", cf)))
         calib = dict(reference_over_port_per_frame=cj["reference_over_port_per_frame"], threads=cj["threads"],
-                     file="profiles/r03_cpu_calibration.json")
+                     file="profiles/" + cf)
     except Exception:
         pass
     return dict(value=round(1.0 / per_frame, 5), unit="frames/s", cores=n_thr, kind="port", calibration_vs_imported_reference=calib,
@@ -645,14 +649,22 @@ def main():
 
     mark = torch.zeros(1, device=dev) if os.environ.get("PSL_BENCH_MARK") == "1" else None
 
-    def timed(first):
+    windows = []
+
+    def timed(first, record_windows=False):
         barrier()
         if mark is not None:        # a kernel no other code launches: tools/rocpd_window.py cuts the rocprofv3 trace at these
             mark.erfinv_()
             torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        t0 = tw = time.perf_counter()
         for i in range(first, first + args.steps):
             run_step(i, slam, frames, cams0, every, cfg, world, args, state)
+            if record_windows and args.fps_window > 0 and (i - first + 1) % args.fps_window == 0:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                windows.append(dict(frames=f"{i - args.fps_window + 1}..{i}", fps=round(args.fps_window / (now - tw), 2),
+                                    points=slam.npc.pts_num(), mapped=state["mapped"]))
+                tw = now
         barrier()
         d = time.perf_counter() - t0
         if mark is not None:
@@ -668,7 +680,7 @@ def main():
     same_frames = world == 1 and not args.different_frames and not args.no_kernel_timing
     snap = take_snapshot(slam, state, dev) if same_frames else None
     n_log0, n_traj0 = len(state.get("map_log", [])), len(state.get("traj", []))
-    dt = timed(args.warmup)
+    dt = timed(args.warmup, record_windows=True)
     pass1 = dict(map_log=state.get("map_log", [])[n_log0:], ate=ate_of(state.get("traj", [])[n_traj0:], frames),
                  points_end=slam.npc.pts_num(), mapped=state["mapped"], added=state["added"])
     # (2) the same work again with a HIP start/stop event pair on every kernel launch of the hot classes
@@ -778,6 +790,10 @@ def main():
                        "mapped_frames": state["mapped"],
                        # what the timed pass actually ran (the mapping iteration count is data dependent, Mapper.py:404-406)
                        "timed_pass": dict(iters_of(pass1["map_log"]), points_end=pass1["points_end"]),
+                       "fps_per_window": windows or None,
+                       "device_memory": dict(torch_allocated_peak_mb=round(torch.cuda.max_memory_allocated(dev) / 2 ** 20, 1),
+                                             torch_reserved_mb=round(torch.cuda.memory_reserved(dev) / 2 ** 20, 1),
+                                             device_used_mb=round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2 ** 20, 1)),
                        "pose_loop": ("open: every frame starts from the ground-truth pose + noise (rounds 1-4)" if args.open_loop else
                                      "closed: frame i starts from the constant-speed extrapolation of the tracker's own two previous "
                                      "estimates (psl_pose_const_speed, Tracker.py:283-290); mapping at the tracker's estimate"),

@@ -389,6 +389,13 @@ typedef enum { PSL_SELFTEST_SINCOS = 0, PSL_SELFTEST_SOFTPLUS = 1, PSL_SELFTEST_
                PSL_SELFTEST_ADAM_REPLAY = 4 } psl_selftest_kind;
 int psl_selftest_math(int kind, const float* in, float* out, int n, void* stream);
 
+/* Known-traffic kernels in the access patterns of the hot path, for calibrating what rocprofv3's FETCH_SIZE / WRITE_SIZE report
+ * on gfx950 (tools/pmc_probe.py --calibrate; no reference counterpart).  kind 0: streaming read of n float4 from `table`
+ * (16 B per lane); 1: streaming write of n float4; 2: gather of n 128-byte rows table[rows[i]][32] with two 16-byte loads per
+ * lane, four lanes per row -- how the decode tiles gather feature rows; 3: float-atomic scatter of n 128-byte rows, 32 lanes
+ * per row -- how the backward scatters row gradients.  `scratch`: >= 1024 floats (kinds 0 and 2).  ABI 6. */
+int psl_selftest_traffic(int kind, float* table, const int32_t* rows, float* scratch, long long n, void* stream);
+
 /* ---- timing helpers for the bench harness ---------------------------------- */
 int psl_sync(psl_ctx* ctx, void* stream);
 /* Kernel-class timing with HIP events recorded on the launch stream (for bench.py's roofline):

@@ -20,7 +20,7 @@ class PslError(RuntimeError):
 ABI_VERSION = 6     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
 #                     full-image pixel indices in psl_track_args, step0_params in psl_map_args; v4: psl_dedupe_count / psl_dedupe_blocks,
 #                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields;
-#                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math; v6: psl_comm_reserve, psl_pose_const_speed
+#                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math; v6: psl_comm_reserve, psl_pose_const_speed, psl_selftest_traffic
 EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 
 
@@ -110,6 +110,7 @@ _SIGS = {
     "psl_dedupe_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "psl_dedupe_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "psl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "psl_selftest_traffic": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "psl_pose_const_speed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "psl_comm_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "psl_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

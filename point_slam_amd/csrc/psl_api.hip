@@ -481,6 +481,71 @@ __global__ void k_selftest_math(int kind, const float* __restrict__ in, float* _
 }
 }  // namespace psl
 
+// ---- known-traffic kernels in the access patterns of the hot path: what FETCH_SIZE / WRITE_SIZE report is calibrated on THEM
+// (the microarchitecture guide calibrates only the 16 B/lane streaming read and says "calibrate on a known byte count in your
+// own access pattern before trusting an absolute").  Launch them under the same rocprofv3 --pmc passes as the probe.
+namespace psl {
+// kind 0: streaming read, 16 B per lane (weight fragments, saved activations): n float4 read, one float written per workgroup
+__global__ __launch_bounds__(256) void k_traffic_stream_read(const float4* __restrict__ src, float* __restrict__ dst, long long n) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dst + (blockIdx.x & 1023), acc);
+}
+// kind 1: streaming write, 16 B per lane (the forward's saved rows)
+__global__ __launch_bounds__(256) void k_traffic_stream_write(float4* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = make_float4((float)i, 1.f, 2.f, 3.f);
+}
+// kind 2: row gather as the decode tiles gather feature rows: lane (row slot = lane & 15, g = lane >> 4) reads 16 B at
+// rows[.] * 128 B + 16 g and + 64 + 16 g: four lanes cover one 128-byte row with two loads each; n rows
+__global__ __launch_bounds__(256) void k_traffic_row_gather(const float* __restrict__ table, const int* __restrict__ rows,
+                                                            float* __restrict__ dst, long long n) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  float acc = 0.f;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long b = wave * 16; b < n; b += nw * 16) {
+    const long long i = b + rl;
+    if (i < n) {
+      const float* row = table + (size_t)rows[i] * 32 + 4 * g;
+      const float4 v0 = *reinterpret_cast<const float4*>(row), v1 = *reinterpret_cast<const float4*>(row + 16);
+      acc += (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) atomicAdd(dst + (blockIdx.x & 1023), acc);
+}
+// kind 3: gradient scatter as scatter_interp_rows issues it: 32 consecutive lanes add one float each to ONE 128-byte row
+// (two rows per wave-instruction), float atomics; n rows
+__global__ __launch_bounds__(256) void k_traffic_row_scatter(float* __restrict__ table, const int* __restrict__ rows, long long n) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, c = lane & 31;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long b = wave * 2; b < n; b += nw * 2) {
+    const long long i = b + half;
+    if (i < n) atomicAdd(table + (size_t)rows[i] * 32 + c, 1.0f);
+  }
+}
+}  // namespace psl
+
+extern "C" int psl_selftest_traffic(int kind, float* table, const int32_t* rows, float* scratch, long long n, void* stream) {
+  // kind | 0x100: the same kernel on a slightly smaller grid, so that a profile keeps two uses of one kernel apart
+  const int blocks = (kind & 0x100) ? 4064 : 4096;
+  kind &= 0xff;
+  if (kind < 0 || kind > 3 || !table || n <= 0 || ((kind == 2 || kind == 3) && !rows) || ((kind == 0 || kind == 2) && !scratch)) {
+    set_error("psl_selftest_traffic: bad argument"); return PSL_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL(psl::k_traffic_stream_read, dim3(blocks), dim3(256), 0, s, (const float4*)table, scratch, n);
+  else if (kind == 1) hipLaunchKernelGGL(psl::k_traffic_stream_write, dim3(blocks), dim3(256), 0, s, (float4*)table, n);
+  else if (kind == 2) hipLaunchKernelGGL(psl::k_traffic_row_gather, dim3(blocks), dim3(256), 0, s, (const float*)table, rows, scratch, n);
+  else hipLaunchKernelGGL(psl::k_traffic_row_scatter, dim3(blocks), dim3(256), 0, s, table, rows, n);
+  PSL_LAUNCH_CHECK();
+  return PSL_OK;
+}
+
 extern "C" int psl_selftest_math(int kind, const float* in, float* out, int n, void* stream) {
   if (kind < 0 || kind > PSL_SELFTEST_ADAM_REPLAY || !in || !out || n < 0) { set_error("psl_selftest_math: bad argument"); return PSL_ERR_ARG; }
   if (n == 0) return PSL_OK;

@@ -14,6 +14,7 @@
 #   trace[:<args>[:<ENV=V,..>]]   rocprofv3 --kernel-trace --stats of bench.py <args> -> <tag>_kernel_trace_stats.csv (+ timeline)
 #   pmc:<mix>                     PMC passes (FETCH_SIZE / WRITE_SIZE / SQ groups) on tools/pmc_probe.py --mix <mix>
 #                                 -> <tag>_pmc_<mix>/*.csv and profiles-ready <tag>_pmc_traffic_<mix>.json
+#   pmccal                        FETCH_SIZE / WRITE_SIZE on kernels of known traffic (tools/pmc_probe.py --calibrate) -> <tag>_pmc_calibration.json
 #   x8[:<steps>[:<points>]]       bench.py --gpus 8 with all ranks sharing the one GPU (gloo) -> <tag>_bench_frame_parallel_x8_shared_gpu.json
 #   knn                           tools/knn_roofline.py -> <tag>_knn_roofline.json
 #   exchange                      tools/exchange_timing.py -> <tag>_exchange_timing.json
@@ -82,6 +83,14 @@ EOF
       fi
       cp $O/pmc_probe_meta.json $P/probe_meta.json
       python tools/pmc_traffic.py $P/fetch.csv $P/write.csv $O/${TAG}_pmc_traffic_$mix.json $COMMIT $P/probe_meta.json | python -c "import json,sys; d=json.load(sys.stdin); [print(k, v.get('bytes_per_launch')) for k,v in d.items() if k!='_meta']" ;;
+    pmccal)
+      P=$O/${TAG}_pmccal; mkdir -p $P
+      for c in FETCH_SIZE WRITE_SIZE; do
+        n=$(echo $c | tr A-Z a-z | cut -d_ -f1)
+        timeout 300 rocprofv3 --pmc $c -d $P -o $n -- python tools/pmc_probe.py --calibrate > $P/$n.log 2>&1
+        python tools/rocpd_pmc.py $P/${n}_results.db > $P/$n.csv 2>&1; rm -f $P/${n}_results.db
+      done
+      python tools/pmc_calibration.py $P/fetch.csv $P/write.csv $O/pmc_calibration_known.json $O/${TAG}_pmc_calibration.json $COMMIT | grep -E "over_known|\"[a-z_0-9A-Z /-]*\": \{" | head -30 ;;
     x8)
       # N = 8 ranks on the ONE GPU over gloo (RCCL refuses two ranks per device): launcher, rank-order merge, ragged / empty
       # blocks and the replica check at N = 8 -- functional evidence, not a scaling number
