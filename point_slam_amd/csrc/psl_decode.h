@@ -109,6 +109,150 @@ __device__ __forceinline__ float4 ray_cotangent(const DecodeArgs& a, const RayFu
   return out;
 }
 
+// ---- the TRACKER's ray stage inside the pose-gradient decode backward (psl_track_iters, batches <= 1024 rays) -------------
+// k_track_mid (psl_slam.hip) -- compositing, tracker loss with its 10 x mean mask (Tracker.py:159-180), lowest-loss pose,
+// compositing backward -- was one more single-workgroup launch between the two decode kernels: 7.9 us + a launch gap, twenty
+// times per frame, for ~200 instructions per ray.  As with the mapper's RayFuse the thread that owns a sample evaluates the
+// sample's ray itself; what the tracker adds is the mask threshold 10 * mean(e) over ALL active rays: every wavefront that
+// needs it composites all rays once (<= 16 per lane, the 16 KB of `raw` are L2-resident) and reduces with shuffles -- the
+// same order in every wavefront of every workgroup, so that all tiles (and both roles) apply one and the same threshold.
+// Same per-ray expressions and order as k_track_mid; the sums over rays (mean, loss) are taken in a different order (double).
+struct TrackFuse {
+  const int* active; const float* gt_color; float coef, w_color; int handle_dynamic, use_color, n_rays;
+  float *depth, *var, *rgb; unsigned char* valid;
+  const float* cam_tensor; float* best; float* loss_out;
+  int on;
+};
+struct RayComp { float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S]; float W, d, v, m0, m1, m2, gt; int nhas; };
+
+__device__ __forceinline__ float signf0_(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// k_composite_fwd of ray r (common.py:298-336), as k_track_mid evaluates it
+__device__ __forceinline__ void track_composite(const DecodeArgs& a, float coef, int r, RayComp& c) {
+  const float4* raw = reinterpret_cast<const float4*>(a.ws.raw);
+  c.gt = a.depth[r];
+  float T = 1.0f, wsum = 0.f;
+  c.nhas = 0;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float4 q = raw[r * S + s];
+    c.z[s] = sample_z(c.gt, s, a.near_s, a.far_s);
+    c.al[s] = sigmoidf(coef * q.w);
+    c.Tt[s] = T;
+    c.w[s] = c.al[s] * T;
+    T = T * (1.0f - c.al[s] + 1e-10f);
+    wsum += c.w[s];
+    c.c0[s] = q.x; c.c1[s] = q.y; c.c2[s] = q.z;
+    c.nhas += (a.ws.cnt[r * S + s] >= a.min_nn) ? 1 : 0;
+  }
+  c.W = wsum + 1e-10f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ad = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { a0 += c.w[s] * c.c0[s]; a1 += c.w[s] * c.c1[s]; a2 += c.w[s] * c.c2[s]; ad += c.w[s] * c.z[s]; }
+  c.d = ad / c.W;
+  c.v = 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) { const float tmp = c.z[s] - c.d; c.v += c.w[s] * tmp * tmp; }
+  c.m0 = a0 / c.W; c.m1 = a1 / c.W; c.m2 = a2 / c.W;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// 10 * mean(e) over the active rays (Tracker.py:165), one whole wavefront; identical in every wavefront that calls it
+__device__ __forceinline__ float track_threshold(const DecodeArgs& a, const TrackFuse& tf) {
+  const int lane = threadIdx.x & 63;
+  double se = 0.0, sc = 0.0;
+  for (int r = lane; r < tf.n_rays; r += 64) {
+    if (tf.active[r] == 0) continue;
+    RayComp c;
+    track_composite(a, tf.coef, r, c);
+    float e = fabsf(c.gt - c.d);
+    if (tf.handle_dynamic) e = e / sqrtf(c.v + 1e-10f);
+    se += (double)e; sc += 1.0;
+  }
+  se = wave_sum_d(se); sc = wave_sum_d(sc);
+  return (sc > 0.0) ? 10.0f * (float)(se / sc) : 0.f;
+}
+
+// cotangent of raw[p]; owner (first sample of its ray, colour role only): the ray's render outputs
+__device__ __forceinline__ float4 track_cotangent(const DecodeArgs& a, const TrackFuse& tf, int p, float thr, bool owner_writes) {
+  const int r = p / S, sj = p - r * S;
+  RayComp c;
+  track_composite(a, tf.coef, r, c);
+  if (owner_writes && sj == 0) {
+    tf.depth[r] = c.d; tf.var[r] = c.v; tf.rgb[r * 3] = c.m0; tf.rgb[r * 3 + 1] = c.m1; tf.rgb[r * 3 + 2] = c.m2;
+    tf.valid[r] = c.nhas >= (S / 2 + 1) ? 1 : 0;
+  }
+  float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  if (tf.active[r] != 0) {
+    const float inv = 1.0f / sqrtf(c.v + 1e-10f);
+    const float diff = fabsf(c.gt - c.d);
+    const float tmp = tf.handle_dynamic ? diff / sqrtf(c.v + 1e-10f) : diff;
+    const bool m = (tmp < thr) && (c.gt > 0.f) && (c.d == c.d) && (c.v == c.v);
+    if (m) {
+      const float e = diff / sqrtf(c.v + 1e-10f);
+      if (e <= 1e3f) gdp = signf0_(c.d - c.gt) * inv;
+      if (tf.use_color) {
+        const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
+        g0 = tf.w_color * signf0_(c.m0 - q0); g1 = tf.w_color * signf0_(c.m1 - q1); g2 = tf.w_color * signf0_(c.m2 - q2);
+      }
+    }
+  }
+  // k_composite_bwd with g_var = 0
+  float gw[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const float dz = c.z[s] - c.d;
+    gw[s] = (gdp * dz + g0 * (c.c0[s] - c.m0) + g1 * (c.c1[s] - c.m1) + g2 * (c.c2[s] - c.m2)) / c.W;
+  }
+  float suffix = 0.f;
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = S - 1; s >= 0; --s) {
+    const float ga = gw[s] * c.Tt[s] - suffix / (1.0f - c.al[s] + 1e-10f);
+    const float gocc = ga * tf.coef * c.al[s] * (1.0f - c.al[s]);
+    const float ws = c.w[s] / c.W;
+    if (s == sj) out = make_float4(g0 * ws, g1 * ws, g2 * ws, gocc);
+    suffix += gw[s] * c.w[s];
+  }
+  return out;
+}
+
+// loss of the iteration and the lowest-loss pose (Tracker.py:176-180,347-350): ONE wavefront of the launch
+__device__ __forceinline__ void track_loss_and_best(const DecodeArgs& a, const TrackFuse& tf, float thr) {
+  const int lane = threadIdx.x & 63;
+  double lg = 0.0, lc = 0.0, nact = 0.0;
+  for (int r = lane; r < tf.n_rays; r += 64) {
+    if (tf.active[r] == 0) continue;
+    nact += 1.0;
+    RayComp c;
+    track_composite(a, tf.coef, r, c);
+    const float diff = fabsf(c.gt - c.d);
+    const float tmp = tf.handle_dynamic ? diff / sqrtf(c.v + 1e-10f) : diff;
+    const bool m = (tmp < thr) && (c.gt > 0.f) && (c.d == c.d) && (c.v == c.v);
+    if (m) {
+      const float e = diff / sqrtf(c.v + 1e-10f);
+      lg += (double)fminf(fmaxf(e, 0.f), 1e3f);
+      const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
+      lc += (double)fabsf(q0 - c.m0) + (double)fabsf(q1 - c.m1) + (double)fabsf(q2 - c.m2);
+    }
+  }
+  lg = wave_sum_d(lg); lc = wave_sum_d(lc); nact = wave_sum_d(nact);
+  if (lane == 0) {
+    const double L = tf.use_color ? lg + (double)tf.w_color * lc : lg;
+    tf.loss_out[0] = (float)L; tf.loss_out[1] = (float)lg; tf.loss_out[2] = (float)lc; tf.loss_out[3] = (float)nact;
+    if ((float)L < tf.best[7]) {
+      tf.best[7] = (float)L;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) tf.best[j] = tf.cam_tensor[j];
+    }
+  }
+}
+
 // work list of the lazy Adam (as adam_worklist_role, psl_ray.hip), one int4 of neighbour indices per lane; wave-level appends
 __device__ __forceinline__ void worklist_role_wave(const AdamWorklist& wl, int i) {
   const int lane = threadIdx.x & 63;

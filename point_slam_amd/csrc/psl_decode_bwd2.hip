@@ -233,14 +233,20 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
 //    compiler otherwise hoists all twelve loads: 48 registers);
 //  * the Fourier epilogue consumes dE before the interpolation-weight epilogue builds its per-neighbour arrays.
 __device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0,
-                                                  ScatterLds& sl) {
+                                                  ScatterLds& sl, const TrackFuse& tf) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
   const bool live = p0 + rl < a.P;
   const float* __restrict__ M = a.master;
   const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
   const bool has = live && a.ws.cnt[p] >= a.min_nn;
-  const float docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  float docc;
+  if (tf.on) {     // the tracker's ray stage inside this kernel: threshold over all rays, then the ray of this lane's sample
+    const float thr = track_threshold(a, tf);
+    docc = live ? track_cotangent(a, tf, p, thr, false).w : 0.f;
+  } else {
+    docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
+  }
   // G = d_occ * w_out (output_linear.weight [1][32]), channel 16 nt + 4 g + r
   f32x4 G[2], dcg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -397,7 +403,7 @@ __device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd
 // ------------------------------------------------------------------------------------------------ colour role
 template <bool PTSG>
 __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0,
-                                               const RayFuse& rf) {
+                                               const RayFuse& rf, const TrackFuse& tf) {
   using L = Bwd2Lds;
   int* sI = (int*)(smem + L::oI);           // [16][8]
   float* sW = smem + L::oW;                 // [16][8] normalised weights
@@ -424,6 +430,15 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   PSL_STAMP(0);
   const float* sWn = smem + L::oWn;
   if (relpos) nbr_stage_dma_b(WB, smem + L::oWn, wave, lane);      // F_theta's backward weights -> LDS; the loads fly during phase 0
+  // the tracker's ray stage inside this kernel (TrackFuse): the wavefront of the d(logits) threads (t = 128..143: wave 2) needs
+  // the mask threshold; wave 3 of workgroup 0 -- idle in phase 0 but for 96 stores -- keeps the iteration's loss and best pose
+  float thr_track = 0.f;
+  if constexpr (PTSG) {
+    if (tf.on && (wave == 2 || (wave == 3 && blockIdx.x == 0))) {
+      thr_track = track_threshold(a, tf);
+      if (wave == 3) track_loss_and_best(a, tf, thr_track);
+    }
+  }
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -464,7 +479,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     if (p < a.P) {
       // psl_map_iters without per-frame exposure: the ray stage (compositing, loss, compositing backward) of this sample's ray
       // runs here instead of in a launch of its own between the two decode kernels
-      const float4 dr = rf.on ? ray_cotangent(a, rf, p, true, lg, lc, lcnt) : reinterpret_cast<const float4*>(a.ws.d_raw)[p];
+      float4 dr;
+      if (PTSG && tf.on) dr = track_cotangent(a, tf, p, thr_track, true);
+      else dr = rf.on ? ray_cotangent(a, rf, p, true, lg, lc, lcnt) : reinterpret_cast<const float4*>(a.ws.d_raw)[p];
       const float4 rw = reinterpret_cast<const float4*>(a.ws.raw)[p];
       d0 = dr.x; d1 = dr.y; d2 = dr.z;
       if (!(a.flags & PSL_NO_SIGMOID)) { d0 *= rw.x * (1.f - rw.x); d1 *= rw.y * (1.f - rw.y); d2 *= rw.z * (1.f - rw.z); }
@@ -864,7 +881,7 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 //  wl_block0 on build the work list of the iteration's lazy Adam, which the ray kernel used to carry)
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
-                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0) {
+                                                                                            RayFuse rf, AdamWorklist wl, int wl_block0, TrackFuse tf) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x >= wl_block0) {
     worklist_role_wave(wl, ((int)blockIdx.x - wl_block0) * (int)blockDim.x + (int)threadIdx.x);
@@ -875,10 +892,10 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(
   const bool is_color = COLOR && b < color_tiles;
   const int tile = is_color ? b : b - color_tiles;
   if (is_color) {
-    color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf);
+    color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf, tf);
   } else {
     if (threadIdx.x >= 64) return;
-    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem));
+    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), tf);
     else geo_tile_bwd<false>(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
   }
   bt.done(a);
@@ -914,14 +931,16 @@ int launch_decode_bwd2(psl_ctx* ctx, const DecodeArgs& a_in, const psl_render_gr
     if (ctx->ray_wl) wl = *(const AdamWorklist*)ctx->ray_wl;
     if (wl.I_a && wl.n4 > 0) wl_blocks = ((wl.I_b ? 2 : 1) * wl.n4 + WG - 1) / WG;
   }
+  TrackFuse tf{};
+  if (ctx->track_fuse && color && ptsg) tf = *(const TrackFuse*)ctx->track_fuse;
   const int grid_c = 2 * tiles + wl_blocks;
   { int rc = blk_trace_begin(a, color ? grid_c : tiles, s); if (rc) return rc; }
   if (color) {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
-    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, true>), dim3(2 * tiles), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, tf);
+    else PSL_KLAUNCH((k_decode_bwd2<false, true>), dim3(grid_c), dim3(WG), lds, s, a, o, WB, tiles, rf, wl, 2 * tiles, tf);
   } else {
-    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
-    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles);
+    if (ptsg) PSL_KLAUNCH((k_decode_bwd2<true, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, tf);
+    else PSL_KLAUNCH((k_decode_bwd2<false, false>), dim3(tiles), dim3(64), sizeof(ScatterLds), s, a, o, WB, 0, rf, wl, tiles, tf);
   }
   PSL_LAUNCH_CHECK();
   { int rc = blk_trace_end(a, ptsg ? "bwd2_ptsg" : "bwd2", color ? grid_c : tiles, color ? tiles : 0, color ? WG : 64); if (rc) return rc; }

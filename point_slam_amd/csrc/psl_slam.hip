@@ -790,7 +790,7 @@ using namespace psl;
 namespace psl {
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
-int g_track_fused = env_flag("PSL_TRACK_FUSED", 1);
+int g_track_fused = env_flag("PSL_TRACK_FUSED", 2);   // 2: k_track_mid inside the decode backward (TrackFuse); 1: its own launch; 0: the ten-launch iteration
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
@@ -928,9 +928,14 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   }
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
   const bool fused = n <= 1024 && g_track_fused != 0;
-  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; } } fused_guard{ctx};
+  // ... and since round 5 k_track_mid's work runs inside the decode backward (TrackFuse, psl_decode.h): an iteration is
+  // k_track_pre, k-NN, decode forward, decode backward.  PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): the launch
+  // of its own, as in rounds 3-4.  (Not with per-frame exposure: no shipped config tracks <= 1024 pixels with it.)
+  const bool mid_in_bwd = fused && g_track_fused >= 2 && !ex;
+  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
+  if (mid_in_bwd) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
     // bias corrections of Adam step `step0 + it` with the formulas of adam_bias(), evaluated here instead of by one thread
@@ -959,7 +964,12 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     int rc = render_fwd_impl(ctx, &ra, s, it == 0);
     if (rc) return rc;
     float* lo = t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch;
-    if (fused) {
+    TrackFuse tf{};
+    if (mid_in_bwd) {
+      tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
+                     t->cam_tensor, t->best_out, lo, 1};
+      ctx->track_fuse = &tf;
+    } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
       PSL_KLAUNCH(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
                          ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, t->sigmoid_coef, t->w_color, t->handle_dynamic,
@@ -970,6 +980,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     }
     PSL_LAUNCH_CHECK();
     rc = render_bwd_impl(ctx, &ra, &rg, s);
+    ctx->track_fuse = nullptr;
     if (rc) return rc;
     if (!fused)
       hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
