@@ -122,6 +122,7 @@ struct TrackFuse {
   float *depth, *var, *rgb; unsigned char* valid;
   const float* cam_tensor; float* best; float* loss_out;
   int on;
+  const float* thr_in;     // batches > 1024 rays: threshold, loss and best pose come from k_track_stats (one launch); null: in here
 };
 struct RayComp { float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S]; float W, d, v, m0, m1, m2, gt; int nhas; };
 
@@ -162,20 +163,75 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// 10 * mean(e) over the active rays (Tracker.py:165), one whole wavefront; identical in every wavefront that calls it
-__device__ __forceinline__ float track_threshold(const DecodeArgs& a, const TrackFuse& tf) {
-  const int lane = threadIdx.x & 63;
-  double se = 0.0, sc = 0.0;
-  for (int r = lane; r < tf.n_rays; r += 64) {
-    if (tf.active[r] == 0) continue;
-    RayComp c;
-    track_composite(a, tf.coef, r, c);
-    float e = fabsf(c.gt - c.d);
-    if (tf.handle_dynamic) e = e / sqrtf(c.v + 1e-10f);
-    se += (double)e; sc += 1.0;
+// 10 * mean(e) over the active rays (Tracker.py:165), by ALL 512 threads of a workgroup (both roles call it on entry: the
+// seven wavefronts of a geometry-role workgroup that exit at once otherwise lend a hand first): thread t composites rays t and
+// t + 512 -- every load of the pass in flight at once, one cache round trip instead of n / 64 serial ones in one wavefront
+// (measured: with one wavefront per tile doing the pass the saved launch was paid back in full) --, 64-ray chunks are summed
+// by wave shuffles, the chunk sums in chunk order by every thread: the same arithmetic in every workgroup of either role, so
+// that all tiles apply ONE threshold.  LOSS (workgroup 0 of the colour role): the iteration's loss and the lowest-loss pose
+// (Tracker.py:176-180,347-350) from the same composites.  n_rays <= 1024.  red: >= 128 floats of LDS nobody else touches yet.
+__device__ __forceinline__ float track_threshold_block(const DecodeArgs& a, const TrackFuse& tf, float* red, bool loss) {
+  double* part = reinterpret_cast<double*>(red);        // [16 chunks][2] (sum e, count), then [16][2] (loss geo, colour)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = tf.n_rays;
+  float gt[2], d[2], v[2], m0[2], m1[2], m2[2];
+  bool act[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = t + 512 * j;
+    act[j] = r < n && tf.active[min(r, n - 1)] != 0;
+    gt[j] = d[j] = v[j] = m0[j] = m1[j] = m2[j] = 0.f;
+    if (r < n) {
+      RayComp c;
+      track_composite(a, tf.coef, r, c);
+      gt[j] = c.gt; d[j] = c.d; v[j] = c.v; m0[j] = c.m0; m1[j] = c.m1; m2[j] = c.m2;
+    }
+    double se = 0.0, sc = 0.0;
+    if (act[j]) {
+      float e = fabsf(gt[j] - d[j]);
+      if (tf.handle_dynamic) e = e / sqrtf(v[j] + 1e-10f);
+      se = (double)e; sc = 1.0;
+    }
+    se = wave_sum_d(se); sc = wave_sum_d(sc);
+    if (lane == 0) { part[2 * (wave + 8 * j)] = se; part[2 * (wave + 8 * j) + 1] = sc; }
   }
-  se = wave_sum_d(se); sc = wave_sum_d(sc);
-  return (sc > 0.0) ? 10.0f * (float)(se / sc) : 0.f;
+  __syncthreads();
+  double tot = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { tot += part[2 * c]; cnt += part[2 * c + 1]; }
+  const float thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f;
+  if (loss) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = t + 512 * j;
+      double lg = 0.0, lc = 0.0;
+      if (act[j]) {
+        const float diff = fabsf(gt[j] - d[j]);
+        const float tmp = tf.handle_dynamic ? diff / sqrtf(v[j] + 1e-10f) : diff;
+        if ((tmp < thr) && (gt[j] > 0.f) && (d[j] == d[j]) && (v[j] == v[j])) {
+          const float e = diff / sqrtf(v[j] + 1e-10f);
+          lg = (double)fminf(fmaxf(e, 0.f), 1e3f);
+          const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
+          lc = (double)fabsf(q0 - m0[j]) + (double)fabsf(q1 - m1[j]) + (double)fabsf(q2 - m2[j]);
+        }
+      }
+      lg = wave_sum_d(lg); lc = wave_sum_d(lc);
+      if (lane == 0) { part[32 + 2 * (wave + 8 * j)] = lg; part[32 + 2 * (wave + 8 * j) + 1] = lc; }
+    }
+    __syncthreads();
+    if (t == 0) {
+      double Lg = 0.0, Lc = 0.0;
+      for (int c = 0; c < 16; ++c) { Lg += part[32 + 2 * c]; Lc += part[32 + 2 * c + 1]; }
+      const double L = tf.use_color ? Lg + (double)tf.w_color * Lc : Lg;
+      tf.loss_out[0] = (float)L; tf.loss_out[1] = (float)Lg; tf.loss_out[2] = (float)Lc; tf.loss_out[3] = (float)cnt;
+      if ((float)L < tf.best[7]) {
+        tf.best[7] = (float)L;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) tf.best[j] = tf.cam_tensor[j];
+      }
+    }
+  }
+  __syncthreads();          // the scratch may be reused from here on
+  return thr;
 }
 
 // cotangent of raw[p]; owner (first sample of its ray, colour role only): the ray's render outputs
@@ -220,37 +276,6 @@ __device__ __forceinline__ float4 track_cotangent(const DecodeArgs& a, const Tra
     suffix += gw[s] * c.w[s];
   }
   return out;
-}
-
-// loss of the iteration and the lowest-loss pose (Tracker.py:176-180,347-350): ONE wavefront of the launch
-__device__ __forceinline__ void track_loss_and_best(const DecodeArgs& a, const TrackFuse& tf, float thr) {
-  const int lane = threadIdx.x & 63;
-  double lg = 0.0, lc = 0.0, nact = 0.0;
-  for (int r = lane; r < tf.n_rays; r += 64) {
-    if (tf.active[r] == 0) continue;
-    nact += 1.0;
-    RayComp c;
-    track_composite(a, tf.coef, r, c);
-    const float diff = fabsf(c.gt - c.d);
-    const float tmp = tf.handle_dynamic ? diff / sqrtf(c.v + 1e-10f) : diff;
-    const bool m = (tmp < thr) && (c.gt > 0.f) && (c.d == c.d) && (c.v == c.v);
-    if (m) {
-      const float e = diff / sqrtf(c.v + 1e-10f);
-      lg += (double)fminf(fmaxf(e, 0.f), 1e3f);
-      const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
-      lc += (double)fabsf(q0 - c.m0) + (double)fabsf(q1 - c.m1) + (double)fabsf(q2 - c.m2);
-    }
-  }
-  lg = wave_sum_d(lg); lc = wave_sum_d(lc); nact = wave_sum_d(nact);
-  if (lane == 0) {
-    const double L = tf.use_color ? lg + (double)tf.w_color * lc : lg;
-    tf.loss_out[0] = (float)L; tf.loss_out[1] = (float)lg; tf.loss_out[2] = (float)lc; tf.loss_out[3] = (float)nact;
-    if ((float)L < tf.best[7]) {
-      tf.best[7] = (float)L;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) tf.best[j] = tf.cam_tensor[j];
-    }
-  }
 }
 
 // work list of the lazy Adam (as adam_worklist_role, psl_ray.hip), one int4 of neighbour indices per lane; wave-level appends

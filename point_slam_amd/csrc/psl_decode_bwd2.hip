@@ -233,7 +233,7 @@ __device__ __forceinline__ void geo_tile_bwd(const DecodeArgs& a, const Bwd2Out&
 //    compiler otherwise hoists all twelve loads: 48 registers);
 //  * the Fourier epilogue consumes dE before the interpolation-weight epilogue builds its per-neighbour arrays.
 __device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, int p0,
-                                                  ScatterLds& sl, const TrackFuse& tf) {
+                                                  ScatterLds& sl, const TrackFuse& tf, float thr_track) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p = min(p0 + rl, a.P - 1);
   const bool live = p0 + rl < a.P;
@@ -241,9 +241,8 @@ __device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd
   const bool featg = (a.flags & PSL_FEAT_GRAD) != 0;
   const bool has = live && a.ws.cnt[p] >= a.min_nn;
   float docc;
-  if (tf.on) {     // the tracker's ray stage inside this kernel: threshold over all rays, then the ray of this lane's sample
-    const float thr = track_threshold(a, tf);
-    docc = live ? track_cotangent(a, tf, p, thr, false).w : 0.f;
+  if (tf.on) {     // the tracker's ray stage inside this kernel: the ray of this lane's sample under the launch-wide threshold
+    docc = live ? track_cotangent(a, tf, p, thr_track, false).w : 0.f;
   } else {
     docc = live ? a.ws.d_raw[(size_t)p * 4 + 3] : 0.f;
   }
@@ -403,7 +402,7 @@ __device__ __forceinline__ void geo_tile_bwd_ptsg(const DecodeArgs& a, const Bwd
 // ------------------------------------------------------------------------------------------------ colour role
 template <bool PTSG>
 __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Out& o, const float* __restrict__ WB, float* smem, int p0,
-                                               const RayFuse& rf, const TrackFuse& tf) {
+                                               const RayFuse& rf, const TrackFuse& tf, float thr_track) {
   using L = Bwd2Lds;
   int* sI = (int*)(smem + L::oI);           // [16][8]
   float* sW = smem + L::oW;                 // [16][8] normalised weights
@@ -430,15 +429,6 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
   PSL_STAMP(0);
   const float* sWn = smem + L::oWn;
   if (relpos) nbr_stage_dma_b(WB, smem + L::oWn, wave, lane);      // F_theta's backward weights -> LDS; the loads fly during phase 0
-  // the tracker's ray stage inside this kernel (TrackFuse): the wavefront of the d(logits) threads (t = 128..143: wave 2) needs
-  // the mask threshold; wave 3 of workgroup 0 -- idle in phase 0 but for 96 stores -- keeps the iteration's loss and best pose
-  float thr_track = 0.f;
-  if constexpr (PTSG) {
-    if (tf.on && (wave == 2 || (wave == 3 && blockIdx.x == 0))) {
-      thr_track = track_threshold(a, tf);
-      if (wave == 3) track_loss_and_best(a, tf, thr_track);
-    }
-  }
   // ---------------------------------------------------------------- phase 0: per-sample state, d(logits)
   if (t < TILE * K) {
     const int s = t >> 3, k = t & 7;
@@ -891,11 +881,17 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(
   const int b = (int)blockIdx.x;      // workgroup -> (role, tile) as in the forward kernel
   const bool is_color = COLOR && b < color_tiles;
   const int tile = is_color ? b : b - color_tiles;
+  // the tracker's ray stage inside this kernel (TrackFuse): the launch-wide mask threshold first, by every thread of the
+  // workgroup -- in the geometry role too, whose other seven wavefronts then leave
+  float thr_track = 0.f;
+  if constexpr (PTSG && COLOR) {
+    if (tf.on) thr_track = tf.thr_in ? *tf.thr_in : track_threshold_block(a, tf, smem + Bwd2Lds::oDZ, is_color && b == 0);
+  }
   if (is_color) {
-    color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf, tf);
+    color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf, tf, thr_track);
   } else {
     if (threadIdx.x >= 64) return;
-    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), tf);
+    if constexpr (PTSG) geo_tile_bwd_ptsg(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), tf, thr_track);
     else geo_tile_bwd<false>(a, o, WB, tile * TILE, *reinterpret_cast<ScatterLds*>(smem), &rf);
   }
   bt.done(a);

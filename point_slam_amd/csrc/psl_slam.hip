@@ -371,12 +371,12 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
                                                     const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx,
                                                     AdamBias bias) {
   __shared__ float red[16][12];
-  const int r = threadIdx.x;
+  // one ray per thread up to 1 024 rays (the base mix: 200); larger batches (Replica 1 500, TUM / ScanNet 5 000) stride
   if (do_step) {
     float acc[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) acc[j] = 0.f;
-    if (r < n) {
+    for (int r = threadIdx.x; r < n; r += blockDim.x) {
       // g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (k_ray_grad)
       float go[3] = {0.f, 0.f, 0.f}, gd3[3] = {0.f, 0.f, 0.f};
       const float gt = b.gd[r];
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
     __syncthreads();
     if (threadIdx.x == 0) {
       float G[3][3], gT[3];
-      const int nw = (n + 63) >> 6;
+      const int nw = min((n + 63) >> 6, 16);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -421,9 +421,63 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
     __syncthreads();          // the new pose is visible to every thread of the workgroup
   }
   if (!do_setup) return;
-  if (r < n) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx, cam_tensor, b);
+  for (int r = threadIdx.x; r < n; r += blockDim.x) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx, cam_tensor, b);
   __syncthreads();
   depth_inlier_block(b.gd, b.active, n);
+}
+
+// Batches of more than 1 024 rays (Replica 1 500, TUM / ScanNet 5 000): the reductions over ALL rays -- the 10 x mean mask
+// threshold (Tracker.py:165), the iteration's loss, the lowest-loss pose (:176-180,347-350) -- in one single-workgroup launch
+// between the two decode kernels; compositing backward runs inside the decode backward (TrackFuse with thr_in), compositing
+// forward here (two passes: the threshold needs every ray's error before any ray's mask).  Replaces k_composite_fwd,
+// k_tracker_loss and k_composite_bwd (three launches) of rounds 1-4.
+__global__ __launch_bounds__(1024) void k_track_stats(DecodeArgs a, TrackFuse tf, float* __restrict__ thr_out, float* __restrict__ zero64) {
+  __shared__ double lds[16];
+  __shared__ float s_thr;
+  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;   // accumulators of the decode backward that follows
+  const int n = tf.n_rays;
+  double se = 0.0, sc = 0.0;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    RayComp c;
+    track_composite(a, tf.coef, r, c);
+    tf.depth[r] = c.d; tf.var[r] = c.v; tf.rgb[r * 3] = c.m0; tf.rgb[r * 3 + 1] = c.m1; tf.rgb[r * 3 + 2] = c.m2;
+    tf.valid[r] = c.nhas >= (S / 2 + 1) ? 1 : 0;
+    if (tf.active[r] != 0) {
+      float e = fabsf(c.gt - c.d);
+      if (tf.handle_dynamic) e = e / sqrtf(c.v + 1e-10f);
+      se += (double)e; sc += 1.0;
+    }
+  }
+  const double tot = block_sum_d(se, lds);
+  const double nact = block_sum_d(sc, lds);
+  if (threadIdx.x == 0) { s_thr = (nact > 0.0) ? 10.0f * (float)(tot / nact) : 0.f; *thr_out = s_thr; }
+  __syncthreads();
+  const float thr = s_thr;
+  double lg = 0.0, lc = 0.0;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) {
+    if (tf.active[r] == 0) continue;
+    const float d = tf.depth[r], v = tf.var[r], gt = a.depth[r];      // this thread's own stores of the first pass
+    const float diff = fabsf(gt - d);
+    const float tmp = tf.handle_dynamic ? diff / sqrtf(v + 1e-10f) : diff;
+    const bool m = (tmp < thr) && (gt > 0.f) && (d == d) && (v == v);
+    if (m) {
+      const float e = diff / sqrtf(v + 1e-10f);
+      lg += (double)fminf(fmaxf(e, 0.f), 1e3f);
+      const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
+      lc += (double)fabsf(q0 - tf.rgb[r * 3]) + (double)fabsf(q1 - tf.rgb[r * 3 + 1]) + (double)fabsf(q2 - tf.rgb[r * 3 + 2]);
+    }
+  }
+  const double Lg = block_sum_d(lg, lds);
+  const double Lc = block_sum_d(lc, lds);
+  if (threadIdx.x == 0) {
+    const double L = tf.use_color ? Lg + (double)tf.w_color * Lc : Lg;
+    tf.loss_out[0] = (float)L; tf.loss_out[1] = (float)Lg; tf.loss_out[2] = (float)Lc; tf.loss_out[3] = (float)nact;
+    if ((float)L < tf.best[7]) {
+      tf.best[7] = (float)L;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) tf.best[j] = tf.cam_tensor[j];
+    }
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_track_mid(const float4* __restrict__ raw, const int* __restrict__ cnt, RayBufs b, int n,
@@ -927,15 +981,22 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     ra.flags |= PSL_HAS_AFFINE; ra.exposure_affine = ex_aff; rg.g_exposure_affine = ex_g;
   }
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
-  const bool fused = n <= 1024 && g_track_fused != 0;
   // ... and since round 5 k_track_mid's work runs inside the decode backward (TrackFuse, psl_decode.h): an iteration is
-  // k_track_pre, k-NN, decode forward, decode backward.  PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): the launch
-  // of its own, as in rounds 3-4.  (Not with per-frame exposure: no shipped config tracks <= 1024 pixels with it.)
-  const bool mid_in_bwd = fused && g_track_fused >= 2 && !ex;
+  // k_track_pre, k-NN, decode forward, decode backward -- four launches.  Larger batches (Replica 1 500 px, TUM / ScanNet
+  // 5 000 px) take the same route with the single-workgroup kernels striding over the rays and the reductions over all rays
+  // in k_track_stats between the decode kernels: five launches instead of the ten of rounds 1-4 (ray set-up, depth mask,
+  // k-NN, forward, compositing, loss, compositing backward, backward, ray gradient, pose step).
+  // PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): rounds 3-4 (pre / mid launches up to 1 024 rays, ten beyond); 0: ten.
+  const bool fused = g_track_fused >= 2 || (n <= 1024 && g_track_fused != 0);
+  const bool mid_in_bwd = fused && g_track_fused >= 2;
+  const bool stats_launch = mid_in_bwd && n > 1024;
   struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
-  if (mid_in_bwd) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
+  if (mid_in_bwd && !stats_launch) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
+  DecodeArgs da{};          // what the ray stage reads of the decode's arguments (track_composite)
+  da.ws = rw; da.depth = b.gd; da.near_s = ctx->cfg.near_end_surface; da.far_s = ctx->cfg.far_end_surface; da.min_nn = ctx->cfg.min_nn_num;
+  float* thr_dev = loss_scratch + 16;
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
     // bias corrections of Adam step `step0 + it` with the formulas of adam_bias(), evaluated here instead of by one thread
@@ -967,7 +1028,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     TrackFuse tf{};
     if (mid_in_bwd) {
       tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
-                     t->cam_tensor, t->best_out, lo, 1};
+                     t->cam_tensor, t->best_out, lo, 1, stats_launch ? thr_dev : nullptr};
+      if (stats_launch) {
+        ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
+        PSL_KLAUNCH(k_track_stats, dim3(1), dim3(1024), 0, s, da, tf, thr_dev, ctx->d_small);
+      }
       ctx->track_fuse = &tf;
     } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);

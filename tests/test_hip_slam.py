@@ -114,6 +114,57 @@ def test_track_native_matches_dropin():
     assert dc < max(0.25 * step, 4 * self_noise) and db < max(0.25 * step, 4 * self_noise)
 
 
+@pytest.mark.parametrize("n_pix,exposure", [(200, False), (1000, False), (1500, False), (5000, False), (5000, True)])
+def test_track_launch_structures_agree(n_pix, exposure):
+    """psl_track_iters under its three launch structures (psl_debug_option("track_fused", v)): 0 = the ten launches of rounds
+    1-2 (ray set-up, depth mask, k-NN, forward, compositing, loss, compositing backward, backward, ray gradient, pose step),
+    1 = pre / mid launches up to 1 024 rays (rounds 3-4), 2 = the ray stage inside the decode backward (TrackFuse; beyond 1 024
+    rays with the reductions over all rays in k_track_stats) -- the default.  Same draws, eight iterations: the per-iteration
+    losses agree to float rounding of the sums over rays, the poses after eight Adam steps to a fraction of one step; the
+    batch sizes of every shipped config (200 base, 1 500 Replica, 5 000 TUM / ScanNet, the last with per-frame exposure)."""
+    from point_slam_amd import _lib
+    from point_slam_amd.slam import camera_tensor_from_c2w
+    from tests.helpers import cfg_variant
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    if exposure:
+        cfg = cfg_variant("scannet")
+        cfg["tracking"]["sample_with_color_grad"] = False
+    cam0 = camera_tensor_from_c2w(frames[1].c2w) + torch.tensor([0.002, -0.001, 0.0015, 0.001, 0.01, -0.008, 0.006])
+    L = _lib.lib()
+    outs, draws = {}, None
+    try:
+        for ver in (0, 1, 2):
+            _lib.check(L.psl_debug_option(b"track_fused", ver))
+            from point_slam_amd.decoders import PointDecoders
+            from point_slam_amd.slam import HipSLAM
+            dec = PointDecoders(cfg).load_reference_state(load_decoders("scannet" if exposure else "replica"))
+            s = HipSLAM(cfg, cam, device="cuda:0", max_points=400000, engine="native", decoders=dec)
+            s.seed_points(pts)
+            if exposure:
+                s.exposure_feat = torch.full((8,), 0.05, device=dev)
+            if draws is None:
+                torch.manual_seed(11)
+                draws = s._draws(8, n_pix, (cam["H"] - 40) * (cam["W"] - 40))
+            s._draws = lambda *a, **k: draws
+            best = s.track(frames[1], cam0, n_iters=8, n_pix=n_pix)
+            torch.cuda.synchronize()
+            outs[ver] = (best.cpu().clone(), s.last_cam.cpu().clone(), s.last_losses.cpu().clone())
+    finally:
+        _lib.check(L.psl_debug_option(b"track_fused", 2))
+    step = cfg["tracking"]["lr"]
+    rep = {}
+    for ver in (1, 2):
+        dl = float(((outs[ver][2][:, :3] - outs[0][2][:, :3]).abs() / outs[0][2][:, :3].abs().clamp_min(1e-6)).max())
+        dn = float((outs[ver][2][:, 3] - outs[0][2][:, 3]).abs().max())
+        dc = float((outs[ver][1] - outs[0][1]).abs().max())
+        db = float((outs[ver][0] - outs[0][0]).abs().max())
+        rep[ver] = dict(loss_rel=dl, n_active_diff=dn, cam_abs=dc, best_abs=db)
+        assert dn == 0 and dl < 2e-4, (ver, rep)
+        assert dc < 0.25 * step and db < 0.25 * step, (ver, rep)
+    report(test="track_launch_structures", n_pix=n_pix, exposure=exposure, **{f"v{k}": v for k, v in rep.items()})
+
+
 @pytest.mark.parametrize("remap", ["cv2", "exact"])
 def test_frustum_select_matches_oracle(remap):
     """Both depth-lookup rules of the frustum selection (Mapper.py:149-155) against their oracle restatements: "cv2" =
