@@ -198,9 +198,10 @@ __device__ __forceinline__ double block_sum_d(double v, double* lds) {
 // mask = (tmp < 10*mean(tmp)) & (gt>0) & ~nan.  Keeps the best (lowest-loss) pose (Tracker.py:347-350).
 __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w_color, int handle_dynamic, int use_color,
                                                        const float* __restrict__ cam_tensor, float* best /*[8]*/,
-                                                       float* loss_out /*[4]*/) {
+                                                       float* loss_out /*[4]*/, float* thr_out = nullptr, float* zero64 = nullptr) {
   __shared__ double lds[16];
   __shared__ float s_thr;
+  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;   // accumulators of the decode backward (k_composite_bwd cleared them)
   double s = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     if (b.active[i]) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
   double tot = block_sum_d(s, lds);
   double cnt = block_sum_d(c, lds);
   // handle_dynamic=False uses the median instead (Tracker.py:167-168): not used by any shipped config
-  if (threadIdx.x == 0) s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f;
+  if (threadIdx.x == 0) { s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f; if (thr_out) *thr_out = s_thr; }
   __syncthreads();
   float thr = s_thr;
   double lg = 0.0, lc = 0.0;
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
                                                     const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx,
                                                     AdamBias bias) {
   __shared__ float red[16][12];
-  // one ray per thread up to 1 024 rays (the base mix: 200); larger batches (Replica 1 500, TUM / ScanNet 5 000) stride
+  // one ray per thread up to 1 024 rays (the base mix: 200); written as strided loops (any n), launched for n <= 1 024 only:
+  // measured in round 5, ONE workgroup striding over 1 500 / 5 000 rays loses to the parallel ray kernels (cfg 1 -4 %, TUM -9 %)
   if (do_step) {
     float acc[12];
 #pragma unroll
@@ -424,60 +426,6 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
   for (int r = threadIdx.x; r < n; r += blockDim.x) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx, cam_tensor, b);
   __syncthreads();
   depth_inlier_block(b.gd, b.active, n);
-}
-
-// Batches of more than 1 024 rays (Replica 1 500, TUM / ScanNet 5 000): the reductions over ALL rays -- the 10 x mean mask
-// threshold (Tracker.py:165), the iteration's loss, the lowest-loss pose (:176-180,347-350) -- in one single-workgroup launch
-// between the two decode kernels; compositing backward runs inside the decode backward (TrackFuse with thr_in), compositing
-// forward here (two passes: the threshold needs every ray's error before any ray's mask).  Replaces k_composite_fwd,
-// k_tracker_loss and k_composite_bwd (three launches) of rounds 1-4.
-__global__ __launch_bounds__(1024) void k_track_stats(DecodeArgs a, TrackFuse tf, float* __restrict__ thr_out, float* __restrict__ zero64) {
-  __shared__ double lds[16];
-  __shared__ float s_thr;
-  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;   // accumulators of the decode backward that follows
-  const int n = tf.n_rays;
-  double se = 0.0, sc = 0.0;
-  for (int r = threadIdx.x; r < n; r += blockDim.x) {
-    RayComp c;
-    track_composite(a, tf.coef, r, c);
-    tf.depth[r] = c.d; tf.var[r] = c.v; tf.rgb[r * 3] = c.m0; tf.rgb[r * 3 + 1] = c.m1; tf.rgb[r * 3 + 2] = c.m2;
-    tf.valid[r] = c.nhas >= (S / 2 + 1) ? 1 : 0;
-    if (tf.active[r] != 0) {
-      float e = fabsf(c.gt - c.d);
-      if (tf.handle_dynamic) e = e / sqrtf(c.v + 1e-10f);
-      se += (double)e; sc += 1.0;
-    }
-  }
-  const double tot = block_sum_d(se, lds);
-  const double nact = block_sum_d(sc, lds);
-  if (threadIdx.x == 0) { s_thr = (nact > 0.0) ? 10.0f * (float)(tot / nact) : 0.f; *thr_out = s_thr; }
-  __syncthreads();
-  const float thr = s_thr;
-  double lg = 0.0, lc = 0.0;
-  for (int r = threadIdx.x; r < n; r += blockDim.x) {
-    if (tf.active[r] == 0) continue;
-    const float d = tf.depth[r], v = tf.var[r], gt = a.depth[r];      // this thread's own stores of the first pass
-    const float diff = fabsf(gt - d);
-    const float tmp = tf.handle_dynamic ? diff / sqrtf(v + 1e-10f) : diff;
-    const bool m = (tmp < thr) && (gt > 0.f) && (d == d) && (v == v);
-    if (m) {
-      const float e = diff / sqrtf(v + 1e-10f);
-      lg += (double)fminf(fmaxf(e, 0.f), 1e3f);
-      const float q0 = tf.gt_color[r * 3], q1 = tf.gt_color[r * 3 + 1], q2 = tf.gt_color[r * 3 + 2];
-      lc += (double)fabsf(q0 - tf.rgb[r * 3]) + (double)fabsf(q1 - tf.rgb[r * 3 + 1]) + (double)fabsf(q2 - tf.rgb[r * 3 + 2]);
-    }
-  }
-  const double Lg = block_sum_d(lg, lds);
-  const double Lc = block_sum_d(lc, lds);
-  if (threadIdx.x == 0) {
-    const double L = tf.use_color ? Lg + (double)tf.w_color * Lc : Lg;
-    tf.loss_out[0] = (float)L; tf.loss_out[1] = (float)Lg; tf.loss_out[2] = (float)Lc; tf.loss_out[3] = (float)nact;
-    if ((float)L < tf.best[7]) {
-      tf.best[7] = (float)L;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) tf.best[j] = tf.cam_tensor[j];
-    }
-  }
 }
 
 __global__ __launch_bounds__(1024) void k_track_mid(const float4* __restrict__ raw, const int* __restrict__ cnt, RayBufs b, int n,
@@ -983,19 +931,17 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
   // ... and since round 5 k_track_mid's work runs inside the decode backward (TrackFuse, psl_decode.h): an iteration is
   // k_track_pre, k-NN, decode forward, decode backward -- four launches.  Larger batches (Replica 1 500 px, TUM / ScanNet
-  // 5 000 px) take the same route with the single-workgroup kernels striding over the rays and the reductions over all rays
-  // in k_track_stats between the decode kernels: five launches instead of the ten of rounds 1-4 (ray set-up, depth mask,
-  // k-NN, forward, compositing, loss, compositing backward, backward, ray gradient, pose step).
+  // 5 000 px) keep their parallel ray kernels (one workgroup striding over thousands of rays lost to them: cfg 1 -4 %, TUM
+  // -9 %, ScanNet -7 %, measured in round 5) and fold only the compositing backward into the decode backward, which reads
+  // the threshold k_tracker_loss leaves in memory: nine launches instead of ten.
   // PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): rounds 3-4 (pre / mid launches up to 1 024 rays, ten beyond); 0: ten.
-  const bool fused = g_track_fused >= 2 || (n <= 1024 && g_track_fused != 0);
+  const bool fused = n <= 1024 && g_track_fused != 0;
   const bool mid_in_bwd = fused && g_track_fused >= 2;
-  const bool stats_launch = mid_in_bwd && n > 1024;
-  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; } } fused_guard{ctx};
+  const bool cbwd_in_bwd = !fused && g_track_fused >= 2;       // large batches: compositing backward inside the decode backward
+  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; c->skip_composite_bwd = false; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
-  if (mid_in_bwd && !stats_launch) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
-  DecodeArgs da{};          // what the ray stage reads of the decode's arguments (track_composite)
-  da.ws = rw; da.depth = b.gd; da.near_s = ctx->cfg.near_end_surface; da.far_s = ctx->cfg.far_end_surface; da.min_nn = ctx->cfg.min_nn_num;
+  if (mid_in_bwd) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
   float* thr_dev = loss_scratch + 16;
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
@@ -1028,11 +974,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     TrackFuse tf{};
     if (mid_in_bwd) {
       tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
-                     t->cam_tensor, t->best_out, lo, 1, stats_launch ? thr_dev : nullptr};
-      if (stats_launch) {
-        ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
-        PSL_KLAUNCH(k_track_stats, dim3(1), dim3(1024), 0, s, da, tf, thr_dev, ctx->d_small);
-      }
+                     t->cam_tensor, t->best_out, lo, 1, nullptr};
       ctx->track_fuse = &tf;
     } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
@@ -1041,11 +983,16 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
                          t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
     } else {
       hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
-                         t->cam_tensor, t->best_out, lo);
+                         t->cam_tensor, t->best_out, lo, cbwd_in_bwd ? thr_dev : nullptr, cbwd_in_bwd ? ctx->d_small : nullptr);
+      if (cbwd_in_bwd) {      // the decode backward composites each sample's ray itself under k_tracker_loss's threshold
+        tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
+                       t->cam_tensor, t->best_out, lo, 1, thr_dev};
+        ctx->track_fuse = &tf; ctx->skip_composite_bwd = true;
+      }
     }
     PSL_LAUNCH_CHECK();
     rc = render_bwd_impl(ctx, &ra, &rg, s);
-    ctx->track_fuse = nullptr;
+    ctx->track_fuse = nullptr; ctx->skip_composite_bwd = false;
     if (rc) return rc;
     if (!fused)
       hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
