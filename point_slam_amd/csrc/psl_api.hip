@@ -311,14 +311,14 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
 int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s) {
   int rc = check_render_args(ctx, a, "psl_render_bwd");
   if (rc) return rc;
-  if (!g || (!g->g_depth && !ctx->fused_ray && !ctx->skip_composite_bwd)) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
+  if (!g || (!g->g_depth && !ctx->fused_ray)) { set_error("psl_render_bwd: missing cotangents"); return PSL_ERR_ARG; }
   if (!(a->flags & (PSL_PTS_GRAD | PSL_PARAM_GRAD | PSL_FEAT_GRAD))) {
     set_error("psl_render_bwd: forward was run without any gradient flag"); return PSL_ERR_STATE;
   }
   if (a->n_rays == 0) return PSL_OK;
   DecodeArgs d;
   fill_decode_args(ctx, a, d);
-  if (!ctx->fused_ray && !ctx->skip_composite_bwd)
+  if (!ctx->fused_ray)
   { ProfScope ps(ctx, PROF_COMPOSITE_BWD, s, 200.0 * a->n_rays, true);
     rc = launch_composite_bwd((const float4*)d.ws.raw, a->z_vals, a->gt_depth, d.near_s, d.far_s, a->n_rays, a->sigmoid_coef,
                               g->g_depth, g->g_var, g->g_rgb, (float4*)d.ws.d_raw, ctx->d_small, s);

@@ -167,7 +167,6 @@ struct psl_ctx {
   bool fused_ray = false;    // psl_map_iters: compositing fwd/bwd + loss run in its own fused kernel
   double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters: [iteration][kLossSlots][4]
   float* fwd_zero64 = nullptr;   // psl_map_iters, ray stage inside the backward: the colour-stage forward clears the backward's accumulators
-  bool skip_composite_bwd = false;    // psl_track_iters, > 1024 rays: the decode backward composites backwards itself (TrackFuse with thr_in)
   const void* track_fuse = nullptr;   // psl_track_iters (<= 1024 rays): TrackFuse* handed to launch_decode_bwd2 -- the tracker's ray stage inside the backward
   const void* ray_fuse = nullptr; const void* ray_wl = nullptr;   // ... RayFuse* / AdamWorklist* handed to launch_decode_bwd2
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators

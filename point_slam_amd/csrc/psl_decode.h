@@ -122,7 +122,6 @@ struct TrackFuse {
   float *depth, *var, *rgb; unsigned char* valid;
   const float* cam_tensor; float* best; float* loss_out;
   int on;
-  const float* thr_in;     // batches > 1024 rays: threshold, loss and best pose come from k_track_stats (one launch); null: in here
 };
 struct RayComp { float w[S], z[S], al[S], Tt[S], c0[S], c1[S], c2[S]; float W, d, v, m0, m1, m2, gt; int nhas; };
 

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(
   // workgroup -- in the geometry role too, whose other seven wavefronts then leave
   float thr_track = 0.f;
   if constexpr (PTSG && COLOR) {
-    if (tf.on) thr_track = tf.thr_in ? *tf.thr_in : track_threshold_block(a, tf, smem + Bwd2Lds::oDZ, is_color && b == 0);
+    if (tf.on) thr_track = track_threshold_block(a, tf, smem + Bwd2Lds::oDZ, is_color && b == 0);
   }
   if (is_color) {
     color_tile_bwd<PTSG>(a, o, WB, smem, tile * TILE, rf, tf, thr_track);

@@ -198,10 +198,9 @@ __device__ __forceinline__ double block_sum_d(double v, double* lds) {
 // mask = (tmp < 10*mean(tmp)) & (gt>0) & ~nan.  Keeps the best (lowest-loss) pose (Tracker.py:347-350).
 __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w_color, int handle_dynamic, int use_color,
                                                        const float* __restrict__ cam_tensor, float* best /*[8]*/,
-                                                       float* loss_out /*[4]*/, float* thr_out = nullptr, float* zero64 = nullptr) {
+                                                       float* loss_out /*[4]*/) {
   __shared__ double lds[16];
   __shared__ float s_thr;
-  if (zero64 && threadIdx.x < 64) zero64[threadIdx.x] = 0.f;   // accumulators of the decode backward (k_composite_bwd cleared them)
   double s = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     if (b.active[i]) {
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
   double tot = block_sum_d(s, lds);
   double cnt = block_sum_d(c, lds);
   // handle_dynamic=False uses the median instead (Tracker.py:167-168): not used by any shipped config
-  if (threadIdx.x == 0) { s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f; if (thr_out) *thr_out = s_thr; }
+  if (threadIdx.x == 0) s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f;
   __syncthreads();
   float thr = s_thr;
   double lg = 0.0, lc = 0.0;
@@ -931,18 +930,16 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   // batches of <= 1024 rays: the seven single-workgroup kernels of an iteration collapse into k_track_pre / k_track_mid
   // ... and since round 5 k_track_mid's work runs inside the decode backward (TrackFuse, psl_decode.h): an iteration is
   // k_track_pre, k-NN, decode forward, decode backward -- four launches.  Larger batches (Replica 1 500 px, TUM / ScanNet
-  // 5 000 px) keep their parallel ray kernels (one workgroup striding over thousands of rays lost to them: cfg 1 -4 %, TUM
-  // -9 %, ScanNet -7 %, measured in round 5) and fold only the compositing backward into the decode backward, which reads
-  // the threshold k_tracker_loss leaves in memory: nine launches instead of ten.
-  // PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): rounds 3-4 (pre / mid launches up to 1 024 rays, ten beyond); 0: ten.
+  // 5 000 px) keep the ten launches of rounds 1-4, measured in round 5 (profiles/r05_track_fuse_ab.txt): one workgroup
+  // striding over thousands of rays loses to the parallel ray kernels (cfg 1 -4 %, TUM -9 %, ScanNet -7 %), and folding only
+  // the compositing backward into the decode backward costs that kernel ~10 us at 5 000 rays for the 5-us launch it saves.
+  // PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): rounds 3-4 (k_track_mid as a launch of its own); 0: ten launches.
   const bool fused = n <= 1024 && g_track_fused != 0;
   const bool mid_in_bwd = fused && g_track_fused >= 2;
-  const bool cbwd_in_bwd = !fused && g_track_fused >= 2;       // large batches: compositing backward inside the decode backward
-  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; c->skip_composite_bwd = false; } } fused_guard{ctx};
+  struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
   if (mid_in_bwd) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
-  float* thr_dev = loss_scratch + 16;
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
     // bias corrections of Adam step `step0 + it` with the formulas of adam_bias(), evaluated here instead of by one thread
@@ -974,7 +971,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     TrackFuse tf{};
     if (mid_in_bwd) {
       tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
-                     t->cam_tensor, t->best_out, lo, 1, nullptr};
+                     t->cam_tensor, t->best_out, lo, 1};
       ctx->track_fuse = &tf;
     } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
@@ -983,16 +980,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
                          t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
     } else {
       hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
-                         t->cam_tensor, t->best_out, lo, cbwd_in_bwd ? thr_dev : nullptr, cbwd_in_bwd ? ctx->d_small : nullptr);
-      if (cbwd_in_bwd) {      // the decode backward composites each sample's ray itself under k_tracker_loss's threshold
-        tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
-                       t->cam_tensor, t->best_out, lo, 1, thr_dev};
-        ctx->track_fuse = &tf; ctx->skip_composite_bwd = true;
-      }
+                         t->cam_tensor, t->best_out, lo);
     }
     PSL_LAUNCH_CHECK();
     rc = render_bwd_impl(ctx, &ra, &rg, s);
-    ctx->track_fuse = nullptr; ctx->skip_composite_bwd = false;
+    ctx->track_fuse = nullptr;
     if (rc) return rc;
     if (!fused)
       hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,

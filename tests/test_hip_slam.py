@@ -118,8 +118,8 @@ def test_track_native_matches_dropin():
 def test_track_launch_structures_agree(n_pix, exposure):
     """psl_track_iters under its three launch structures (psl_debug_option("track_fused", v)): 0 = the ten launches of rounds
     1-2 (ray set-up, depth mask, k-NN, forward, compositing, loss, compositing backward, backward, ray gradient, pose step),
-    1 = pre / mid launches up to 1 024 rays (rounds 3-4), 2 = the ray stage inside the decode backward (TrackFuse: the whole of
-    k_track_mid up to 1 024 rays; beyond, the compositing backward only, under the threshold k_tracker_loss leaves) -- the default.  Same draws, eight iterations: the per-iteration
+    1 = pre / mid launches up to 1 024 rays (rounds 3-4), 2 = the ray stage inside the decode backward up to 1 024 rays
+    (TrackFuse), ten launches beyond -- the default.  Same draws, eight iterations: the per-iteration
     losses agree to float rounding of the sums over rays, the poses after eight Adam steps to a fraction of one step; the
     batch sizes of every shipped config (200 base, 1 500 Replica, 5 000 TUM / ScanNet, the last with per-frame exposure)."""
     from point_slam_amd import _lib
