@@ -745,7 +745,7 @@ def main():
         t_track = (time.perf_counter() - t0) / len(ids)
         t0 = time.perf_counter()
         for i in ids[:2]:
-            slam.map(frames[i], frames[i].gt_c2w)
+            slam.map(frames[i], frames[i].gt_c2w, n_iters=cfg["mapping"]["iters"], fixed_iters=True)   # the yaml's count, not the data-dependent one
         torch.cuda.synchronize()
         t_map = (time.perf_counter() - t0) / 2
         split = {"track_ms_per_frame": round(t_track * 1e3, 3), "track_only_fps": round(1.0 / t_track, 2),
