@@ -257,7 +257,7 @@ typedef struct psl_track_args {
   int32_t step0;                    /* Adam steps already taken on this state */
   float lr_T, lr_quat;              /* tracking.lr, 0.2*tracking.lr (separate_LR, Tracker.py:305-306) */
   float w_color;                    /* tracking.w_color_loss */
-  int32_t handle_dynamic, use_color;
+  int32_t handle_dynamic, use_color;   /* handle_dynamic 0: the median mask of Tracker.py:166-168 (round 5; ten-launch path) */
   float sigmoid_coef;
   const float *geo_feats, *col_feats, *params, *col_embed_B;
   float* ws;                        /* psl_track_ws_floats(n_pix) floats */

@@ -230,8 +230,10 @@ def save(name, d):
     print("  wrote", path, f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
-def run_tracker_case(name, n_pts, n_rays, seed):
-    """One real Tracker.optimize_cam_in_batch iteration (src/Tracker.py:89-186) with a fake self."""
+def run_tracker_case(name, n_pts, n_rays, seed, handle_dynamic=True):
+    """One real Tracker.optimize_cam_in_batch iteration (src/Tracker.py:89-186) with a fake self.
+    handle_dynamic=False: the median-mask branch (Tracker.py:166-168; no shipped config uses it) on the SAME scene and draws --
+    only the reference's results are stored (the inputs are those of the handle_dynamic=True fixture of the same seed)."""
     ns = RI.load()
     if ns.tracker_mod is None:
         print("Tracker module not importable:", ns.tracker_err)
@@ -278,7 +280,7 @@ def run_tracker_case(name, n_pts, n_rays, seed):
         sample_with_color_grad=False, fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"],
         depth_limit=False, use_dynamic_radius=True, dynamic_r_query=rq_img, renderer=rend,
         decoders=RI.PointCPU(dec), npc_geo_feats=sc["geo"].clone(), npc_col_feats=sc["col"].clone(),
-        cloud_pos=sc["cloud"], exposure_feat=None, handle_dynamic=True, use_color_in_tracking=True,
+        cloud_pos=sc["cloud"], exposure_feat=None, handle_dynamic=bool(handle_dynamic), use_color_in_tracking=True,
         w_color_loss=cfg["tracking"]["w_color_loss"])
     torch.manual_seed(seed + 3)
     # record the pixel indices the reference will draw: select_uv uses torch.randint on the global RNG
@@ -301,6 +303,7 @@ def run_tracker_case(name, n_pts, n_rays, seed):
     # oracle replay: loss, then torch Adam on the same leaves
     q2 = cam_t[:4].clone().requires_grad_(True)
     t2 = cam_t[4:].clone().requires_grad_(True)
+    cfg["tracking"]["handle_dynamic"] = bool(handle_dynamic)
     l2, g2, c2, m2 = O.tracker_iteration(cfg, P, sc["cloud"], sc["geo"], sc["col"], q2, t2, idx, depth_img,
                                          color_img.double(), rq_img, cam, out["fb_geo"], out["fb_col"], 20, 20,
                                          coef=rend.sigmoid_coefficient)
@@ -312,12 +315,19 @@ def run_tracker_case(name, n_pts, n_rays, seed):
     assert abs(float(l2) - loss) / loss < 1e-5
     assert float((tn - Tt.detach()).abs().max()) < 1e-6 and float((qn - quad.detach()).abs().max()) < 1e-6
     out["ref_g_quad_sign"] = torch.sign(q2.grad)
+    out["ref_mask_count"] = int(m2.sum())
+    if not handle_dynamic:      # results only: the scene and the draws are the dynamic fixture's
+        out = {k: v for k, v in out.items() if k.startswith("ref_") or k in ("seed", "n_rays")}
+        out["handle_dynamic"] = False
     save(name, out)
 
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--tracker-static" in sys.argv:   # the handle_dynamic=False branch of the tracker loss (results only; inputs = tracker_iter_replica)
+        run_tracker_case("tracker_iter_replica_static", 2000, 200, 106, handle_dynamic=False)
+        return
     if "--scannet-mapper" in sys.argv:   # encode_exposure with exposure_feat=None: raw colour logits, no sigmoid (decoder.py:432-448)
         run_render_case("render_scannet_color_mapper", "scannet", "color", False, 2000, 64, 109)
         return
@@ -337,6 +347,7 @@ def main():
                              exposure=True, store_param_grads=True)
     save("decoders_seed1219_scannet", {k: v for k, v in P.items()})
     run_tracker_case("tracker_iter_replica", 2000, 200, 106)
+    run_tracker_case("tracker_iter_replica_static", 2000, 200, 106, handle_dynamic=False)
     run_render_case("render_holes_nearpcl_mapper", "replica", "color", False, 3000, 96, 107, sparse_frac=0.35,
                     zero_depth_frac=0.4, sample_near_pcl=True)
     run_render_case("render_holes_uniform_tracker", "replica", "color", True, 2000, 64, 108,

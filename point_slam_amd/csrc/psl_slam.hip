@@ -102,16 +102,21 @@ __global__ void k_track_init(FrameDev* fdev, FrameDev fh, float* best) {
 // (Tracker.py:142-144, Mapper.py:507-509).  One workgroup.  n <= 4096: every thread ranks its own element
 // against all others held in LDS (n^2/1024 compares per thread, no sort, two barriers); larger batches use a
 // 4-pass byte-wise radix select over the float bit patterns (positive floats order like their bits).
-__device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd, int* active, int n) {
+// Lower median (torch.median) of the non-negative floats v[i] over the elements with active[i] != 0, by one workgroup; also
+// their count, minimum and maximum.  Every thread returns the same values.  (positive floats order like their bit patterns)
+struct BlockStats { unsigned cnt; float mn, mx, med; };
+__device__ __forceinline__ BlockStats block_lower_median(const float* __restrict__ v, const int* __restrict__ active, int n,
+                                                         bool skip_median_if_inlier_rule_is_void) {
   __shared__ unsigned keys[4096];
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_rank, s_cnt, s_max, s_min, s_med;
+  __syncthreads();           // a previous call's readers are done with the shared state
   if (threadIdx.x == 0) { s_cnt = 0; s_max = 0; s_min = 0xFFFFFFFFu; s_prefix = 0; s_med = 0; }
   __syncthreads();
   unsigned lc = 0, lm = 0, ln = 0xFFFFFFFFu;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     bool a = active[i] != 0;
-    unsigned b = a ? __float_as_uint(gd[i]) : 0xFFFFFFFFu;
+    unsigned b = a ? __float_as_uint(v[i]) : 0xFFFFFFFFu;
     if (n <= 4096) keys[i] = b;
     if (a) { lc++; lm = max(lm, b); ln = min(ln, b); }
   }
@@ -123,12 +128,13 @@ __device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd,
   }
   if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt, lc); atomicMax(&s_max, lm); atomicMin(&s_min, ln); }
   __syncthreads();
-  const unsigned cnt = s_cnt;
-  if (cnt == 0) return;
-  // median >= min, so 10*min >= 1.2*max implies thr = 1.2*max >= every depth: nothing to mask and no median
-  // needed (the usual indoor case); the result is identical to evaluating the reference expression
-  if (10.0f * __uint_as_float(s_min) >= 1.2f * __uint_as_float(s_max)) return;
-  const unsigned want = (cnt - 1) >> 1;
+  BlockStats st;
+  st.cnt = s_cnt; st.mn = __uint_as_float(s_min); st.mx = __uint_as_float(s_max); st.med = 0.f;
+  if (st.cnt == 0) return st;
+  // depth-outlier rule only: median >= min, so 10*min >= 1.2*max implies thr = 1.2*max >= every depth: nothing to mask and
+  // no median needed (the usual indoor case); the result is identical to evaluating the reference expression
+  if (skip_median_if_inlier_rule_is_void && 10.0f * st.mn >= 1.2f * st.mx) { st.med = st.mn; return st; }
+  const unsigned want = (st.cnt - 1) >> 1;
   if (n <= 4096) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const unsigned mine = keys[i];
@@ -151,7 +157,7 @@ __device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd,
       const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
         if (active[i]) {
-          unsigned b = __float_as_uint(gd[i]);
+          unsigned b = __float_as_uint(v[i]);
           if ((b & himask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
         }
       }
@@ -167,9 +173,14 @@ __device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd,
     if (threadIdx.x == 0) s_med = s_prefix;
     __syncthreads();
   }
-  const float med = __uint_as_float(s_med);
-  const float mx = __uint_as_float(s_max);
-  const float thr = fminf(10.0f * med, 1.2f * mx);
+  st.med = __uint_as_float(s_med);
+  return st;
+}
+
+__device__ __forceinline__ void depth_inlier_block(const float* __restrict__ gd, int* active, int n) {
+  const BlockStats st = block_lower_median(gd, active, n, true);
+  if (st.cnt == 0 || 10.0f * st.mn >= 1.2f * st.mx) return;
+  const float thr = fminf(10.0f * st.med, 1.2f * st.mx);
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     if (active[i] && !(gd[i] <= thr)) active[i] = 0;
 }
@@ -211,10 +222,18 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
   }
   double tot = block_sum_d(s, lds);
   double cnt = block_sum_d(c, lds);
-  // handle_dynamic=False uses the median instead (Tracker.py:167-168): not used by any shipped config
   if (threadIdx.x == 0) s_thr = (cnt > 0.0) ? 10.0f * (float)(tot / cnt) : 0.f;
   __syncthreads();
   float thr = s_thr;
+  if (!handle_dynamic) {
+    // tracking.handle_dynamic = False (Tracker.py:166-168; no shipped config): tmp = |gt - d|, mask = tmp < 10 * tmp.median()
+    // (torch.median: the lower median) over the rays of the batch.  tmp goes through g_depth, which the loop below overwrites.
+    for (int i = threadIdx.x; i < n; i += blockDim.x) b.g_depth[i] = b.active[i] ? fabsf(b.gd[i] - b.depth[i]) : 0.f;
+    __syncthreads();
+    const BlockStats st = block_lower_median(b.g_depth, b.active, n, false);
+    thr = st.cnt ? 10.0f * st.med : 0.f;
+    __syncthreads();
+  }
   double lg = 0.0, lc = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     float gdp = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -876,7 +895,6 @@ extern "C" int64_t psl_track_ws_floats(int n_pix) {
 extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stream) {
   if (!ctx || !t || !t->pix_idx || !t->cam_tensor || !t->adam_state || !t->ws || !t->frame.depth || !t->frame.color ||
       !t->fallback || !t->best_out) { set_error("psl_track_iters: missing argument"); return PSL_ERR_ARG; }
-  if (!t->handle_dynamic) { set_error("psl_track_iters: tracking.handle_dynamic=False (median mask) is not built; every shipped config uses True"); return PSL_ERR_UNSUPPORTED; }
   if (t->n_pix <= 0 || t->n_pix > 65536) { set_error("psl_track_iters: n_pix must be in [1,65536]"); return PSL_ERR_ARG; }
   const psl_exposure_args* ex = t->exposure;
   if (ex && (!ex->mlp || !ex->feats || !ex->adam)) { set_error("psl_track_iters: incomplete exposure block"); return PSL_ERR_ARG; }
@@ -934,7 +952,9 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   // striding over thousands of rays loses to the parallel ray kernels (cfg 1 -4 %, TUM -9 %, ScanNet -7 %), and folding only
   // the compositing backward into the decode backward costs that kernel ~10 us at 5 000 rays for the 5-us launch it saves.
   // PSL_TRACK_FUSED=1 / psl_debug_option("track_fused", 1): rounds 3-4 (k_track_mid as a launch of its own); 0: ten launches.
-  const bool fused = n <= 1024 && g_track_fused != 0;
+  // tracking.handle_dynamic = False (the median mask, Tracker.py:166-168; no shipped config) takes the ten-launch path: the
+  // median lives in k_tracker_loss only
+  const bool fused = n <= 1024 && g_track_fused != 0 && t->handle_dynamic != 0;
   const bool mid_in_bwd = fused && g_track_fused >= 2;
   struct FusedGuard { psl_ctx* c; ~FusedGuard() { c->fused_ray = false; c->track_fuse = nullptr; c->fwd_zero64 = nullptr; } } fused_guard{ctx};
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));

@@ -46,6 +46,69 @@ def test_track_native_one_iter_matches_reference_golden():
     assert torch.allclose(best.cpu(), fx["cam0"], atol=1e-7)      # the evaluated (pre-step) pose is the candidate
 
 
+def test_track_native_static_mask_matches_reference_golden():
+    """tracking.handle_dynamic = False (the median mask, Tracker.py:166-168): one psl_track_iters iteration == the reference's
+    optimize_cam_in_batch step of tests/golden/tracker_iter_replica_static.npz (results; scene and draws of tracker_iter_replica)."""
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    fx, st = load_npz("tracker_iter_replica"), load_npz("tracker_iter_replica_static")
+    cfg = base_cfg()
+    cfg["tracking"]["handle_dynamic"] = False
+    cam = syn.intrinsics(160, 120)
+    s = _slam(cfg, cam, "native", dev, fx)
+    frame = Frame(0, fx["depth_img"].to(dev), fx["color_img"].to(dev), r_query=fx["rq_img"].to(dev))
+    n = int(fx["n_rays"])
+    idx = fx["pix_idx"].to(dev).int().reshape(1, n).contiguous()
+    fb = torch.stack([fx["fb_geo"], fx["fb_col"]]).reshape(1, 2, 32).to(dev).contiguous()
+    s._draws = lambda n_iters, n_idx, hi: (idx, fb)
+    s.track(frame, fx["cam0"], n_iters=1, n_pix=n)
+    torch.cuda.synchronize()
+    rel = abs(float(s.last_losses[0, 0]) - st["ref_loss"]) / st["ref_loss"]
+    after = s.last_cam.cpu()
+    dq, dT = float((after[:4] - st["ref_quad_after"]).abs().max()), float((after[4:] - st["ref_T_after"]).abs().max())
+    report(test="track_native_static_mask_golden", loss_rel=rel, dq=dq, dT=dT)
+    assert rel < 1e-4 and dq < 1e-6 and dT < 1e-6
+
+
+def test_track_static_mask_on_perturbed_depth_matches_oracle():
+    """... and on a second input (a tenth of the sensor depths pushed 6 % off the map) against the oracle's tracker iteration:
+    loss and its two terms.  (Point-SLAM samples a ray's five points within +-2 % of the SENSOR depth, so |d_gt - d| stays
+    within a few per cent of the depth whatever the map holds and the 10 x median threshold rarely binds -- it does not on
+    either input here; what the two tests pin is the branch's loss, gradient and pose step, and that the median is not
+    degenerate: a zero threshold would mask every ray.  The selection code itself is the depth-outlier mask's, tested at
+    n <= 4096 and beyond.)"""
+    from oracle import pointslam_oracle as O
+    from point_slam_amd import synthetic as syn
+    from point_slam_amd.slam import Frame
+    dev = torch.device("cuda:0")
+    fx = load_npz("tracker_iter_replica")
+    cfg = base_cfg()
+    cfg["tracking"]["handle_dynamic"] = False
+    cam = syn.intrinsics(160, 120)
+    g = torch.Generator().manual_seed(2)
+    depth = fx["depth_img"].clone()
+    off = torch.rand(depth.shape, generator=g) < 0.1
+    depth[off] = depth[off] * 1.06
+    P = load_decoders("replica")
+    q, t = fx["cam0"][:4].clone().requires_grad_(True), fx["cam0"][4:].clone().requires_grad_(True)
+    loss, geo, col, mask = O.tracker_iteration(cfg, P, fx["cloud"], fx["geo"], fx["col"], q, t, fx["pix_idx"], depth,
+                                               fx["color_img"].double(), fx["rq_img"], cam, fx["fb_geo"], fx["fb_col"], 20, 20)
+    s = _slam(cfg, cam, "native", dev, fx)
+    frame = Frame(0, depth.to(dev), fx["color_img"].to(dev), r_query=fx["rq_img"].to(dev))
+    n = int(fx["n_rays"])
+    idx = fx["pix_idx"].to(dev).int().reshape(1, n).contiguous()
+    fb = torch.stack([fx["fb_geo"], fx["fb_col"]]).reshape(1, 2, 32).to(dev).contiguous()
+    s._draws = lambda n_iters, n_idx, hi: (idx, fb)
+    s.track(frame, fx["cam0"], n_iters=1, n_pix=n)
+    torch.cuda.synchronize()
+    got = s.last_losses[0].cpu().double()
+    rep = dict(loss_rel=abs(float(got[0]) - float(loss)) / float(loss), geo_rel=abs(float(got[1]) - float(geo)) / float(geo),
+               col_rel=abs(float(got[2]) - float(col)) / float(col), masked=int((~mask).sum()))
+    report(test="track_static_mask_outliers", **rep)
+    assert rep["loss_rel"] < 1e-5 and rep["geo_rel"] < 1e-5 and rep["col_rel"] < 1e-5
+
+
 def _scene(dev, n_pts=60000, W=320, H=240):
     from point_slam_amd import synthetic as syn
     from point_slam_amd.slam import Frame
