@@ -743,14 +743,19 @@ def main():
             slam.track(frames[i], cams0[i])
         torch.cuda.synchronize()
         t_track = (time.perf_counter() - t0) / len(ids)
-        t0 = time.perf_counter()
+        t_maps, map_detail = [], []
         for i in ids[:2]:
+            t0 = time.perf_counter()
             slam.map(frames[i], frames[i].gt_c2w, n_iters=cfg["mapping"]["iters"], fixed_iters=True)   # the yaml's count, not the data-dependent one
-        torch.cuda.synchronize()
-        t_map = (time.perf_counter() - t0) / 2
+            torch.cuda.synchronize()
+            t_maps.append(time.perf_counter() - t0)
+            map_detail.append(dict(slam.last_map, ms=round(t_maps[-1] * 1e3, 3)))
+        t_map = sum(t_maps) / len(t_maps)
         split = {"track_ms_per_frame": round(t_track * 1e3, 3), "track_only_fps": round(1.0 / t_track, 2),
                  "map_ms_per_mapped_frame": round(t_map * 1e3, 3),
-                 "map_only_fps": round(cfg["mapping"]["every_frame"] / t_map, 2)}
+                 "map_only_fps": round(cfg["mapping"]["every_frame"] / t_map, 2),
+                 # what the two mapping calls of this split ran (frustum rows, window, iterations: the cost of a call follows them)
+                 "map_calls": map_detail}
 
     if rank == 0:
         pmc_key = "cfg5" if (args.points >= 2_000_000 and args.width >= 1280) else args.mix

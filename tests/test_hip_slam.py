@@ -106,7 +106,7 @@ def test_track_static_mask_on_perturbed_depth_matches_oracle():
     rep = dict(loss_rel=abs(float(got[0]) - float(loss)) / float(loss), geo_rel=abs(float(got[1]) - float(geo)) / float(geo),
                col_rel=abs(float(got[2]) - float(col)) / float(col), masked=int((~mask).sum()))
     report(test="track_static_mask_outliers", **rep)
-    assert rep["loss_rel"] < 1e-5 and rep["geo_rel"] < 1e-5 and rep["col_rel"] < 1e-5
+    assert rep["loss_rel"] < 1e-4 and rep["geo_rel"] < 1e-4 and rep["col_rel"] < 1e-4          # the bound of the golden tracker tests
 
 
 def _scene(dev, n_pts=60000, W=320, H=240):
