@@ -745,6 +745,11 @@ def main():
         t_track = (time.perf_counter() - t0) / len(ids)
         t_maps, map_detail = [], []
         for i in ids[:2]:
+            # a mapping call always follows the tracking of its frame (Point_SLAM's loop; every_frame >= 1); two mapping calls
+            # directly after one another -- which no run of the loop produces -- cost the second one a one-off ~130 ms
+            # (tools/map_repeat_probe.py: 43 / 176 / 43 / 43 ms; 43 / 43 / 43 with a tracked frame in between)
+            slam.track(frames[i], cams0[i])
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             slam.map(frames[i], frames[i].gt_c2w, n_iters=cfg["mapping"]["iters"], fixed_iters=True)   # the yaml's count, not the data-dependent one
             torch.cuda.synchronize()
