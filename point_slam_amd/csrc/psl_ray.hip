@@ -447,12 +447,11 @@ __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRows
   adam_lazy_rows_block<LPR>(is_col ? col : geo, is_col, blk0, nb_rows, b1, b2, eps, lz, stab);
 }
 
-// lanes per feature row of the lazy launch (32 = one channel per lane, the layout of rounds 2-3; 16 = float2, 8 = float4 per lane).
-// Measured on one box (profiles/r04_adam_lanes_per_row.txt): 25.6 / 23.3 / 23.9 us per launch by the dispatch events, 21.4 us
-// (colour stage: two row groups + decoder parameters) and 13.1 us (geometry stage: one row group) in the kernel trace for
-// 32 and 8 alike, 95.1-95.2 frames/s end to end for all three -- the launch is bound by its fixed costs (dispatch of the
-// grid, the dependent list -> row state -> row data round trips, the write-back at the kernel boundary), not by the access width.
-int g_adam_lpr = [] { const char* e = getenv("PSL_ADAM_LPR"); const int v = e ? atoi(e) : 16; return (v == 32 || v == 8) ? v : 16; }();
+// Lanes per feature row of the lazy launch: 16 (two channels, one 8-byte access per stream and lane).  Round 4 measured 32 / 16 / 8
+// lanes per row on one box (profiles/r04_adam_lanes_per_row.txt): 25.6 / 23.3 / 23.9 us per launch by the dispatch events, 95.1-95.2
+// frames/s end to end for all three -- the launch is bound by its fixed costs (dispatch of the grid, the write-back at the kernel
+// boundary), not by the access width; round 5 kept the one instantiation (advisor r4) and dropped the PSL_ADAM_LPR switch.
+constexpr int kAdamLpr = 16;
 
 }  // namespace psl
 
@@ -476,7 +475,7 @@ namespace psl {
 int adam_lazy_row_blocks(const AdamLazy& lazy, int n_rows) {
   // a fixed grid of at most 2 048 workgroups per group (256 / lanes-per-row rows each per trip) walks the list with a stride
   const long long rows = lazy.list ? std::min<long long>(lazy.list_cap, n_rows) : n_rows;
-  const int rpt = 256 / g_adam_lpr;
+  const int rpt = 256 / kAdamLpr;
   return (int)std::min<long long>((rows + rpt - 1) / rpt, 2048);
 }
 
@@ -491,9 +490,7 @@ int launch_map_adam(AdamRowsSeg geo, int step_geo, float lr_geo, AdamRowsSeg col
     const int nb_rows = adam_lazy_row_blocks(lazy, geo.n_rows), n_groups = col.n_rows > 0 ? 2 : 1;
     if (nb_rows * n_groups + nb_par == 0) return PSL_OK;
     const dim3 grid(nb_rows * n_groups + nb_par);
-    if (g_adam_lpr == 32) PSL_KLAUNCH(k_map_adam_lazy<32>, grid, dim3(256), 0, s, geo, col, par, nb_rows, n_groups, 0.9f, 0.999f, 1e-8f, lazy);
-    else if (g_adam_lpr == 16) PSL_KLAUNCH(k_map_adam_lazy<16>, grid, dim3(256), 0, s, geo, col, par, nb_rows, n_groups, 0.9f, 0.999f, 1e-8f, lazy);
-    else PSL_KLAUNCH(k_map_adam_lazy<8>, grid, dim3(256), 0, s, geo, col, par, nb_rows, n_groups, 0.9f, 0.999f, 1e-8f, lazy);
+    PSL_KLAUNCH(k_map_adam_lazy<kAdamLpr>, grid, dim3(256), 0, s, geo, col, par, nb_rows, n_groups, 0.9f, 0.999f, 1e-8f, lazy);
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }
