@@ -32,8 +32,8 @@ over xGMI (what a multi-GPU node runs), on gloo the CPU tests / ranks sharing on
 libpointslam_hip.so (`psl_allgather_new_points` on the library's own RCCL communicator, `psl_comm_init`; the 128-byte
 ncclUniqueId travels over torch.distributed once) is OPT-IN: `transport="native"` / PSL_NATIVE_RCCL=1.  It has only ever run
 on a one-rank communicator (no multi-GPU node has been available to any session), so it is not the path a first 8-GPU run
-takes by default (advisor, round 4); tests/test_hip_dist.py::test_exchange_two_gpus_nccl runs BOTH transports with two
-ranks wherever two GPUs are visible.  Before any rank enters ncclCommInitRank the ranks agree (all-reduce over
+takes by default (advisor, round 4); tests/test_hip_dist.py::test_exchange_two_gpus_nccl runs the default transport with two
+ranks wherever two GPUs are visible (the native one under PSL_TEST_NATIVE_RCCL=1).  Before any rank enters ncclCommInitRank the ranks agree (all-reduce over
 torch.distributed) that every one of them could load librccl and reserve its device buffers: a rank-local failure can no
 longer leave the others blocked inside the communicator's rendezvous.
 
