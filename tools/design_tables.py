@@ -29,9 +29,12 @@ def bench_table():
             ("replica_6steps", "same, 6 frames after 2 (round 2's command)", "`--mix replica --steps 6 --warmup 2`"),
             ("tum", "TUM yaml (track 5 000 px x 200, map 10 000 px x 150 every 2), NOISY depth: 0.5 % noise, 2 % holes", "`--mix tum`"),
             ("tum_6steps", "same, 6 frames after 2", "`--mix tum --steps 6 --warmup 2`"),
+            ("tum_200steps", "same, 200 timed frames", "`--mix tum --steps 200 --fps-window 50`"),
             ("scannet", "ScanNet yaml (exposure latents; track 5 000 px x 100, map 10 000 px x 300)", "`--mix scannet`"),
+            ("scannet_200steps", "same, 200 timed frames", "`--mix scannet --steps 200 --fps-window 50`"),
             ("scannet_6steps", "same, 6 frames after 2", "`--mix scannet --steps 6 --warmup 2`"),
             ("cfg5", "cfg 5: 2 M points, 1280x960", "`--points 2000000 --width 1280 --height 960`"),
+            ("cfg5_500steps", "same, 500 timed frames", "`--points 2000000 --width 1280 --height 960 --steps 500 --fps-window 100`"),
             ("cfg1", "cfg 1: tracking only, fixed 50 k cloud, 1200x680, 200 frames", "`--track-only --points 50000 --width 1200 --height 680 --mix replica --steps 200`"),
             ("closed_loop_0p5u_100steps", "base mix, CLOSED loop at a Replica-like camera speed (1.4 cm / frame), 100 frames", "`--closed-loop --units-per-frame 0.5 --steps 100`"),
             ("replica_closed_loop_40steps", "Replica yaml, CLOSED loop at full speed (5.6 cm / frame), 40 frames", "`--mix replica --closed-loop --steps 40`"),
@@ -112,7 +115,7 @@ def traffic_table():
 
 
 def window_table():
-    for key in ("base_500steps", "replica_500steps"):
+    for key in ("base_500steps", "replica_500steps", "tum_200steps", "scannet_200steps", "cfg5_500steps"):
         d = load(f"bench_{key}")
         if not d or not d["config"].get("fps_per_window"):
             continue
