@@ -890,7 +890,7 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
     // queries from which the high-occupancy instantiation <4 records in flight, 8 wavefronts per SIMD> is used (it is held to
-    // 64 VGPRs and spills two registers to scratch, profiles/r04_kernel_resources.json; PSL_KNN_FLAT_LARGE, < 0 = never).
+    // 64 VGPRs and spills two registers to scratch, profiles/r05_kernel_resources.json; PSL_KNN_FLAT_LARGE, < 0 = never).
     // Measured [MI355X, round 4]: 25 000 queries (TUM / ScanNet tracker) 74.6 -> 64.1 us, TUM yaml +2.7 %, ScanNet +1 %,
     // Replica (7 500 queries) +1.5 %; at the base mix's 1 000 queries (4 wavefronts per CU: no occupancy to gain) -0.5 %
     static int large_from = -2;

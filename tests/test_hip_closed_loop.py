@@ -7,7 +7,8 @@ tracker loop / add_neural_points fixtures).  What nothing else checks is the ORC
 points the mapper adds at THAT pose, the frustum rows it then selects, the data-dependent iteration count, the trained
 rows and decoder the next tracked frame renders against, the constant-speed initial pose built from two estimated poses.
 
-Protocol.  ONE closed-loop HIP run over seven frames (map every 2nd), which RECORDS every host-side random draw (pixel
+Protocol.  ONE closed-loop HIP run over five frames (map every 2nd: three mapped, four tracked; seven
+frames until round 5 -- shortened for the suite's wall time, the stages covered are the same), which RECORDS every host-side random draw (pixel
 indices and fallback vectors of every tracking / mapping call, the add-pixels, the keyframe window, the N(0, 0.1^2) initial
 features of the new points) and snapshots its state (cloud, both feature sets, decoder, estimated poses) in front of every
 frame.  The oracle then replays every STAGE from the HIP run's own hand-over -- the state and the poses the previous stages
@@ -29,7 +30,7 @@ from tests.test_hip_parity import report
 
 pytestmark = pytest.mark.gpu
 
-N_FRAMES, MAP_EVERY = 7, 2
+N_FRAMES, MAP_EVERY = 5, 2
 TRACK_ITERS, TRACK_PIX = 20, 200
 MAP_ITERS, MAP_PIX, ADD_PIX = 20, 600, 1500
 
@@ -44,7 +45,7 @@ def _cfg():
 
 def _scene(dev, n_pts=50000, W=320, H=240):
     """~50 k seeded points seen from around the trajectory (with unseeded stripes, so that every mapped frame ADDS
-    points), seven frames 1 trajectory unit (~2.8 cm, 0.2 degrees) apart."""
+    points), N_FRAMES frames 1 trajectory unit (~2.8 cm, 0.2 degrees) apart."""
     from point_slam_amd import synthetic as syn
     from point_slam_amd.slam import Frame
     cfg = _cfg()
@@ -258,7 +259,7 @@ def test_track_map_track_closed_loop_matches_oracle():
     # The lowest-loss pose of 20 Adam steps is NOT a parity quantity: next to the optimum the signs of Adam's +-lr steps are decided by
     # gradient components at the rounding level, and the oracle separates from ITSELF by 1e-5 .. 1.3e-2 (6 steps) when its
     # initial pose moves by one ulp (first measured run: HIP-vs-oracle 1e-4 .. 1.0e-2 on the same frames).  What can be
-    # asserted is that the two spreads are of one size -- over the six tracked frames, against six perturbed oracle runs:
+    # asserted is that the two spreads are of one size -- over the tracked frames, against as many perturbed oracle runs:
     worst_pose = max(r["pose_abs"] for r in per_frame[1:])
     worst_noise = max(r["oracle_self_noise_1ulp"] for r in per_frame[1:])
     assert worst_pose <= max(0.25 * step, 4 * worst_noise), (worst_pose, worst_noise)

@@ -372,7 +372,9 @@ def test_map_iters_140_iterations_vs_oracle(semantics):
     if frozen:
         cfg["mapping"]["fix_color_decoder"] = True
         semantics = "torch2"
-    n_iters, ppf = 140, 400
+    # torch1 differs from torch2 only in the decoder group's step counter: 72 iterations (one prefetch-block end, 28 geometry
+    # + 44 colour iterations) show it; the 140-iteration runs are the other two variants
+    n_iters, ppf = (72 if semantics == "torch1" else 140), 400
     n_geo = int(n_iters * cfg["mapping"]["geo_iter_ratio"])
     g = torch.Generator().manual_seed(21)
     idx = torch.randint(cam["H"] * cam["W"], (n_iters, 3 * ppf), generator=g, dtype=torch.int32)
@@ -410,7 +412,7 @@ def test_map_iters_140_iterations_vs_oracle(semantics):
         dd = max(float((theta[k] - P_o[k]).abs().max()) for k in theta if k.startswith("color_decoder") and k in P_o)
         rep[f"{tag}_geo_max"], rep[f"{tag}_col_max"] = float(dg.max()), float(dc.max())
         rep.update({f"{tag}_loss_rel_first20": float(rel[:20].max()), f"{tag}_loss_rel_geo_stage": float(rel[:n_geo + 1].max()),
-                    f"{tag}_loss_rel_at_64": float(rel[60:70].max()), f"{tag}_loss_rel_at_128": float(rel[124:134].max()),
+                    f"{tag}_loss_rel_at_64": float(rel[60:70].max()), f"{tag}_loss_rel_at_128": float(rel[124:134].max()) if n_iters > 134 else None,
                     f"{tag}_loss_rel_max": float(rel.max()), f"{tag}_loss_rel_mean": float(rel.mean()),
                     f"{tag}_loss_rel_last": float(rel[-1]),
                     f"{tag}_geo_mean": float(dg.mean()), f"{tag}_geo_frac_gt_1e3": float((dg > 1e-3).float().mean()),
