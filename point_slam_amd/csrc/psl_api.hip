@@ -113,9 +113,10 @@ RenderWs carve_ws(float* base, int n_rays, int flags) {
   w.cnt = (int*)take(Pp);
   w.raw = take(Pp * 4);
   w.w = take(Pp * K);
-  w.cg = take(Pp * C);
+  w.dcc = take(Pp * C);
   w.cc = take(Pp * C);
   w.out3 = take(Pp * 4);
+  if (color) w.c_emb2 = take(Pp * EC);
   w.cw = take((int64_t)n_rays * S);
   w.ray_aux = take((int64_t)n_rays * 4);
   if (grad) {
@@ -372,11 +373,12 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
+namespace psl { extern int g_color_split; extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
   if (!strcmp(name, "knn")) { psl::g_knn_version = value; return PSL_OK; }
+  if (!strcmp(name, "color_split")) { psl::g_color_split = value; return PSL_OK; }
   if (!strcmp(name, "lazy_adam")) { psl::g_lazy_adam = value; return PSL_OK; }
   if (!strcmp(name, "track_fused")) { psl::g_track_fused = value; return PSL_OK; }
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }

@@ -260,6 +260,19 @@ struct ProfScope {
     }                                                                                                             \
   } while (0)
 
+// two launches under ONE armed event pair (split colour stage: k_nbr_* + k_trunk_*): the first launch takes the start event,
+// the last one the stop event, so that the class time spans both dispatches and the gap between them
+#define PSL_KLAUNCH2(kern, first, last, grid, block, lds, stream, ...)                                            \
+  do {                                                                                                            \
+    if (psl::g_prof_arm.armed) {                                                                                  \
+      hipEvent_t e0__ = (first) ? psl::g_prof_arm.start : nullptr, e1__ = (last) ? psl::g_prof_arm.stop : nullptr; \
+      if (last) psl::g_prof_arm.armed = false;                                                                    \
+      hipExtLaunchKernelGGL(kern, grid, block, lds, stream, e0__, e1__, 0, __VA_ARGS__);                          \
+    } else {                                                                                                      \
+      hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                            \
+    }                                                                                                             \
+  } while (0)
+
 // ---- internal launchers (defined in the .hip files) -------------------------
 int grid_build(psl_ctx* ctx, hipStream_t s);
 int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float* depth, const float* z_vals, const float* r_query,
@@ -302,12 +315,13 @@ struct RenderWs {
   int* cnt;          // [Ppad]
   float* raw;        // [Ppad][4]  rgb (post sigmoid/affine), occ (masked)
   float* w;          // [Ppad][8]  normalised interpolation weights
-  float* cg;         // [Ppad][32]
+  float* dcc;        // [Ppad][32]  dL/d(interpolated colour features), written by k_trunk_bwd, read by k_nbr_bwd
   float* cc;         // [Ppad][32]
   float* g_y;        // [Ppad][5][32]   geo post-activation
   float* c_y;        // [Ppad][5][128]  colour post-activation
   float* c_hin;      // [Ppad][5][128]  colour layer inputs h_1..h_5 (after +fc_c)
   float* c_emb;      // [Ppad][40]
+  float* c_emb2;     // [Ppad][40]  the same values in k_trunk_fwd's lane order: [g][sin f = 4 ks + g, ks = 0..4 | cos ...] (split colour stage)
   float* out3;       // [Ppad][4] pre-affine colour logits
   float* n_x;        // [Ppad][8][52]
   float* n_h1;       // [Ppad][8][128]

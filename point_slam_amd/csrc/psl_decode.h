@@ -306,6 +306,15 @@ __device__ __forceinline__ void worklist_role_wave(const AdamWorklist& wl, int i
 }
 
 
+// Colour-stage launch structure (psl_debug_option("color_split", v) / PSL_COLOR_SPLIT): 0 = always the fused 16-sample tile
+// kernels (k_decode_fwd2<true> / k_decode_bwd2<., true>), 2 = always the split kernels (k_nbr_* + k_trunk_*), 1 = by launch
+// size: the split pays once a launch holds clearly more tiles than the chip has CUs -- its four kernels each carry ~5 us of
+// dependent-load set-up and tail that the fused tile pays once (measured on one box, gpurun r06h / r06j: 5 000 samples fused
+// 48.2 + 46.6 us against 49.1 + 51.8 split; 25 000: 185 + 203 against 180 + 190; 125 000: 872 + 978 against 763 + 937)
+extern int g_color_split;
+constexpr int kSplitMinTiles = 384;
+inline bool color_split_on(int tiles) { return g_color_split == 2 || (g_color_split == 1 && tiles > kSplitMinTiles); }
+
 // ray-level arguments of the one-launch geometry-stage iteration (psl_decode_geo.hip)
 struct GeoIterRays {
   const int* active;            // [R] 1 = ray passed the depth filters (common.py:173-179, Mapper.py:507-514)
@@ -320,6 +329,7 @@ struct GeoIterRays {
 int blk_trace_begin(DecodeArgs& a, int grid, hipStream_t s);                                  // psl_api.hip
 int blk_trace_end(const DecodeArgs& a, const char* kernel, int grid, int color_tiles, int threads);
 #define PSL_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
+#define PSL_STAMPB(i, blk) do { if (a.dbg && (int)blockIdx.x == (blk) && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
 #ifdef PSL_FINE_STAMPS   // stamps inside the GEMM loops perturb scheduling: opt-in build (make EXTRA=-DPSL_FINE_STAMPS)
 #define PSL_STAMPF(i) PSL_STAMP(i)
 #else

@@ -497,6 +497,379 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   }
 }
 
+// ================================================================================================ split colour stage (round 6)
+// The fused colour tile above puts F_theta (43 % of a sample's FLOPs, wave-private: 16 (sample, neighbour) pairs per
+// wavefront) and the trunk (barrier-coupled: 16 samples per 8 wavefronts) into one 512-thread workgroup, so the unit of
+// load balance is the 16-sample tile: 5 000 samples = 313 tiles on 256 CUs, 57 CUs carry two and the launch takes their
+// 45 us while 199 CUs idle from 30 us on (profiles/r05_block_trace.txt).  Split:
+//   k_nbr_fwd   -- F_theta and the interpolation weights in units of ONE WAVEFRONT (16 pairs = 2 samples), four per workgroup,
+//                  three workgroups per CU (48 KiB of weight fragments in LDS each): 2 500 units spread over 1 024 SIMDs;
+//                  the one-wave geometry tiles ride in the same launch (four per workgroup, first in the grid).
+//   k_trunk_fwd -- the colour trunk per 16-sample tile, no neighbour phase: the tile's features come from `cc`.
+// Same products, same order of every sum as color_tile() except the 128 -> 3 output layer, which is K-split over the eight
+// wavefronts (each contracts the 16 hidden channels it holds in registers).
+constexpr int NBR_WG = 256;
+
+// one wavefront: pairs 16 u .. 16 u + 15 = samples 2 u, 2 u + 1.  Lane (pair rl, g); the four lanes of a pair repeat the
+// pair's scalar set-up (no LDS, no barrier except the one that publishes the weight fragments).
+template <bool RELPOS>
+__device__ __forceinline__ void nbr_unit_fwd(const DecodeArgs& a, const float* __restrict__ WF, float* smem, int u_in, int n_units, int sb) {
+  const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
+  PSL_STAMPB(50, sb);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool act = u_in < n_units;
+  const int u = min(u_in, n_units - 1);
+  const float* __restrict__ M = a.master;
+  const float* sWn = smem;
+  constexpr int f1 = ffirst(FL_N1);
+  // ---- set-up of this lane's pair: list entry, neighbour position, inverse-distance weight (decoder.py:143-160).  The list
+  // entry heads a chain of two dependent memory trips (I -> position / feature row): it is requested FIRST, the 12 KiB of
+  // weight-fragment DMA of this wave behind it (issued first, the DMA stood in the CU's one vector-memory queue in front of
+  // the latency-critical loads of all twelve resident wavefronts)
+  const int s = rl >> 3, k = rl & 7;
+  const int ps = 2 * u + s;                       // sample slot (< Ppad)
+  const int p = min(ps, a.P - 1);
+  const int i = a.ws.I[(size_t)p * K + k];
+  const int cnt_p = a.ws.cnt[p];
+  const SampleGeom sg = sample_geom(a, p);
+  sched_fence();
+  if (RELPOS) nbr_stage_dma<kNbrFrags>(WF, smem, wave, NBR_WG / 64, lane);
+  sched_fence();
+  const float4 q = a.pos[max(i, 0)];
+  f32x4 xf[2];
+  {
+    const float* frow = a.col_feats + (size_t)max(i, 0) * C + 4 * g;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(frow), v1 = *reinterpret_cast<const f32x4*>(frow + 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? v0[r] : 0.f; xf[1][r] = (i >= 0) ? v1[r] : 0.f; }
+  }
+  const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
+  float wgt = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+  wgt = wgt / fmaxf(group8_sum(wgt), 1e-12f);
+  const float rx = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f, ry = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f,
+              rz = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;
+  const bool has = cnt_p >= a.min_nn;
+  const size_t grow = (size_t)u * 16 + rl;        // row of the per-pair save buffers = sample slot * 8 + k
+  // Fourier features of the two sample positions for the trunk (decoder.py:8-37,411): 2 x 20 (sin, cos) pairs on the first 20
+  // of a sample's 32 lanes; stored after the barrier
+  float esn = 0.f, ecs = 0.f;
+  const int ef = k * 4 + g;
+  if (ef < ECF) fast_sincosf(fourier_phase(sg.x, sg.y, sg.z, a.Bcol, ECF, ef), esn, ecs);
+  PSL_STAMPB(51, sb);
+  if (RELPOS) lds_barrier_dma();                  // no global store in front of this barrier (see nbr_stage_dma)
+  PSL_STAMPB(52, sb);
+  if (act && g == 0) a.ws.w[grow] = wgt;
+  if (act && ef < ECF) {
+    // lane order of k_trunk_fwd: lane (sample, g) reads the ten values of frequencies 4 ks + g as one 40-byte run
+    float* e2 = a.ws.c_emb2 + (size_t)ps * EC + (ef & 3) * 10 + (ef >> 2);
+    e2[0] = esn; e2[5] = ecs;
+    if (a.ws.c_emb) { a.ws.c_emb[(size_t)ps * EC + ef] = esn; a.ws.c_emb[(size_t)ps * EC + ECF + ef] = ecs; }
+  }
+  f32x4 cc[2];
+  if constexpr (RELPOS) {
+    f32x4 afn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + j * 4 + 0, lane);
+    // F_theta input [sin(10) cos(10) | feat(32)] (decoder.py:371-378); this lane holds sin or cos of f = 2 ks + (g >> 1)
+    const float* __restrict__ Brel = M + MO(PI_C_BREL);
+    f32x4 xe; float xe4 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int f = 2 * ks + (g >> 1);
+      float sn, cs;
+      fast_sincosf(fourier_phase(rx, ry, rz, Brel, ERF, f), sn, cs);
+      const float v = (g & 1) ? cs : sn;
+      if (ks < 4) xe[ks] = v; else xe4 = v;
+      if (a.ws.n_x && act) a.ws.n_x[grow * NX + (g & 1) * ERF + f] = v;
+    }
+    if (a.ws.n_x && act) {
+      *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 4 * g) = xf[0];
+      *reinterpret_cast<f32x4*>(a.ws.n_x + grow * NX + ER + 16 + 4 * g) = xf[1];
+    }
+    PSL_STAMPB(53, sb);
+    f32x4 hid[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) hid[nt] = ldbias(WF, fbias(FL_N1), nt, g);
+    auto activate = [&](int nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hid[nt][r] = softplus100_nb(hid[nt][r]);
+      if (a.ws.n_h1 && act) *reinterpret_cast<f32x4*>(a.ws.n_h1 + grow * HC + nt * 16 + 4 * g) = hid[nt];
+    };
+    constexpr int f2 = ffirst(FL_N2);
+    f32x4 a0n, a1n;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      sched_fence();
+      const int half = st >> 2, qq = st & 3;
+      f32x4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = afn[j];
+      if (st < 7) {
+        const int h2 = (st + 1) >> 2, q2 = (st + 1) & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + (4 * h2 + j) * 4 + q2, lane);
+      } else {
+        a0n = ldsfrag(sWn, f2 + 0, lane); a1n = ldsfrag(sWn, f2 + 8 + 0, lane);
+      }
+      if (qq < 3) {
+        const f32x4 b = (qq == 0) ? xf[0] : (qq == 1 ? xf[1] : xe);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][r], b[r], hid[4 * half + j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hid[4 * half + j] = mfma16(af[j][0], xe4, hid[4 * half + j]);
+      }
+      if (half == 1) activate(qq);
+    }
+    PSL_STAMPB(54, sb);
+    f32x4 nf[2];
+    nf[0] = ldbias(WF, fbias(FL_N2), 0, g); nf[1] = ldbias(WF, fbias(FL_N2), 1, g);
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      sched_fence();
+      const f32x4 a0 = a0n, a1 = a1n;
+      if (qq < 7) { a0n = ldsfrag(sWn, f2 + qq + 1, lane); a1n = ldsfrag(sWn, f2 + 8 + qq + 1, lane); }
+      if (qq < 4) activate(4 + qq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { nf[0] = mfma16(a0[r], hid[qq][r], nf[0]); nf[1] = mfma16(a1[r], hid[qq][r], nf[1]); }
+    }
+    sched_fence();
+    PSL_STAMPB(55, sb);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      if (a.ws.n_out && act) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, nf[nt][r]));   // sum_k w_k F_theta(.)  (decoder.py:380-385)
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, xf[nt][r]));
+  }
+  if (act && k == 0) {       // one lane per (sample, g): the sample's colour features, fallback where it has too few neighbours
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
+      f32x4 c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r] = has ? cc[nt][r] : fb[r];
+      *reinterpret_cast<f32x4*>(a.ws.cc + (size_t)ps * C + nt * 16 + 4 * g) = c;
+    }
+  }
+  PSL_STAMPB(56, sb);
+}
+
+// grid: [0, geo_blocks) four one-wave geometry tiles each (the longest units start first), then four F_theta units each
+template <bool RELPOS>
+__global__ __launch_bounds__(NBR_WG, 3) void k_nbr_fwd(DecodeArgs a, const float* __restrict__ WF, int geo_blocks, int n_units) {
+  if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BlkTrace bt(a);
+  const int b = (int)blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (b < geo_blocks) {
+    const int p0 = (b * 4 + wave) * TILE;
+    // a geometry tile is one long dependent chain (its wave is the launch's critical path): it wins the issue arbitration
+    // against the F_theta wavefronts it shares a SIMD with
+    __builtin_amdgcn_s_setprio(3);
+    if (p0 < a.P) geo_tile<4>(a, WF, p0, false, false);
+  } else {
+    nbr_unit_fwd<RELPOS>(a, WF, smem, (b - geo_blocks) * 4 + wave, n_units, geo_blocks);
+  }
+  bt.done(a);
+}
+
+// ---- trunk: one 512-thread workgroup per tile of MT x 16 samples, wavefront w owns output columns 16 w .. 16 w + 15 of every
+// layer for all MT sub-tiles (one A fragment feeds MT MFMAs).
+//  * Weight fragments live in eight register slots; a slot is refilled with the NEXT layer's fragment right after the MFMAs
+//    that consumed it, so that the 80 KB of weights a tile needs per layer stream in under its MFMAs instead of in a burst in
+//    the epilogue (phase stamps of the fused tile: "epi" 2.4 k cycles per layer = eight wavefronts x 12 KB through the CU's one
+//    vector-memory path, next to 2.2 k cycles of MFMA).
+//  * MT = 2 where a CU would otherwise hold two 16-sample tiles (5 000 samples = 313 sub-tiles on 256 CUs: 57 double tiles +
+//    199 single ones, ONE workgroup per CU): two co-resident tiles took 17.5-20.8 us against 11.9 us for one
+//    (gpurun r06g block trace) -- they fetch every weight twice and meet at twice the barriers; the double tile fetches once.
+template <int MT> struct TrunkLdsT { static constexpr int oH = 0, oOut = 2 * MT * 8 * FRAG, total = oOut + 8 * MT * TILE * 4; };
+template <int MT>
+__device__ __forceinline__ void trunk_tile_fwd(const DecodeArgs& a, const float* __restrict__ WF, float* smem, int p0) {
+  using L = TrunkLdsT<MT>;
+  float* sH = smem + L::oH;            // [2][MT][8][64][4] hidden tiles, fragment order, double buffered
+  float* sOut = smem + L::oOut;        // [8][MT * 16][4] K-split partial colour logits
+  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
+  const int nt = __builtin_amdgcn_readfirstlane(t >> 6);
+  const float* __restrict__ M = a.master;
+  PSL_STAMP(0);
+  f32x4 w[8], c[2], bias, cbias;
+  // layer 0: embedding fragments in slots 0..3; slots 4..7 take layer 1's fragments 4..7 at once
+  {
+    constexpr int b0 = ffirst(FL_C0), b1 = ffirst(FL_C1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = ldfrag(WF, b0 + nt * 4 + q, lane);
+    c[0] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 0, lane); c[1] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 1, lane);
+    bias = ldbias(WF, fbias(FL_C0), nt, g); cbias = ldbias(WF, fbias(FL_CF0), nt, g);
+#pragma unroll
+    for (int q = 4; q < 8; ++q) w[q] = ldfrag(WF, b1 + nt * 8 + q, lane);
+  }
+  // the tile's interpolated colour features are the B operands of the fc_c products as they lie in `cc`; the Fourier features
+  // of the sample positions come from k_nbr_fwd in this lane's order (no dependent position chain in front of layer 0)
+  f32x4 ccb0[MT], ccb1[MT], esn[MT], ecs[MT];
+  float sn4[MT], cs4[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const size_t row = (size_t)(p0 + m * TILE + rl);
+    ccb0[m] = *reinterpret_cast<const f32x4*>(a.ws.cc + row * C + 4 * g);
+    ccb1[m] = *reinterpret_cast<const f32x4*>(a.ws.cc + row * C + 16 + 4 * g);
+    const float2* e2 = reinterpret_cast<const float2*>(a.ws.c_emb2 + row * EC + g * 10);
+    const float2 v0 = e2[0], v1 = e2[1], v2 = e2[2], v3 = e2[3], v4 = e2[4];
+    esn[m] = f32x4{v0.x, v0.y, v1.x, v1.y}; sn4[m] = v2.x;
+    ecs[m] = f32x4{v2.y, v3.x, v3.y, v4.x}; cs4[m] = v4.y;
+  }
+  const float ob0 = M[MO(PI_C_OUT + 1) + 0], ob1 = M[MO(PI_C_OUT + 1) + 1], ob2 = M[MO(PI_C_OUT + 1) + 2];
+  PSL_STAMP(7);
+  f32x4 hh[MT];
+  auto layer = [&](auto I_) {
+    constexpr int i = decltype(I_)::value;
+    constexpr int nxt = i < 4 ? kTrunkL[i < 4 ? i + 1 : 4] : FL_COUT;
+    constexpr int nq_n = kFLayers[nxt].ngroups;                         // fragments per output tile of the next layer
+    const int nbase = ffirst(nxt) + (i < 4 ? nt * nq_n : 0);            // slot s <- fragment nbase + s
+    const float* bufp = sH + ((i + 1) & 1) * MT * 8 * FRAG;             // the previous layer's hidden tiles
+    f32x4 acc_a[MT], acc_b[MT], u[MT];
+    f32x4 hq0[MT], hq1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      acc_a[m] = bias; acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f}; u[m] = cbias;
+      if (i != 0) {
+        hq0[m] = *reinterpret_cast<const f32x4*>(bufp + m * 8 * FRAG + lane * 4);
+        hq1[m] = *reinterpret_cast<const f32x4*>(bufp + m * 8 * FRAG + FRAG + lane * 4);
+      }
+    }
+    sched_fence();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mma4(u[m], c[0], ccb0[m]);
+    if (i == 0 || i == 3) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        mma4(acc_a[m], w[0], esn[m]);
+        mma4(acc_b[m], w[2], ecs[m]);
+        acc_a[m] = mfma16(w[1][0], sn4[m], acc_a[m]);
+        acc_b[m] = mfma16(w[3][0], cs4[m], acc_b[m]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) mma4(u[m], c[1], ccb1[m]);
+    sched_fence();
+    if constexpr (i < 4) {
+      c[0] = ldfrag(WF, ffirst(kTrunkF[i + 1]) + nt * 2 + 0, lane); c[1] = ldfrag(WF, ffirst(kTrunkF[i + 1]) + nt * 2 + 1, lane);
+      bias = ldbias(WF, fbias(kTrunkL[i + 1]), nt, g); cbias = ldbias(WF, fbias(kTrunkF[i + 1]), nt, g);
+    }
+    if constexpr (i == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = ldfrag(WF, nbase + q, lane);
+    }
+    if constexpr (i == 3) {       // hidden groups 4..7 of the skip layer go where its embedding fragments were
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = ldfrag(WF, ffirst(FL_C3) + nt * 12 + 8 + q, lane);
+    }
+    if (i != 0) {
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        sched_fence();
+        f32x4 h0[MT], h1[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          h0[m] = hq0[m]; h1[m] = hq1[m];
+          if (q < 6) {
+            hq0[m] = *reinterpret_cast<const f32x4*>(bufp + m * 8 * FRAG + (q + 2) * FRAG + lane * 4);
+            hq1[m] = *reinterpret_cast<const f32x4*>(bufp + m * 8 * FRAG + (q + 3) * FRAG + lane * 4);
+          }
+        }
+        const int s0 = (i == 3) ? (q < 4 ? 4 + q : q - 4) : q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) { acc_a[m] = mfma16(w[s0][r], h0[m][r], acc_a[m]); acc_b[m] = mfma16(w[s0 + 1][r], h1[m][r], acc_b[m]); }
+        sched_fence();
+        if (i < 4) { w[s0] = ldfrag(WF, nbase + s0, lane); w[s0 + 1] = ldfrag(WF, nbase + s0 + 1, lane); }
+        else if (s0 == 0) w[0] = ldfrag(WF, nbase + nt, lane);     // output layer, K-split: this wave's one fragment
+      }
+    }
+    sched_fence();
+    PSL_STAMP(10 + 3 * i);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 y;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { y[r] = softplus100_nb(acc_a[m][r] + acc_b[m][r]); hh[m][r] = y[r] + u[m][r]; }
+      if (a.ws.c_y) {
+        const size_t o = ((size_t)i * a.ws.Ppad + p0 + m * TILE + rl) * HC + nt * 16 + 4 * g;
+        *reinterpret_cast<f32x4*>(a.ws.c_y + o) = y;
+        if (a.ws.c_hin) *reinterpret_cast<f32x4*>(a.ws.c_hin + o) = hh[m];
+      }
+      if (i < 4) *reinterpret_cast<f32x4*>(sH + (i & 1) * MT * 8 * FRAG + m * 8 * FRAG + nt * FRAG + lane * 4) = hh[m];
+    }
+    if (i < 4) {
+      PSL_STAMP(10 + 3 * i + 1);
+      lds_barrier();
+      PSL_STAMP(10 + 3 * i + 2);
+    }
+  };
+  layer(std::integral_constant<int, 0>{});
+  layer(std::integral_constant<int, 1>{});
+  layer(std::integral_constant<int, 2>{});
+  layer(std::integral_constant<int, 3>{});
+  layer(std::integral_constant<int, 4>{});
+  // ---- output_linear 128 -> 3, K-split: this wave contracts the 16 hidden channels it holds (decoder.py:430-448)
+  {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 oa = {0.f, 0.f, 0.f, 0.f};
+      mma4(oa, w[0], hh[m]);
+      if (g == 0) *reinterpret_cast<f32x4*>(sOut + (nt * MT * TILE + m * TILE + rl) * 4) = oa;     // rows 0..2 of the padded tile
+    }
+    lds_barrier();
+    if (t < MT * TILE && p0 + t < a.P) {
+      const int pp = p0 + t;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const float* po = sOut + (w8 * MT * TILE + t) * 4;
+        r0 += po[0]; r1 += po[1]; r2 += po[2];
+      }
+      r0 += ob0; r1 += ob1; r2 += ob2;
+      a.ws.out3[(size_t)pp * 4 + 0] = r0; a.ws.out3[(size_t)pp * 4 + 1] = r1; a.ws.out3[(size_t)pp * 4 + 2] = r2;
+      if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
+        const float* A = a.affine;
+        const float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
+        const float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
+        const float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
+        r0 = q0; r1 = q1; r2 = q2;
+      }
+      if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
+      a.ws.raw[(size_t)pp * 4 + 0] = r0; a.ws.raw[(size_t)pp * 4 + 1] = r1; a.ws.raw[(size_t)pp * 4 + 2] = r2;
+    }
+    PSL_STAMP(26);
+  }
+}
+
+// workgroup b -> its tile: the first n2 workgroups take double tiles (32 samples), the rest single ones (see trunk_plan)
+struct TrunkPlan { int n2, n1; };
+TrunkPlan trunk_plan(int tiles) {      // tiles = 16-sample sub-tiles of the launch
+  constexpr int kCUs = 256;
+  if (tiles <= kCUs) return TrunkPlan{0, tiles};                      // one single tile per CU
+  if (tiles <= 2 * kCUs) return TrunkPlan{tiles - kCUs, 2 * kCUs - tiles};   // one workgroup per CU, as few double tiles as that takes
+  return TrunkPlan{tiles / 2, tiles & 1};                             // throughput regime: double tiles throughout
+}
+__global__ __launch_bounds__(WG, 2) void k_trunk_fwd(DecodeArgs a, const float* __restrict__ WF, int n2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BlkTrace bt(a);
+  const int b = (int)blockIdx.x;
+  if (b < n2) trunk_tile_fwd<2>(a, WF, smem, b * 2 * TILE);
+  else trunk_tile_fwd<1>(a, WF, smem, (2 * n2 + (b - n2)) * TILE);
+  bt.done(a);
+}
+
 // grid: [0, color_tiles) colour role (one tile per workgroup), then the geometry role: ONE WAVEFRONT per tile, each in a
 // workgroup of its own so that the tiles spread over all CUs (eight tiles in one workgroup would sit on one CU and share
 // its L1 port and its four SIMDs).  In the colour-stage launch the workgroup size is the colour role's 512: the seven
@@ -610,6 +983,37 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
     attr_set = true;
   }
   const bool color = a.flags & PSL_STAGE_COLOR;
+  if (color && color_split_on(tiles)) {
+    // split colour stage: F_theta + geometry role in wave-sized units, then the trunk per tile
+    const bool relpos = (a.flags & 0x10000) != 0;
+    const int n_units = tiles * (TILE / 2), f_blocks = (n_units + 3) / 4, geo_blocks = (tiles + 3) / 4;
+    const size_t lds1 = relpos ? sizeof(float) * kNbrFrags * FRAG : 0;
+    { int rc = blk_trace_begin(a, geo_blocks + f_blocks, s); if (rc) return rc; }
+    if (relpos) PSL_KLAUNCH2(k_nbr_fwd<true>, true, false, dim3(geo_blocks + f_blocks), dim3(NBR_WG), lds1, s, a, (const float*)ctx->wf, geo_blocks, n_units);
+    else PSL_KLAUNCH2(k_nbr_fwd<false>, true, false, dim3(geo_blocks + f_blocks), dim3(NBR_WG), lds1, s, a, (const float*)ctx->wf, geo_blocks, n_units);
+    PSL_LAUNCH_CHECK();
+    { int rc = blk_trace_end(a, "nbr_fwd", geo_blocks + f_blocks, -geo_blocks, NBR_WG); if (rc) return rc; }
+    const TrunkPlan tp = trunk_plan(tiles);
+    const size_t lds2 = sizeof(float) * (tp.n2 ? TrunkLdsT<2>::total : TrunkLdsT<1>::total);
+    { int rc = blk_trace_begin(a, tp.n2 + tp.n1, s); if (rc) return rc; }
+    PSL_KLAUNCH2(k_trunk_fwd, false, true, dim3(tp.n2 + tp.n1), dim3(WG), lds2, s, a, (const float*)ctx->wf, tp.n2);
+    PSL_LAUNCH_CHECK();
+    { int rc = blk_trace_end(a, "trunk_fwd", tp.n2 + tp.n1, tp.n2, WG); if (rc) return rc; }
+    if (dbg_on) {
+      unsigned long long h[64];
+      PSL_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[psl nbr_fwd P=%d] F unit: issue %llu wait+barrier %llu sincos %llu lin1 %llu lin2 %llu reduce+store %llu | total %llu\n", a.P, h[51] - h[50],
+              h[52] - h[51], h[53] - h[52], h[54] - h[53], h[55] - h[54], h[56] - h[55], h[56] - h[50]);
+      fprintf(stderr, "[psl trunk_fwd P=%d] set-up %llu |", a.P, h[7] - h[0]);
+      unsigned long long prev = h[7];
+      for (int i = 0; i < 5; ++i) {
+        if (i < 4) { fprintf(stderr, " L%d: mfma %llu epi %llu bar %llu |", i, h[10 + 3 * i] - prev, h[11 + 3 * i] - h[10 + 3 * i], h[12 + 3 * i] - h[11 + 3 * i]); prev = h[12 + 3 * i]; }
+        else { fprintf(stderr, " L4: mfma %llu |", h[22] - prev); prev = h[22]; }
+      }
+      fprintf(stderr, " epi+out %llu | total %llu\n", h[26] - prev, h[26] - h[0]);
+    }
+    return PSL_OK;
+  }
   { int rc = blk_trace_begin(a, color ? 2 * tiles : tiles, s); if (rc) return rc; }
   if (color)
     PSL_KLAUNCH(k_decode_fwd2<true>, dim3(2 * tiles), dim3(WG), lds, s, a, (const float*)ctx->wf, tiles);

@@ -33,3 +33,15 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=["by-size", "split"])
+def color_structure(request):
+    """Colour-stage launch structure of the decode kernels: "by-size" = the default (fused 16-sample tiles for small launches, the
+    split k_nbr_* / k_trunk_* kernels beyond 384 tiles), "split" = the split kernels at every size -- the reference fixtures are
+    small, so the split kernels meet them only when forced."""
+    from point_slam_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.psl_debug_option(b"color_split", 2 if request.param == "split" else 1))
+    yield request.param
+    _lib.check(L.psl_debug_option(b"color_split", 1))

@@ -85,7 +85,7 @@ def _render(w, ro, rd, gd, rq, stage="color", grads=None):
     return geo.grad, col.grad, theta
 
 
-def test_render_is_invariant_to_batch_splitting(world):
+def test_render_is_invariant_to_batch_splitting(world, color_structure):
     """10 000 rays in one launch (50 000 samples: 32-slot tiles, several rounds of workgroups) == the same rays in
     launches of 5 000 / 3 000 / 2 000 (other tile geometries).  Rays are independent in the reference."""
     w = world
@@ -106,7 +106,7 @@ def test_render_is_invariant_to_batch_splitting(world):
     assert float(valid.float().mean()) > 0.5
 
 
-def test_backward_is_linear_in_cotangents(world):
+def test_backward_is_linear_in_cotangents(world, color_structure):
     w = world
     ro, rd, gd, gc, rq = _rays(w, 5000, 12)
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -212,7 +212,7 @@ def oracle_world(world):
 
 
 @pytest.mark.parametrize("kind,n_pix", LOSS_PARITY_CASES)
-def test_loss_parity_vs_oracle_at_1m_points(world, oracle_world, kind, n_pix):
+def test_loss_parity_vs_oracle_at_1m_points(world, oracle_world, kind, n_pix, color_structure):
     """|L_hip - L_oracle| / |L_oracle| <= 1e-4 at 1 M points, for the geometry and the colour term separately, plus
     per-ray outputs and every gradient the iteration produces (SURVEY.md 8d parity protocol)."""
     from tests import parity_probe as PP

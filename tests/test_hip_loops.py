@@ -28,7 +28,7 @@ def _slam(cfg, cam, fx, dev, cfg_name):
 
 
 @pytest.mark.parametrize("case", ["mapper_iters_replica", "mapper_iters_scannet"])
-def test_map_iters_native_matches_reference_loop(case):
+def test_map_iters_native_matches_reference_loop(case, color_structure):
     from point_slam_amd import params as P_
     from point_slam_amd.slam import Frame
     dev = torch.device("cuda:0")
@@ -97,7 +97,7 @@ def test_map_iters_native_matches_reference_loop(case):
         assert rep["exposure_abs"] < 1e-4 and rep["exposure_mlp_abs"] < 2e-3
 
 
-def test_colour_refinement_native_matches_reference():
+def test_colour_refinement_native_matches_reference(color_structure):
     """HipSLAM's end-of-run refinement step (psl_map_iters with sel = all rows, geometry lr 0, colour lr / 10, decoder
     frozen, iteration 0 in stage 'geometry') vs the reference's optimize_map(color_refine=True) (fixture
     mapper_refine_replica, Mapper.py:706-720,427-430)."""
@@ -151,7 +151,7 @@ def test_refine_runs_five_passes_over_all_rows():
 
 
 @pytest.mark.parametrize("case", ["tracker_iters_tum", "tracker_iters_scannet"])
-def test_track_iters_native_matches_reference_loop(case):
+def test_track_iters_native_matches_reference_loop(case, color_structure):
     from point_slam_amd.slam import Frame
     dev = torch.device("cuda:0")
     fx = load_npz(case)

@@ -197,7 +197,7 @@ def _run_case(case, dev, grads):
 
 
 @pytest.mark.parametrize("case", RENDER_CASES)
-def test_render_forward_matches_reference(dev, case):
+def test_render_forward_matches_reference(dev, case, color_structure):
     with torch.no_grad():
         fx, cfg, dec, _, (d, v, c, valid) = _run_case(case, dev, grads=False)
     d, v, c, valid = d.cpu(), v.cpu(), c.cpu(), valid.cpu()
@@ -222,7 +222,7 @@ def test_render_forward_matches_reference(dev, case):
 
 # ------------------------------------------------------------------------------ render backward
 @pytest.mark.parametrize("case", RENDER_CASES)
-def test_render_backward_matches_reference(dev, case):
+def test_render_backward_matches_reference(dev, case, color_structure):
     fx, cfg, dec, (ro, rd, geo, col, ef), (d, v, c, valid) = _run_case(case, dev, grads=True)
     obj = (d * fx["w_d"].to(dev)).sum() + (c * fx["w_c"].to(dev)).sum() + (v * fx["w_v"].to(dev)).sum()
     obj.backward()
@@ -342,7 +342,7 @@ def test_adam_matches_torch(dev):
 
 
 # ------------------------------------------------------------------------------ drop-in tracker iteration
-def test_tracker_iteration_through_hip_renderer(dev):
+def test_tracker_iteration_through_hip_renderer(dev, color_structure):
     """The reference's Tracker.optimize_cam_in_batch step (golden: loss + pose after one Adam step), re-run with
     HipRenderer substituted for Renderer and everything else (sampling, loss, torch Adam) as in the reference."""
     import types

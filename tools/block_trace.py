@@ -26,7 +26,9 @@ def main(path, limit=None):
         span = (max(b[1] for b in B) - t0) / 100.0
         print(f"== {d['kernel']} P={d['P']} flags={d['flags']:#x} grid={d['grid']} colour tiles={ct} threads={d['threads']}: "
               f"first start -> last end {span:.1f} us")
-        for role, blocks in (("colour", B[:ct]), ("geometry", B[ct:])):
+        # colour tiles first (fused kernels, trunk kernels); ct < 0: -ct geometry-role workgroups FIRST (k_nbr_fwd / k_nbr_bwd)
+        roles = (("colour", B[:ct]), ("geometry", B[ct:])) if ct >= 0 else (("geometry", B[:-ct]), ("f_theta", B[-ct:]))
+        for role, blocks in roles:
             blocks = [b for b in blocks if b[0]]      # work-list workgroups of a launch leave no record
             if not blocks:
                 continue

@@ -63,7 +63,7 @@ EOF
       rm -f $O/${TAG}_blocks.raw
       PSL_DEBUG_BLOCKS=$PWD/$O/${TAG}_blocks.raw timeout 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 5 --warmup 5 > /dev/null 2>&1
       python tools/block_trace.py $O/${TAG}_blocks.raw > $O/${TAG}_block_trace.txt 2>&1; rm -f $O/${TAG}_blocks.raw
-      grep -A3 "P=5000 flags=0x1000d" $O/${TAG}_block_trace.txt | tail -8 ;;
+      grep -A4 "P=5000 flags=0x1000d" $O/${TAG}_block_trace.txt | tail -24 ;;
     trace)
       env PSL_BENCH_MARK=1 $(sp "$a2") timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$TAG -o $TAG -- python bench.py $(sp "$a1") > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof.err
       python tools/rocpd_stats.py $O/prof_$TAG/${TAG}_results.db --csv $O/${TAG}_kernel_trace_stats.csv --by-grid adam_lazy | grep -E "by-grid|^kernel|^[^,]*,[0-9]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+,[0-9.]+$" | head -26
