@@ -373,12 +373,13 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_color_split; extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
+namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
   if (!strcmp(name, "knn")) { psl::g_knn_version = value; return PSL_OK; }
   if (!strcmp(name, "color_split")) { psl::g_color_split = value; return PSL_OK; }
+  if (!strcmp(name, "wave_trunk")) { psl::g_wave_trunk_tiles = value; return PSL_OK; }
   if (!strcmp(name, "lazy_adam")) { psl::g_lazy_adam = value; return PSL_OK; }
   if (!strcmp(name, "track_fused")) { psl::g_track_fused = value; return PSL_OK; }
   if (!strcmp(name, "dw_fused")) { psl::g_dw_fused = value; return PSL_OK; }

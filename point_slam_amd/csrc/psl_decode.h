@@ -313,6 +313,10 @@ __device__ __forceinline__ void worklist_role_wave(const AdamWorklist& wl, int i
 // 48.2 + 46.6 us against 49.1 + 51.8 split; 25 000: 185 + 203 against 180 + 190; 125 000: 872 + 978 against 763 + 937)
 extern int g_color_split;
 constexpr int kSplitMinTiles = 384;
+// trunk of the split structure: one wavefront per tile (psl_trunk_wave.hip) from this many tiles on (PSL_WAVE_TRUNK / option
+// "wave_trunk": tiles from which it is used; 0 = never)
+extern int g_wave_trunk_tiles;
+inline bool wave_trunk_on(int tiles) { return g_wave_trunk_tiles > 0 && tiles >= g_wave_trunk_tiles; }
 inline bool color_split_on(int tiles) { return g_color_split == 2 || (g_color_split == 1 && tiles > kSplitMinTiles); }
 
 // ray-level arguments of the one-launch geometry-stage iteration (psl_decode_geo.hip)

@@ -24,6 +24,7 @@
 
 namespace psl {
 
+int launch_trunk_fwd_w(psl_ctx* ctx, const DecodeArgs& a, int tiles, bool last, hipStream_t s);   // psl_trunk_wave.hip
 constexpr int kNbrFrags = 48;     // fragments of F_theta's two layers (see NbrStage below)
 struct Fwd2Lds {
   static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oCc = 720, oH = oCc + 2 * FRAG,
@@ -993,6 +994,13 @@ int launch_decode_fwd2(psl_ctx* ctx, const DecodeArgs& a_in, hipStream_t s) {
     else PSL_KLAUNCH2(k_nbr_fwd<false>, true, false, dim3(geo_blocks + f_blocks), dim3(NBR_WG), lds1, s, a, (const float*)ctx->wf, geo_blocks, n_units);
     PSL_LAUNCH_CHECK();
     { int rc = blk_trace_end(a, "nbr_fwd", geo_blocks + f_blocks, -geo_blocks, NBR_WG); if (rc) return rc; }
+    if (wave_trunk_on(tiles)) {      // throughput regime: one wavefront per tile (psl_trunk_wave.hip)
+      { int rc = blk_trace_begin(a, (tiles + 3) / 4, s); if (rc) return rc; }
+      int rc = launch_trunk_fwd_w(ctx, a, tiles, true, s);
+      if (rc) return rc;
+      { int rc2 = blk_trace_end(a, "trunk_fwd_w", (tiles + 3) / 4, (tiles + 3) / 4, 256); if (rc2) return rc2; }
+      return PSL_OK;
+    }
     const TrunkPlan tp = trunk_plan(tiles);
     const size_t lds2 = sizeof(float) * (tp.n2 ? TrunkLdsT<2>::total : TrunkLdsT<1>::total);
     { int rc = blk_trace_begin(a, tp.n2 + tp.n1, s); if (rc) return rc; }

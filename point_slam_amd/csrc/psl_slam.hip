@@ -810,6 +810,7 @@ using namespace psl;
 namespace psl {
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 int g_color_split = env_flag("PSL_COLOR_SPLIT", 1);   // colour-stage launch structure: 0 fused tiles, 2 split kernels, 1 by launch size (psl_decode.h)
+int g_wave_trunk_tiles = env_flag("PSL_WAVE_TRUNK", 1024);   // split structure: trunk as one wavefront per tile from this many tiles on
 int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
 int g_track_fused = env_flag("PSL_TRACK_FUSED", 2);   // 2: k_track_mid inside the decode backward (TrackFuse); 1: its own launch; 0: the ten-launch iteration
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
