@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <mutex>
 #include "psl_common.h"
 
 namespace psl {
@@ -346,9 +347,13 @@ extern "C" int psl_keyframe_overlap_sync(const float* rays_o, const float* rays_
     }
   }
   // scratch for the poses and the answers: kept per device and grown on demand (a hipMalloc + hipFree pair per call cost
-  // two device-wide synchronisations per mapped frame)
+  // two device-wide synchronisations per mapped frame).  Process-lifetime, shared by every context and host thread of the
+  // process: the lock is held until this (synchronous) call has read its answers back, so a second thread can neither grow
+  // the buffer under a kernel in flight nor overwrite its poses (advisor, round 5).
   static float* g_dev[64] = {nullptr};
   static size_t g_cap[64] = {0};
+  static std::mutex g_mu;
+  std::lock_guard<std::mutex> lock(g_mu);
   int devid = 0;
   PSL_HIP(hipGetDevice(&devid));
   if (devid < 0 || devid >= 64) { set_error("psl_keyframe_overlap_sync: device %d", devid); return PSL_ERR_ARG; }

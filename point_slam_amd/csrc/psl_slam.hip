@@ -228,10 +228,17 @@ __global__ __launch_bounds__(1024) void k_tracker_loss(RayBufs b, int n, float w
   if (!handle_dynamic) {
     // tracking.handle_dynamic = False (Tracker.py:166-168; no shipped config): tmp = |gt - d|, mask = tmp < 10 * tmp.median()
     // (torch.median: the lower median) over the rays of the batch.  tmp goes through g_depth, which the loop below overwrites.
-    for (int i = threadIdx.x; i < n; i += blockDim.x) b.g_depth[i] = b.active[i] ? fabsf(b.gd[i] - b.depth[i]) : 0.f;
-    __syncthreads();
+    // A NaN among the batch's tmp makes torch's median NaN and the mask empty (tmp < NaN is False everywhere); the bit-pattern
+    // selection below would rank it as the largest key instead, so it is looked for first (advisor, round 5).
+    int any_nan = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float tmp = b.active[i] ? fabsf(b.gd[i] - b.depth[i]) : 0.f;
+      any_nan |= (tmp != tmp) ? 1 : 0;
+      b.g_depth[i] = tmp;
+    }
+    any_nan = __syncthreads_or(any_nan);
     const BlockStats st = block_lower_median(b.g_depth, b.active, n, false);
-    thr = st.cnt ? 10.0f * st.med : 0.f;
+    thr = (st.cnt && !any_nan) ? 10.0f * st.med : 0.f;
     __syncthreads();
   }
   double lg = 0.0, lc = 0.0;

@@ -97,12 +97,11 @@ class _NativeTransport:
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
             return int(t.item()) == 1
         # pre-init agreement (advisor r4): EVERY rank does everything psl_comm_init does in front of ncclCommInitRank -- dlopen of
-        # librccl + its symbols (ncclGetUniqueId on a scratch id exercises both) and the device buffers of the counts phase
-        # (psl_comm_reserve) -- and the ranks compare notes BEFORE anybody enters the communicator's rendezvous
-        scratch = C.create_string_buffer(128)
-        rc0 = L.psl_comm_unique_id(scratch)
-        if rc0 >= 0:
-            rc0 = L.psl_comm_reserve(npc.handle, self.world)
+        # librccl + the resolution of its symbols and the device buffers of the counts phase, all inside psl_comm_reserve --
+        # and the ranks compare notes BEFORE anybody enters the communicator's rendezvous.  Only rank 0 ever creates a unique
+        # id (advisor r5: every ncclGetUniqueId starts a bootstrap root -- a listening socket and a thread -- that is never
+        # torn down, and needs a usable network interface, i.e. can fail for reasons that have nothing to do with this rank)
+        rc0 = L.psl_comm_reserve(npc.handle, self.world)
         if not all_ok(rc0 >= 0):
             raise RuntimeError("native RCCL transport: librccl / device buffers unavailable on some rank"
                                + (": " + L.psl_last_error().decode() if rc0 < 0 else ""))
@@ -306,6 +305,8 @@ class FrameParallelSync:
             if self.merge == "owner":
                 # SURVEY.md 8e owner-writes: the change of the rank that created the point if it is among the contributors,
                 # else the lowest contributing rank's (seed-map points have no creator) -- one contributor's change, whole
+                if self._owner is not None and self._owner.shape[0] < geo.shape[0]:       # the store grew since the table was sized
+                    self._owner = torch.cat([self._owner, torch.full((geo.shape[0] - self._owner.shape[0],), -1, dtype=torch.int16, device=dev)])
                 own = self._owner[uniq] if self._owner is not None else torch.full_like(uniq, -1, dtype=torch.int16)
                 best = torch.full((uniq.shape[0],), 1 << 20, dtype=torch.int64, device=dev)
                 win = torch.zeros(uniq.shape[0], 64, device=dev)
@@ -338,8 +339,8 @@ class FrameParallelSync:
             theta[:self.n_color] = self.snap_theta + d / dist.get_world_size(self.group)
         # 1-2. new points
         creators: list = []
-        counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport, creators)
-        if creators and creators[0].numel():
+        counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport, creators if self.merge == "owner" else None)
+        if self.merge == "owner" and creators and creators[0].numel():     # the creator table only serves the owner-writes rule
             geo = npc.get_geo_feats()
             cap = max(getattr(npc, "_max_points", 0) or 0, geo.shape[0], self.n_base + int(creators[0].numel()))
             if self._owner is None or self._owner.shape[0] < cap:

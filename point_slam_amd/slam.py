@@ -176,8 +176,12 @@ class HipSLAM:
         """The same on the device, camera tensors in, camera tensor out (psl_pose_const_speed): one launch, no host copy of
         a pose -- what a closed track -> track loop calls once per frame."""
         out = torch.empty(7, device=self.device)
-        a = cam_prev.detach().float().contiguous()
-        b = cam_prev2.detach().float().contiguous() if cam_prev2 is not None else None
+        # the kernel dereferences these pointers: bring host tensors (what init_pose / camera_tensor_from_c2w return) and tensors
+        # of another device onto this one, and refuse anything that is not a camera tensor [qw qx qy qz tx ty tz]
+        a = cam_prev.detach().to(self.device, torch.float32).contiguous()
+        b = cam_prev2.detach().to(self.device, torch.float32).contiguous() if cam_prev2 is not None else None
+        if a.numel() != 7 or (b is not None and b.numel() != 7):
+            raise ValueError("init_pose_device: camera tensors have 7 elements (quaternion + translation)")
         _lib.check(_lib.lib().psl_pose_const_speed(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.stream_ptr()),
                    "psl_pose_const_speed")
         self._keep_pose = (a, b)

@@ -12,9 +12,11 @@ args = types.SimpleNamespace(gpus=1, steps=1, warmup=0, points=1_000_000, engine
 dev = torch.device("cuda:0")
 cfg, cam, slam, frames, cams0, every = B.build_world(args, 0, 1, dev)
 w = dict(cfg=cfg, cam=cam, slam=slam, frame=frames[0], dev=dev)
+import os as _os
+MODES = tuple(_os.environ.get("SAVE_PROBE_MODES", "no_grad,grad").split(","))
 for n in (1000, 5000, 25000):
     ro, rd, gd, gc, rq = _rays(w, n, 5)
-    for mode in ("no_grad", "grad"):
+    for mode in MODES:
         for rep in range(2):
             if rep == 1: _lib.check(_lib.lib().psl_profile_enable(slam.npc.handle, 1))
             for k in range(5):
