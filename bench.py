@@ -85,6 +85,10 @@ def parse():
     ap.add_argument("--fps-window", type=int, default=0,
                     help="long runs: frames/s of every window of this many frames of the timed pass (one device synchronisation per "
                          "window), next to the device-memory high-water mark -- the steady-state evidence behind the 20-frame headline")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip config.closed_loop / config.steady_state: two further runs of this script (100 closed-loop frames at "
+                         "the camera speed the base tracker holds; 500 open-loop frames with the frames/s of every 100-frame window), "
+                         "made after the timed passes so that the one line the driver keeps carries them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -551,6 +555,35 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def sub_records(args):
+    """Two further runs of this script, after the timed passes (the headline stream is open loop and 20
+    frames long; the line should also say what the loop does closed, and what a long run sustains):
+      closed_loop   100 frames, frame i starts from the constant-speed extrapolation of the tracker's own two previous estimates,
+                    mapping at the tracker's estimate, at the camera speed the base yaml's tracker budget holds (0.5 trajectory
+                    units = 1.4 cm per frame; at the headline's 5.6 cm per frame the 200 px x 20 it tracker diverges, DESIGN.md 5);
+      steady_state  500 open-loop frames of the headline stream: frames/s over the run and of every 100-frame window.
+    Each is a fresh process (its own world, the same seeds); neither touches `value`."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-kernel-timing", "--no-sub-records", "--mix", args.mix,
+            "--points", str(args.points), "--width", str(args.width), "--height", str(args.height), "--warmup", str(args.warmup)]
+
+    def run(extra, pick):
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=420)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            return pick(d)
+        except Exception as e:
+            return {"error": repr(e)}
+    closed = run(["--closed-loop", "--units-per-frame", "0.5", "--steps", "100"],
+                 lambda d: dict(frames=d["steps"], fps=d["value"], ate_rmse_cm=d["config"]["ate_rmse_cm"], ate_max_cm=d["config"]["ate_max_cm"],
+                                camera_speed="0.5 trajectory units (~1.4 cm) per frame", pose_loop=d["config"]["pose_loop"][:6]))
+    steady = run(["--steps", "500", "--fps-window", "100"],
+                 lambda d: dict(frames=d["steps"], fps=d["value"], fps_per_window=[w["fps"] for w in (d["config"]["fps_per_window"] or [])],
+                                fps_window_min=min([w["fps"] for w in (d["config"]["fps_per_window"] or [])], default=None),
+                                points_end=d["config"]["points_end"], device_used_mb=d["config"]["device_memory"]["device_used_mb"]))
+    return closed, steady
+
+
 def held_out_render_loss(slam, cfg, cam, frame, n_pix=4000, seed=5):
     """Mean |depth error| (m) and mean |colour error| of a render of `frame` at its ground-truth pose through the product path
     (HipRenderer.render_batch_ray -> psl_render_fwd): what the map looks like after an exchange, under either merge rule."""
@@ -886,6 +919,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(cfg, cam, args.points)
             except Exception as e:      # the baseline must never take the measured line down with it
                 out["cpu_baseline"] = {"error": repr(e)}
+        # only in the full default invocation (what the driver runs): development calls pass --no-cpu-baseline
+        if (world == 1 and not args.no_sub_records and not args.no_cpu_baseline and not args.track_only and not args.closed_loop
+                and not args.no_kernel_timing):
+            out["config"]["closed_loop"], out["config"]["steady_state"] = sub_records(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
