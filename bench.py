@@ -252,12 +252,14 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
         state.setdefault("map_log", []).append(dict(slam.last_map, frame=i))
         if world > 1 and (state["mapped"] % state["exchange_every"] == 0 or i in state.get("force_exchange_at_all", ())):
             # new points (cross-rank dedupe), features of shared rows and the colour decoder are reconciled
-            import time as _t
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
+            # timed by two events on the stream, read after the pass: no device synchronisation around the exchange (the host
+            # goes on enqueueing the next frame's tracking while the collectives run).  The exchange itself
+            # still synchronises where it must learn the sizes of the ragged blocks (dist.py).
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
             state["sync"].exchange(slam.npc, slam.theta)
-            torch.cuda.synchronize()
-            state.setdefault("exchange_s", []).append(_t.perf_counter() - t0)
+            ev[1].record()
+            state.setdefault("exchange_ev", []).append(ev)
         if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
             slam.keyframes.append(fr)
             if len(slam.keyframes) > 40:        # the reference keeps every keyframe on the CPU; bounded here
@@ -555,6 +557,50 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def pin_rank_to_cpus(local_rank, local_world, gpu_index):
+    """One process per GPU, eight Python hosts on one node: each rank keeps to its own cores -- those of its GPU's NUMA node
+    when the kernel says which that is (/sys/class/drm/card*/device/numa_node), split evenly among the ranks that share the
+    node; otherwise an even slice of what the process may run on.  Returns what was done (printed per rank in the line)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    how, cpus = "even slice of the allowed cores", None
+    try:
+        if gpu_index is not None:
+            import glob
+            import torch
+            bdf = torch.cuda.get_device_properties(gpu_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(gpu_index), "pci_bus_id") else None
+            nodes = {}
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                try:
+                    nodes[os.path.basename(os.path.realpath(d)).lower()] = int(open(os.path.join(d, "numa_node")).read())
+                except Exception:
+                    pass
+            node = None
+            if bdf:
+                node = next((v for k, v in nodes.items() if k.endswith(str(bdf).lower()[-7:])), None)
+            if node is not None and node >= 0:
+                txt = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+                ncpus = []
+                for part in txt.split(","):
+                    a, _, b = part.partition("-")
+                    ncpus += list(range(int(a), int(b or a) + 1))
+                ncpus = [c for c in ncpus if c in allowed]
+                n_nodes = max(len({v for v in nodes.values() if v >= 0}), 1)
+                per_node = max(local_world // n_nodes, 1)
+                k = local_rank % per_node
+                share = max(len(ncpus) // per_node, 1)
+                cpus, how = ncpus[k * share:(k + 1) * share], f"NUMA node {node} of the GPU, slice {k} of {per_node}"
+    except Exception:
+        cpus = None
+    if not cpus:
+        share = max(len(allowed) // max(local_world, 1), 1)
+        cpus = allowed[local_rank * share:(local_rank + 1) * share] or allowed
+    try:
+        os.sched_setaffinity(0, cpus)
+    except Exception as e:
+        how += f" (sched_setaffinity failed: {e!r})"
+    return dict(cpus=[cpus[0], cpus[-1]] if cpus else None, n=len(cpus), how=how)
+
+
 def sub_records(args):
     """Two further runs of this script, after the timed passes (the headline stream is open loop and 20
     frames long; the line should also say what the loop does closed, and what a long run sustains):
@@ -644,6 +690,10 @@ def main():
         junk = [torch.full((256 << 20,), 0x7F7F7F7F, dtype=torch.int32, device=dev) for _ in range(6)]
         torch.cuda.synchronize()
         del junk
+    affinity = None
+    if world > 1:
+        affinity = pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None if share else local_rank)
+        torch.set_num_threads(max(1, min(4, affinity["n"])))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -748,12 +798,13 @@ def main():
         state["sync"].exchange(slam.npc, slam.theta)
         torch.cuda.synchronize()
         t_ex = time.perf_counter() - t0
+        state["exchange_s"] = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in state.get("exchange_ev", [])]
         ex_ms = sorted(round(x * 1e3, 3) for x in state.get("exchange_s", []))
         try:
             loss_after = held_out_render_loss(slam, cfg, cam, frames[args.warmup + args.steps - 1])
         except Exception as e:
             loss_after = {"error": repr(e)}
-        mine = dict(rank=rank, device=str(dev), points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
+        mine = dict(rank=rank, device=str(dev), cpu_affinity=affinity, host_threads=torch.get_num_threads(), points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
                     added=state["added"], mapped=state["mapped"], final_exchange_ms=round(t_ex * 1e3, 3),
                     exchange_ms=[round(x * 1e3, 3) for x in state.get("exchange_s", [])],
                     exchange_ms_p50=ex_ms[len(ex_ms) // 2] if ex_ms else None, exchange_ms_p100=ex_ms[-1] if ex_ms else None,

@@ -509,6 +509,14 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     sDP[t - TILE * K - TILE - 32] = 0.f;
   }
   if (relpos && wave != 2 && wave != 7) wait_dma();     // phases of waves 0, 1, 3..6 issue no global store before this point
+  // Weight fragments of the trunk's first layer (i = 4), requested in front of the barrier; during the layers a slot is refilled
+  // with layer i - 1's fragment as soon as its MFMAs have issued (mapper instantiation; the pose-gradient one has no registers
+  // to hold them across a layer boundary and keeps loading at the layer's start: "pre" 2-4 k cycles per layer in its stamps)
+  f32x4 wq[8];
+  if constexpr (!PTSG) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, bfirst(BL_C4) + wave * 8 + q, lane);
+  }
   lds_barrier();
   PSL_STAMP(1);
 
@@ -538,9 +546,9 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       constexpr int BLf[5] = {BL_CF0, BL_CF1, BL_CF2, BL_CF3, BL_CF4};
       sched_fence_b();
       // this layer's weight fragments: hidden-part tile nt of W_i^T (8 groups), the two fc_c tiles for group nt
-      f32x4 wq[8], wc[2];
+      f32x4 wc[2];
       const int fb = bfirst(BLs[i]);
-      if (i > 0) {
+      if (PTSG && i > 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) wq[q] = ldfragb(WB, fb + nt * 8 + q, lane);
       }
@@ -583,6 +591,11 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) { ga = mfma16(wq[q][r], c0[r], ga); gb = mfma16(wq[q + 1][r], c1[r], gb); }
+          if (!PTSG && i > 1) {
+            sched_fence_b();
+            const int fn = bfirst(BLs[i > 1 ? i - 1 : 1]);
+            wq[q] = ldfragb(WB, fn + nt * 8 + q, lane); wq[q + 1] = ldfragb(WB, fn + nt * 8 + q + 1, lane);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) G[r] = ga[r] + gb[r];

@@ -28,8 +28,9 @@ int launch_trunk_fwd_w(psl_ctx* ctx, const DecodeArgs& a, int tiles, bool last, 
 constexpr int kNbrFrags = 48;     // fragments of F_theta's two layers (see NbrStage below)
 struct Fwd2Lds {
   static constexpr int oI = 0, oW = 128, oRel = 256, oPts = 640, oHas = 704, oCc = 720, oH = oCc + 2 * FRAG,
-                       total = oH + 2 * 8 * FRAG,     // 5.3 K floats = 21 KB
-                       oWn = total, total_nbr = oWn + kNbrFrags * FRAG;   // + F_theta's weight fragments: 69 KB
+                       oOut = oH + 2 * 8 * FRAG, oFb = oOut + 8 * TILE * 4,   // K-split partial colour logits; the fallback feature vector
+                       total = oFb + 32,              // 5.9 K floats = 23 KB
+                       oWn = total, total_nbr = oWn + kNbrFrags * FRAG;   // + F_theta's weight fragments: 71 KB
 };
 
 // F_theta's weights in LDS.  A wavefront uses every fragment of F_theta once per 16 pairs, eight (four) wavefronts of a
@@ -195,22 +196,29 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------ colour role
-// weights of trunk layer i for output tile nt: up to 12 fragments of W_i and 2 of the fc_c layer
-// (layer 3 has 12: its last four are requested once the four embedding fragments have been consumed, see below)
-struct TrunkW { f32x4 w[8]; f32x4 c[2]; f32x4 bias, cbias; };
 constexpr int kTrunkL[5] = {FL_C0, FL_C1, FL_C2, FL_C3, FL_C4};
 constexpr int kTrunkF[5] = {FL_CF0, FL_CF1, FL_CF2, FL_CF3, FL_CF4};
-template <int I>
-__device__ __forceinline__ void load_trunk(TrunkW& t, const float* __restrict__ WF, int nt, int lane, int g) {
-  constexpr int nq = kFLayers[kTrunkL[I]].ngroups;
-  const int base = ffirst(kTrunkL[I]) + nt * nq;
+// weight slots of a trunk wavefront (output tile nt): eight fragment slots, the two fc_c fragments, the two bias tiles
+struct TrunkRegs { f32x4 w[8], c[2], bias, cbias; };
+// layer 0's operands: embedding fragments in slots 0..3, fc_c.0, biases (requested as early as the caller can afford) ...
+__device__ __forceinline__ void trunk_prologue_a(TrunkRegs& R, const float* __restrict__ WF, int nt, int lane, int g) {
+  constexpr int b0 = ffirst(FL_C0);
 #pragma unroll
-  for (int q = 0; q < (nq < 8 ? nq : 8); ++q) t.w[q] = ldfrag(WF, base + q, lane);
-  t.c[0] = ldfrag(WF, ffirst(kTrunkF[I]) + nt * 2 + 0, lane);
-  t.c[1] = ldfrag(WF, ffirst(kTrunkF[I]) + nt * 2 + 1, lane);
-  t.bias = ldbias(WF, fbias(kTrunkL[I]), nt, g);
-  t.cbias = ldbias(WF, fbias(kTrunkF[I]), nt, g);
+  for (int q = 0; q < 4; ++q) R.w[q] = ldfrag(WF, b0 + nt * 4 + q, lane);
+  R.c[0] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 0, lane); R.c[1] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 1, lane);
+  R.bias = ldbias(WF, fbias(FL_C0), nt, g); R.cbias = ldbias(WF, fbias(FL_CF0), nt, g);
 }
+// ... and layer 1's fragments 4..7 into the slots layer 0 leaves empty
+__device__ __forceinline__ void trunk_prologue_b(TrunkRegs& R, const float* __restrict__ WF, int nt, int lane) {
+  constexpr int b1 = ffirst(FL_C1);
+#pragma unroll
+  for (int q = 4; q < 8; ++q) R.w[q] = ldfrag(WF, b1 + nt * 8 + q, lane);
+}
+
+template <int MT>
+__device__ __forceinline__ void trunk_layers_fwd(const DecodeArgs& a, const float* __restrict__ WF, float* sH, float* sOut, int p0, TrunkRegs& R,
+                                                 const f32x4 (&ccb0)[MT], const f32x4 (&ccb1)[MT], const f32x4 (&esn)[MT], const f32x4 (&ecs)[MT],
+                                                 const float (&sn4)[MT], const float (&cs4)[MT], float ob0, float ob1, float ob2);
 
 __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __restrict__ WF, float* smem, int p0) {
   using L = Fwd2Lds;
@@ -255,6 +263,8 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       sPts[s * 4 + 0] = sg.x; sPts[s * 4 + 1] = sg.y; sPts[s * 4 + 2] = sg.z; sPts[s * 4 + 3] = sg.r2;
       sHas[s] = (cnt_p >= a.min_nn) ? 1 : 0;
     }
+  } else if (t < TILE * K + C) {
+    smem[L::oFb + t - TILE * K] = a.fb_col[t - TILE * K];    // the fallback vector (decoder.py:386-388): a late global load at the reduction otherwise
   }
   lds_barrier_dma();
   PSL_STAMP(1);
@@ -265,7 +275,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     for (int j = 0; j < 4; ++j) afn[j] = ldsfrag(sWn, f1 + j * 4 + 0, lane);
   }
 
-  TrunkW tw;
+  TrunkRegs tw;
   // ---------------------------------------------------------------- phase F: colour features of the tile
   {
     const int row = 16 * wave + rl;            // (sample, neighbour) pair of this lane; 4 lanes (g) share a pair
@@ -355,7 +365,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       }
       sched_fence();
       PSL_STAMP(5);
-      load_trunk<0>(tw, WF, wave, lane, g);     // the trunk's first layer: in flight across the reduction and the barrier
+      trunk_prologue_a(tw, WF, wave, lane, g);  // the trunk's first layer: in flight across the reduction and the barrier
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         if (a.ws.n_out) *reinterpret_cast<f32x4*>(a.ws.n_out + grow * C + nt * 16 + 4 * g) = nf[nt];
@@ -363,7 +373,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         for (int r = 0; r < 4; ++r) cc[nt][r] = group8_sum(__fmul_rn(wgt, nf[nt][r]));   // sum_k w_k F_theta(.)  (decoder.py:380-385)
       }
     } else {
-      load_trunk<0>(tw, WF, wave, lane, g);
+      trunk_prologue_a(tw, WF, wave, lane, g);
       // plain interpolation sum_k w_k f[I_k] (decoder.py:380-385 without the neighbour MLP)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -374,7 +384,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
       const bool has = sHas[s] != 0;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 fb = *reinterpret_cast<const f32x4*>(a.fb_col + nt * 16 + 4 * g);      // decoder.py:386-388
+        const f32x4 fb = *reinterpret_cast<const f32x4*>(smem + L::oFb + nt * 16 + 4 * g);      // decoder.py:386-388
         f32x4 c;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[r] = has ? cc[nt][r] : fb[r];
@@ -388,9 +398,10 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
   PSL_STAMP(7);
 
   // ---------------------------------------------------------------- phase T: colour trunk, wave w = output tile w
+  // (the layers themselves are trunk_layers_fwd, shared with k_trunk_fwd: weight slots refilled under the MFMAs, K-split head)
   {
-    const int nt = wave;
-    const f32x4 ccb0 = *reinterpret_cast<const f32x4*>(sCc + lane * 4), ccb1 = *reinterpret_cast<const f32x4*>(sCc + FRAG + lane * 4);
+    trunk_prologue_b(tw, WF, wave, lane);
+    const f32x4 ccb0[1] = {*reinterpret_cast<const f32x4*>(sCc + lane * 4)}, ccb1[1] = {*reinterpret_cast<const f32x4*>(sCc + FRAG + lane * 4)};
     // Fourier features of the sample position: frequencies f = 4 ks + g, sin and cos (decoder.py:8-37,411)
     float sn[5], cs[5];
     {
@@ -405,96 +416,10 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
         }
       }
     }
-    const f32x4 esn = {sn[0], sn[1], sn[2], sn[3]}, ecs = {cs[0], cs[1], cs[2], cs[3]};
-    auto layer = [&](auto I_) {
-      constexpr int i = decltype(I_)::value;
-      const float* bufp = sH + ((i + 1) & 1) * 8 * FRAG;      // the previous layer's hidden tile
-      // three independent accumulator chains: even / odd k-groups of W_i h, and Wc_i c
-      f32x4 acc_a = tw.bias, acc_b = {0.f, 0.f, 0.f, 0.f}, u = tw.cbias;
-      f32x4 hq0, hq1;
-      if (i != 0) { hq0 = *reinterpret_cast<const f32x4*>(bufp + lane * 4); hq1 = *reinterpret_cast<const f32x4*>(bufp + FRAG + lane * 4); }
-      sched_fence();
-      mma4(u, tw.c[0], ccb0);
-      if (i == 0 || i == 3) {
-        mma4(acc_a, tw.w[0], esn);
-        mma4(acc_b, tw.w[2], ecs);
-        acc_a = mfma16(tw.w[1][0], sn[4], acc_a);
-        acc_b = mfma16(tw.w[3][0], cs[4], acc_b);
-      }
-      mma4(u, tw.c[1], ccb1);
-      if (i != 0) {
-        // slot of hidden group q: layer 3 keeps groups 0..3 in slots 4..7 and fetches groups 4..7 into slots 0..3, which
-        // its embedding fragments have just left
-        if (i == 3) {
-          sched_fence();
-          const int base = ffirst(FL_C3) + nt * 12;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) tw.w[q] = ldfrag(WF, base + 8 + q, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          sched_fence();
-          const f32x4 h0 = hq0, h1 = hq1;
-          if (q < 6) {
-            hq0 = *reinterpret_cast<const f32x4*>(bufp + (q + 2) * FRAG + lane * 4);
-            hq1 = *reinterpret_cast<const f32x4*>(bufp + (q + 3) * FRAG + lane * 4);
-          }
-          const int s0 = (i == 3) ? (q < 4 ? 4 + q : q - 4) : q;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { acc_a = mfma16(tw.w[s0][r], h0[r], acc_a); acc_b = mfma16(tw.w[s0 + 1][r], h1[r], acc_b); }
-        }
-      }
-      sched_fence();
-      PSL_STAMP(10 + 3 * i);
-      // the next layer's weights are requested now: their L2 latency elapses behind the epilogue and the barrier
-      if constexpr (i < 4) load_trunk<(i < 4 ? i + 1 : 4)>(tw, WF, nt, lane, g);
-      sched_fence();
-      f32x4 y, hh;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { y[r] = softplus100_nb(acc_a[r] + acc_b[r]); hh[r] = y[r] + u[r]; }
-      if (a.ws.c_y) {
-        const size_t o = ((size_t)i * a.ws.Ppad + p0 + rl) * HC + nt * 16 + 4 * g;
-        *reinterpret_cast<f32x4*>(a.ws.c_y + o) = y;
-        if (a.ws.c_hin) *reinterpret_cast<f32x4*>(a.ws.c_hin + o) = hh;
-      }
-      *reinterpret_cast<f32x4*>(sH + (i & 1) * 8 * FRAG + nt * FRAG + lane * 4) = hh;
-      PSL_STAMP(10 + 3 * i + 1);
-      lds_barrier();
-      PSL_STAMP(10 + 3 * i + 2);
-    };
-    layer(std::integral_constant<int, 0>{});
-    layer(std::integral_constant<int, 1>{});
-    layer(std::integral_constant<int, 2>{});
-    layer(std::integral_constant<int, 3>{});
-    layer(std::integral_constant<int, 4>{});
-    // ---- output_linear 128 -> 3 (one padded tile, wave 0) and the colour head (decoder.py:430-448)
-    if (wave == 0) {
-      const float* buf = sH;     // layer 4 wrote buffer 0
-      f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
-      constexpr int fo = ffirst(FL_COUT);
-#pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        mma4(oa, ldfrag(WF, fo + q, lane), *reinterpret_cast<const f32x4*>(buf + q * FRAG + lane * 4));
-        mma4(ob, ldfrag(WF, fo + q + 1, lane), *reinterpret_cast<const f32x4*>(buf + (q + 1) * FRAG + lane * 4));
-      }
-      if (g == 0 && p0 + rl < a.P) {
-        const int p = p0 + rl;
-        float r0 = (oa[0] + ob[0]) + M[MO(PI_C_OUT + 1) + 0];
-        float r1 = (oa[1] + ob[1]) + M[MO(PI_C_OUT + 1) + 1];
-        float r2 = (oa[2] + ob[2]) + M[MO(PI_C_OUT + 1) + 2];
-        a.ws.out3[(size_t)p * 4 + 0] = r0; a.ws.out3[(size_t)p * 4 + 1] = r1; a.ws.out3[(size_t)p * 4 + 2] = r2;
-        if (a.flags & PSL_HAS_AFFINE) {  // out @ rot + trans (decoder.py:433-436)
-          const float* A = a.affine;
-          const float q0 = r0 * A[0] + r1 * A[3] + r2 * A[6] + A[9];
-          const float q1 = r0 * A[1] + r1 * A[4] + r2 * A[7] + A[10];
-          const float q2 = r0 * A[2] + r1 * A[5] + r2 * A[8] + A[11];
-          r0 = q0; r1 = q1; r2 = q2;
-        }
-        if (!(a.flags & PSL_NO_SIGMOID)) { r0 = sigmoidf(r0); r1 = sigmoidf(r1); r2 = sigmoidf(r2); }
-        a.ws.raw[(size_t)p * 4 + 0] = r0; a.ws.raw[(size_t)p * 4 + 1] = r1; a.ws.raw[(size_t)p * 4 + 2] = r2;
-      }
-      PSL_STAMP(26);
-    }
+    const f32x4 esn[1] = {f32x4{sn[0], sn[1], sn[2], sn[3]}}, ecs[1] = {f32x4{cs[0], cs[1], cs[2], cs[3]}};
+    const float sn4[1] = {sn[4]}, cs4[1] = {cs[4]};
+    const float ob0 = M[MO(PI_C_OUT + 1) + 0], ob1 = M[MO(PI_C_OUT + 1) + 1], ob2 = M[MO(PI_C_OUT + 1) + 2];
+    trunk_layers_fwd<1>(a, WF, sH, smem + L::oOut, p0, tw, ccb0, ccb1, esn, ecs, sn4, cs4, ob0, ob1, ob2);
   }
 }
 
@@ -702,17 +627,9 @@ __device__ __forceinline__ void trunk_tile_fwd(const DecodeArgs& a, const float*
   const int nt = __builtin_amdgcn_readfirstlane(t >> 6);
   const float* __restrict__ M = a.master;
   PSL_STAMP(0);
-  f32x4 w[8], c[2], bias, cbias;
-  // layer 0: embedding fragments in slots 0..3; slots 4..7 take layer 1's fragments 4..7 at once
-  {
-    constexpr int b0 = ffirst(FL_C0), b1 = ffirst(FL_C1);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = ldfrag(WF, b0 + nt * 4 + q, lane);
-    c[0] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 0, lane); c[1] = ldfrag(WF, ffirst(FL_CF0) + nt * 2 + 1, lane);
-    bias = ldbias(WF, fbias(FL_C0), nt, g); cbias = ldbias(WF, fbias(FL_CF0), nt, g);
-#pragma unroll
-    for (int q = 4; q < 8; ++q) w[q] = ldfrag(WF, b1 + nt * 8 + q, lane);
-  }
+  TrunkRegs R;
+  trunk_prologue_a(R, WF, nt, lane, g);
+  trunk_prologue_b(R, WF, nt, lane);
   // the tile's interpolated colour features are the B operands of the fc_c products as they lie in `cc`; the Fourier features
   // of the sample positions come from k_nbr_fwd in this lane's order (no dependent position chain in front of layer 0)
   f32x4 ccb0[MT], ccb1[MT], esn[MT], ecs[MT];
@@ -729,6 +646,20 @@ __device__ __forceinline__ void trunk_tile_fwd(const DecodeArgs& a, const float*
   }
   const float ob0 = M[MO(PI_C_OUT + 1) + 0], ob1 = M[MO(PI_C_OUT + 1) + 1], ob2 = M[MO(PI_C_OUT + 1) + 2];
   PSL_STAMP(7);
+  trunk_layers_fwd<MT>(a, WF, sH, sOut, p0, R, ccb0, ccb1, esn, ecs, sn4, cs4, ob0, ob1, ob2);
+}
+
+// the five trunk layers and the colour head of a tile of MT x 16 samples: shared by k_trunk_fwd and the fused colour tile
+template <int MT>
+__device__ __forceinline__ void trunk_layers_fwd(const DecodeArgs& a, const float* __restrict__ WF, float* sH, float* sOut, int p0, TrunkRegs& R,
+                                                 const f32x4 (&ccb0)[MT], const f32x4 (&ccb1)[MT], const f32x4 (&esn)[MT], const f32x4 (&ecs)[MT],
+                                                 const float (&sn4)[MT], const float (&cs4)[MT], float ob0, float ob1, float ob2) {
+  const int t = threadIdx.x, lane = t & 63, rl = lane & 15, g = lane >> 4;
+  const int nt = __builtin_amdgcn_readfirstlane(t >> 6);
+  f32x4 (&w)[8] = R.w;
+  f32x4 (&c)[2] = R.c;
+  f32x4& bias = R.bias;
+  f32x4& cbias = R.cbias;
   f32x4 hh[MT];
   auto layer = [&](auto I_) {
     constexpr int i = decltype(I_)::value;
