@@ -624,6 +624,14 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
     }
   }
   PSL_STAMP(17);
+  // F_theta's saved hidden activations of this wave's rows (HBM: the forward wrote them): requested in front of the two barriers
+  // of the dL/dc reduction instead of behind them (the activation step waited 6-10 k cycles for them, phase stamps r06s)
+  f32x4 h1v[8];
+  if (relpos) {
+    const size_t grow0 = (size_t)p0 * K + 16 * wave + rl;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) h1v[it] = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow0 * HC + it * 16 + 4 * g);
+  }
   lds_barrier();
   {   // 512 threads, 512 elements [it][lane][r]: sum over the waves, mask samples without neighbours
     const int e = t;
@@ -706,17 +714,14 @@ __device__ __forceinline__ void color_tile_bwd(const DecodeArgs& a, const Bwd2Ou
       // dH1^T[hid][row] = W2^T d_nf^T (linear2.weight [32][128]): 8 hidden tiles x 2 k-groups, walked as four steps of
       // four tiles; the fragments of step + 1 and -- from the start -- the saved hidden activations h1 of this wave's
       // rows (HBM: written by the forward kernel) are in flight while the MFMAs of a step issue.
-      f32x4 dh[8], h1v[8];
+      f32x4 dh[8];
       constexpr int b2 = bfirst(BL_N2);
       constexpr int b1 = bfirst(BL_N1);
       f32x4 wn[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) wn[j] = ldsfragb(sWn, b2 + j * 2 + 0, lane);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        h1v[it] = *reinterpret_cast<const f32x4*>(a.ws.n_h1 + grow * HC + it * 16 + 4 * g);
-      }
+      for (int it = 0; it < 8; ++it) dh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < 4; ++st) {       // st = 2 * half + q
         sched_fence_b();

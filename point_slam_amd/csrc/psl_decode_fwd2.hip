@@ -394,31 +394,34 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     }
   }
   PSL_STAMP(6);
+  // In front of the barrier that closes phase F -- a wavefront that finished its F_theta rows early waits there for the slowest
+  // one (stamps: ~6 k cycles for wave 0 of a tile that shares its CU) --: layer 1's fragments 4..7 are requested and the Fourier
+  // features of the sample positions (decoder.py:8-37,411: frequencies f = 4 ks + g, sin and cos; they need phase 0 only) are
+  // evaluated.  Both stood at the head of layer 0 behind the barrier (its "mfma" stamp: 7 k cycles against 2.5 k for a layer).
+  trunk_prologue_b(tw, WF, wave, lane);
+  float sn[5], cs[5];
+  {
+    const float x = sPts[rl * 4], y = sPts[rl * 4 + 1], z = sPts[rl * 4 + 2];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int f = 4 * ks + g;
+      fast_sincosf(fourier_phase(x, y, z, a.Bcol, ECF, f), sn[ks], cs[ks]);
+      if (wave == 0 && a.ws.c_emb) {
+        a.ws.c_emb[(size_t)(p0 + rl) * EC + f] = sn[ks];
+        a.ws.c_emb[(size_t)(p0 + rl) * EC + ECF + f] = cs[ks];
+      }
+    }
+  }
+  const float ob0 = M[MO(PI_C_OUT + 1) + 0], ob1 = M[MO(PI_C_OUT + 1) + 1], ob2 = M[MO(PI_C_OUT + 1) + 2];
   lds_barrier();
   PSL_STAMP(7);
 
   // ---------------------------------------------------------------- phase T: colour trunk, wave w = output tile w
   // (the layers themselves are trunk_layers_fwd, shared with k_trunk_fwd: weight slots refilled under the MFMAs, K-split head)
   {
-    trunk_prologue_b(tw, WF, wave, lane);
     const f32x4 ccb0[1] = {*reinterpret_cast<const f32x4*>(sCc + lane * 4)}, ccb1[1] = {*reinterpret_cast<const f32x4*>(sCc + FRAG + lane * 4)};
-    // Fourier features of the sample position: frequencies f = 4 ks + g, sin and cos (decoder.py:8-37,411)
-    float sn[5], cs[5];
-    {
-      const float x = sPts[rl * 4], y = sPts[rl * 4 + 1], z = sPts[rl * 4 + 2];
-#pragma unroll
-      for (int ks = 0; ks < 5; ++ks) {
-        const int f = 4 * ks + g;
-        fast_sincosf(fourier_phase(x, y, z, a.Bcol, ECF, f), sn[ks], cs[ks]);
-        if (wave == 0 && a.ws.c_emb) {
-          a.ws.c_emb[(size_t)(p0 + rl) * EC + f] = sn[ks];
-          a.ws.c_emb[(size_t)(p0 + rl) * EC + ECF + f] = cs[ks];
-        }
-      }
-    }
     const f32x4 esn[1] = {f32x4{sn[0], sn[1], sn[2], sn[3]}}, ecs[1] = {f32x4{cs[0], cs[1], cs[2], cs[3]}};
     const float sn4[1] = {sn[4]}, cs4[1] = {cs[4]};
-    const float ob0 = M[MO(PI_C_OUT + 1) + 0], ob1 = M[MO(PI_C_OUT + 1) + 1], ob2 = M[MO(PI_C_OUT + 1) + 2];
     trunk_layers_fwd<1>(a, WF, sH, smem + L::oOut, p0, tw, ccb0, ccb1, esn, ecs, sn4, cs4, ob0, ob1, ob2);
   }
 }
