@@ -284,7 +284,7 @@ def pmc_traffic(mix):
     """HBM bytes per launch of each kernel class from the PMC pass of the same command (tools/pmc_traffic.sh: separate
     rocprofv3 --pmc runs for FETCH_SIZE and WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md applied there);
     rocprofv3 cannot run inside the timed process, so the figures are read from the committed summary."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{mix}.json")
         if not os.path.exists(path):
             continue

@@ -153,7 +153,7 @@ def test_decode_kernels_fit_their_register_budget_without_scratch():
         pytest.skip("hipcc not installed")
     from tools import kernel_resources as KR
     seen = {}
-    for f in ("psl_decode_fwd2.hip", "psl_decode_bwd2.hip", "psl_decode_geo.hip"):
+    for f in ("psl_decode_fwd2.hip", "psl_decode_bwd2.hip", "psl_decode_geo.hip", "psl_trunk_wave.hip"):
         for k in KR.resources(os.path.join(KR.CSRC, f)):
             seen[k["name"]] = k
             assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
@@ -161,6 +161,12 @@ def test_decode_kernels_fit_their_register_budget_without_scratch():
     assert len(two_per_cu) == 3
     for k in two_per_cu:
         assert k["vgpr_count"] + k["agpr_count"] <= 128 and k["max_flat_workgroup_size"] == 512, k
+    # the split colour stage (round 6): three four-wavefront workgroups per CU for the F_theta kernels and three wavefronts per
+    # SIMD for the wave-per-tile trunk (<= 168 registers), one 512-thread trunk workgroup per CU (<= 256)
+    three = [k for n, k in seen.items() if ("k_nbr_fwd" in n or "k_nbr_bwd" in n or "k_trunk_fwd_w" in n)]
+    assert len(three) == 7 and all(k["vgpr_count"] + k["agpr_count"] <= 168 for k in three), [(k["name"], k["vgpr_count"]) for k in three]
+    one = [k for n, k in seen.items() if ("k_trunk_fwdE" in n or "k_trunk_bwdILb" in n)]
+    assert len(one) == 3 and all(k["vgpr_count"] + k["agpr_count"] <= 256 for k in one)
 
 
 def test_kernel_resources_parses_metadata():

@@ -16,25 +16,54 @@ import sys
 # One symbol serves the tracker's and the mapper's colour-stage forward: they are told apart by the work-item count of the
 # TRACKER's launch, which tools/pmc_probe.py writes to gpurun_out/pmc_probe_meta.json (base mix: 126 x 512 = 64 512).
 TRACK_ITEMS = [64512]
+TRACK_TILES = [63]         # 16-sample tiles of the tracker's launch (pmc_probe_meta.json: track_rays)
 
 
 def _is_track(g):
     return g == TRACK_ITEMS[0]
 
 
+def _split_items(tiles):
+    """work-item counts of the split colour-stage kernels for a launch of `tiles` 16-sample tiles (psl_decode_fwd2.hip)"""
+    nbr = ((tiles + 3) // 4 + (tiles * 8 + 3) // 4) * 256
+    if tiles <= 256:
+        trunk = tiles * 512
+    elif tiles <= 512:
+        trunk = 256 * 512
+    else:
+        trunk = (tiles // 2 + (tiles & 1)) * 512
+    return dict(nbr=nbr, trunk=trunk, trunk_w=((tiles + 3) // 4) * 256)
+
+
+def _trk(kind):
+    return lambda g: g == _split_items(TRACK_TILES[0])[kind]
+
+
+# (substring, predicate on the work-item count, class, member): a class launch of the SPLIT colour stage is two kernels (members
+# "nbr" and "trunk"); its bytes per launch are the SUM of its members' means
 CLASS_OF = [
-    ("decode_fwd2ILb1", lambda g: not _is_track(g), "decode_fwd"),
-    ("decode_fwd2ILb1", lambda g: True, "decode_fwd_track"),
-    ("decode_fwd2ILb0", lambda g: True, "decode_fwd_geo"),
-    ("2ILb0ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd"),
-    ("2ILb1ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_track"),
-    ("2ILb0ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo"),
-    ("2ILb1ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo_track"),
-    ("k_geo_iter", lambda g: True, "geo_iter"),
-    ("k_dwE", lambda g: True, "dw_gemm"),
-    ("AdamRowsSeg", lambda g: True, "adam"),
-    ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn"),
-    ("k_map_ray_fused", lambda g: True, "map_ray"),
+    ("decode_fwd2ILb1", lambda g: not _is_track(g), "decode_fwd", "fused"),
+    ("decode_fwd2ILb1", lambda g: True, "decode_fwd_track", "fused"),
+    ("decode_fwd2ILb0", lambda g: True, "decode_fwd_geo", "fused"),
+    ("2ILb0ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd", "fused"),
+    ("2ILb1ELb1EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_track", "fused"),
+    ("2ILb0ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo", "fused"),
+    ("2ILb1ELb0EEEvNS_10DecodeArgsENS_7Bwd2Out", lambda g: True, "decode_bwd_geo_track", "fused"),
+    ("k_nbr_fwd", _trk("nbr"), "decode_fwd_track", "nbr"),
+    ("k_nbr_fwd", lambda g: True, "decode_fwd", "nbr"),
+    ("k_trunk_fwd_w", _trk("trunk_w"), "decode_fwd_track", "trunk"),
+    ("k_trunk_fwd_w", lambda g: True, "decode_fwd", "trunk"),
+    ("k_trunk_fwdE", _trk("trunk"), "decode_fwd_track", "trunk"),
+    ("k_trunk_fwdE", lambda g: True, "decode_fwd", "trunk"),
+    ("k_trunk_bwdILb1E", lambda g: True, "decode_bwd_track", "trunk"),
+    ("k_trunk_bwdILb0E", lambda g: True, "decode_bwd", "trunk"),
+    ("k_nbr_bwdILb1E", lambda g: True, "decode_bwd_track", "nbr"),
+    ("k_nbr_bwdILb0E", lambda g: True, "decode_bwd", "nbr"),
+    ("k_geo_iter", lambda g: True, "geo_iter", "fused"),
+    ("k_dwE", lambda g: True, "dw_gemm", "fused"),
+    ("AdamRowsSeg", lambda g: True, "adam", "fused"),
+    ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn", "fused"),
+    ("k_map_ray_fused", lambda g: True, "map_ray", "fused"),
 ]
 DOUBLE_FETCH = {"geo_iter", "decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
                 "dw_gemm", "adam"}
@@ -53,14 +82,15 @@ def read(path, counter):
             g = int(float(grid))
         except ValueError:
             g = 0
-        for sub, pred, cls in CLASS_OF:
+        for sub, pred, cls, member in CLASS_OF:
             if sub in name and pred(g):
                 n, mean = int(parts[2]), float(parts[3])
-                a = out.setdefault(cls, [0, 0.0])
+                a = out.setdefault(cls, {}).setdefault(member, [0, 0.0])
                 a[0] += n
                 a[1] += mean * n
                 break
-    return {k: v[1] / v[0] for k, v in out.items() if v[0]}
+    # bytes per CLASS launch: the members' means added up (a member is launched once per class launch)
+    return {k: sum(v[1] / v[0] for v in m.values() if v[0]) for k, m in out.items()}
 
 
 def main():
@@ -69,6 +99,7 @@ def main():
         try:
             meta_probe = json.load(open(sys.argv[5]))
             TRACK_ITEMS[0] = int(meta_probe["track_fwd_items"])
+            TRACK_TILES[0] = (5 * int(meta_probe["track_rays"]) + 15) // 16
         except Exception:
             meta_probe = None
     fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")

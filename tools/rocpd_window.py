@@ -19,6 +19,10 @@ def short(name):
                 "k_decode_bwd2ILb1ELb0"):
         if key in n:
             return key.replace("ILb", "<").replace("ELb", ",") + ">"
+    for key in ("k_nbr_fwdILb1E", "k_nbr_fwdILb0E", "k_trunk_fwd_w", "k_trunk_fwdE", "k_trunk_bwdILb0E", "k_trunk_bwdILb1E", "k_nbr_bwdILb0ELb1E",
+                "k_nbr_bwdILb0ELb0E", "k_nbr_bwdILb1ELb1E", "k_nbr_bwdILb1ELb0E"):       # the split colour stage (round 6)
+        if key in n:
+            return key.rstrip("E").replace("ILb", "<").replace("ELb", ",") + (">" if "ILb" in key else "")
     if "psl" in n:
         i = n.find("psl")
         return n[i:i + 40]
