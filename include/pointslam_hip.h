@@ -411,7 +411,10 @@ int psl_profile_enable(psl_ctx* ctx, int on);
 int64_t psl_knn_candidates(psl_ctx* ctx);
 /* run-time A/B switches for tests and profiling: "knn" 0 = by launch size, 1 = one wavefront per sample, 2 = one per
  * ray; "lazy_adam" 0 = dense Adam sweep over every selected feature row, 1 (default) = lazy replay (psl_map_iters);
- * "track_fused" 0 = separate per-ray kernels in psl_track_iters, 1 (default) = fused for batches <= 1024 rays */
+ * "track_fused" 0 = separate per-ray kernels in psl_track_iters, 1 (default) = fused for batches <= 1024 rays;
+ * "color_split" launch structure of the colour-stage decode (decoder.py:341-449): 0 = fused 16-sample tiles, 2 = split F_theta /
+ * trunk kernels, 1 (default) = split beyond 384 tiles; "wave_trunk" = tiles from which the split structure's trunk forward runs
+ * one wavefront per tile (default 1024, 0 = never).  Results are the same to fp32 rounding of one sum order (the colour head) */
 int psl_debug_option(const char* name, int value);
 int psl_profile_classes(void);
 const char* psl_profile_name(int i);
