@@ -207,6 +207,9 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
     return PSL_ERR_UNSUPPORTED;
   }
   if (cfg->max_points <= 0 || cfg->max_query_radius <= 0.f) { set_error("psl_create: bad capacity/radius"); return PSL_ERR_ARG; }
+  if (cfg->max_points > kMaxPointsScatter) {          // psl_decode2.h: gradient rows are addressed by 32-bit byte offsets
+    set_error("psl_create: max_points %d exceeds %d", cfg->max_points, kMaxPointsScatter); return PSL_ERR_ARG;
+  }
   PSL_HIP(hipSetDevice(device));
   psl_ctx* c = new psl_ctx();
   memset(c, 0, sizeof(*c));

@@ -19,6 +19,7 @@ constexpr int EG = 93;  // geometry Fourier size (sin only)   (decoder.py:99-104
 constexpr int EGP = 96; // ... padded to a multiple of 4 for the MFMA k-step
 constexpr int ECF = 20; // colour Fourier frequencies (sin+cos -> 40) (decoder.py:302-306)
 constexpr int EC = 40;
+constexpr int kMaxPointsScatter = 1 << 25;   // the gradient scatters address a row by a 32-bit byte offset (row * 128 B): psl_decode2.h
 constexpr int ERF = 10; // rel-pos Fourier frequencies (sin+cos -> 20) (decoder.py:314-315)
 constexpr int ER = 20;
 constexpr int NX = ER + C;  // neighbour-MLP input width 52 (decoder.py:316-317)

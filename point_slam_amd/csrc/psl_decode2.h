@@ -79,6 +79,9 @@ struct ScatterLds { float dc[TILE * C]; float w[TILE * K]; int row[TILE * K]; };
 // 14 k cycles of the one-launch geometry iteration's 58 k (its phase stamps).  Now a lane owns one channel and the FOUR
 // neighbour slots 4 half .. 4 half + 3 of every sample: the rows / weights of a sample's slots are one 16-byte LDS read each,
 // four samples (12 reads) are requested together, and the sixteen atomics of the group issue back to back.
+// Round 6: a slot used to cost ~17 instructions on the lone wavefront of a geometry tile (64-bit row address, a nested branch for the
+// work-list tag): the rows are addressed as a 32-bit BYTE offset from the uniform base (psl_create bounds the capacity to 2^25 rows
+// for exactly this) and the tags are written once per list entry by the lanes that hold the lists.
 __device__ __forceinline__ void scatter_interp_rows(ScatterLds& L, float* __restrict__ g_feat, unsigned char* __restrict__ touched,
                                                     const f32x4 (&dc)[2], const float (&w)[K], const int (&dst)[K]) {
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
@@ -89,9 +92,16 @@ __device__ __forceinline__ void scatter_interp_rows(ScatterLds& L, float* __rest
     *reinterpret_cast<float4*>(L.w + rl * K + 4) = make_float4(w[4], w[5], w[6], w[7]);
     *reinterpret_cast<int4*>(L.row + rl * K) = make_int4(dst[0], dst[1], dst[2], dst[3]);
     *reinterpret_cast<int4*>(L.row + rl * K + 4) = make_int4(dst[4], dst[5], dst[6], dst[7]);
+    if (touched) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (dst[k] >= 0) touched[dst[k]] = 1;
+    }
   }
   wave_lds_sync();
   const int ch = lane & 31, half = lane >> 5;
+  char* __restrict__ base = reinterpret_cast<char*>(g_feat);
+  const unsigned ch4 = 4u * (unsigned)ch;
 #pragma unroll
   for (int s0 = 0; s0 < TILE; s0 += 4) {
     int4 rows[4];
@@ -110,12 +120,8 @@ __device__ __forceinline__ void scatter_interp_rows(ScatterLds& L, float* __rest
       const int r4[4] = {rows[j].x, rows[j].y, rows[j].z, rows[j].w};
       const float w4[4] = {ws[j].x, ws[j].y, ws[j].z, ws[j].w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (r4[k] >= 0) {
-          atomic_add_f32(&g_feat[(size_t)r4[k] * C + ch], w4[k] * dv[j]);
-          if (touched && ch == 0) touched[r4[k]] = 1;
-        }
-      }
+      for (int k = 0; k < 4; ++k)
+        if (r4[k] >= 0) atomic_add_f32(reinterpret_cast<float*>(base + ((unsigned)r4[k] * (4u * C) + ch4)), w4[k] * dv[j]);
     }
   }
 }
@@ -140,7 +146,7 @@ __device__ __forceinline__ void scatter_pair_rows(float* tile /*[16][32] per-wav
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (row[j] >= 0) atomic_add_f32(&g_feat[(size_t)row[j] * C + ch], v[j]);
+      if (row[j] >= 0) atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(g_feat) + ((unsigned)row[j] * (4u * C) + 4u * (unsigned)ch)), v[j]);
   }
   wave_lds_sync();
 }

@@ -49,37 +49,43 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
   }
   const int cnt_p = a.ws.cnt[p];
   const SampleGeom sg = sample_geom(a, p);
-  float w[K];
+  // The Fourier matrix columns of this lane and the first weight fragments depend on nothing: they are requested behind the
+  // lists, so that the sine phase below runs while the positions and feature rows (the second dependent trip) are in flight
+  const float* __restrict__ Bg = M + MO(PI_G_B);
+  float Bv[6][4][3];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float4 q = a.pos[max(nb[k], 0)];
-    const float D = (nb[k] >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-    w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
-  }
-  const float wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
-  const float inv = fmaxf(wsum, 1e-12f);
-#pragma unroll
-  for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
-  const bool has = cnt_p >= a.min_nn;     // has_neighbors (decoder.py:150)
-  PSL_STAMP(1);
-  f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    if ((k & 3) == 0) sched_fence();
-    const float* row = a.geo_feats + (size_t)max(nb[k], 0) * C + 4 * g;
-    const f32x4 f0 = *reinterpret_cast<const f32x4*>(row), f1 = *reinterpret_cast<const f32x4*>(row + 16);
+  for (int q = 0; q < 6; ++q)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      cg[0][r] = __fadd_rn(cg[0][r], __fmul_rn(w[k], f0[r]));
-      cg[1][r] = __fadd_rn(cg[1][r], __fmul_rn(w[k], f1[r]));
+      const int f = min(16 * q + 4 * g + r, EG - 1);
+      Bv[q][r][0] = Bg[f]; Bv[q][r][1] = Bg[EG + f]; Bv[q][r][2] = Bg[2 * EG + f];
     }
-  }
-  {
-    const f32x4 fb0 = *reinterpret_cast<const f32x4*>(a.fb_geo + 4 * g), fb1 = *reinterpret_cast<const f32x4*>(a.fb_geo + 16 + 4 * g);
+  sched_fence();
+  float4 qp[K];
+  f32x4 f0[K], f1[K];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
+  for (int k = 0; k < K; ++k) {
+    qp[k] = a.pos[max(nb[k], 0)];
+    const float* row = a.geo_feats + (size_t)max(nb[k], 0) * C + 4 * g;
+    f0[k] = *reinterpret_cast<const f32x4*>(row); f1[k] = *reinterpret_cast<const f32x4*>(row + 16);
   }
-  pin(cg[0]); pin(cg[1]);      // see psl_device.h: the interpolation must not be sunk behind the sine phase
+  const f32x4 fb0 = *reinterpret_cast<const f32x4*>(a.fb_geo + 4 * g), fb1 = *reinterpret_cast<const f32x4*>(a.fb_geo + 16 + 4 * g);
+  sched_fence();
+  PSL_STAMP(1);
+  // ---- Fourier features sin(2 pi p . B) (decoder.py:8-37), channel 16 q + 4 g + r
+  f32x4 eg[6];
+  {
+    const float x2 = __fmul_rn(TWO_PI, sg.x), y2 = __fmul_rn(TWO_PI, sg.y), z2 = __fmul_rn(TWO_PI, sg.z);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = fast_sinf(fmaf(z2, Bv[q][r][2], fmaf(y2, Bv[q][r][1], __fmul_rn(x2, Bv[q][r][0]))));   // = fourier_phase
+        eg[q][r] = (16 * q + 4 * g + r < EG) ? v : 0.f;
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) pin(eg[q]);
   sched_fence();
   PSL_STAMP(2);
 #pragma unroll
@@ -88,17 +94,30 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
     if (kGeo.s[st].f1 >= 0) W1[st] = ldfrag(WF, kGeo.s[st].f1, lane);
   }
   sched_fence();
-  // ---- Fourier features sin(2 pi p . B) (decoder.py:8-37), channel 16 q + 4 g + r
-  const float* __restrict__ Bg = M + MO(PI_G_B);
-  f32x4 eg[6];
+  // ---- inverse-distance weights (decoder.py:152-160), interpolation (:162-171)
+  float w[K];
 #pragma unroll
-  for (int q = 0; q < 6; ++q)
+  for (int k = 0; k < K; ++k) {
+    const float D = (nb[k] >= 0) ? dist2(qp[k].x, qp[k].y, qp[k].z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
+    w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+  }
+  const float wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+  const float inv = fmaxf(wsum, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < K; ++k) w[k] = w[k] / inv;
+  const bool has = cnt_p >= a.min_nn;     // has_neighbors (decoder.py:150)
+  f32x4 cg[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int f = min(16 * q + 4 * g + r, EG - 1);
-      const float v = fast_sinf(fourier_phase(sg.x, sg.y, sg.z, Bg, EG, f));
-      eg[q][r] = (16 * q + 4 * g + r < EG) ? v : 0.f;
+      cg[0][r] = __fadd_rn(cg[0][r], __fmul_rn(w[k], f0[k][r]));
+      cg[1][r] = __fadd_rn(cg[1][r], __fmul_rn(w[k], f1[k][r]));
     }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { cg[0][r] = has ? cg[0][r] : fb0[r]; cg[1][r] = has ? cg[1][r] : fb1[r]; }
+  pin(cg[0]); pin(cg[1]);
+  sched_fence();
   PSL_STAMP(3);
   // ---- five blocks: h = relu(W_i h + b_i) + (Wc_i c + bc_i); the embedding is re-attached after block 2
   f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
