@@ -30,7 +30,7 @@ constexpr int GI_TILE = 15;     // samples per wavefront: three rays
 __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* __restrict__ WF, const float* __restrict__ WB,
                                               const GeoIterRays& gr, float* g_geo, const int* __restrict__ row_map,
                                               unsigned char* t_geo, int tile, ScatterLds& sl) {
-  constexpr int GEO_AHEAD = 4;
+  constexpr int GEO_AHEAD = 6;
   const int lane = threadIdx.x & 63, rl = lane & 15, g = lane >> 4;
   const int p0 = tile * GI_TILE;
   const bool slot = rl < GI_TILE;
@@ -226,8 +226,10 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
     suffix += gw[s] * wq[s];
   }
   docc = live ? docc : 0.f;        // d_occ flows for masked samples too (straight-through of the -100 write)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lg += __shfl_xor(lg, o); lcnt += __shfl_xor(lcnt, o); }
+  // the three head lanes (0, 5, 10) hold the tile's terms: summed in the order the xor butterfly over the wavefront gave lane 0,
+  // (ray 0 + ray 2) + ray 1, without its twelve dependent 64-bit shuffles
+  lg = (readlane_d(lg, 0) + readlane_d(lg, 10)) + readlane_d(lg, 5);
+  lcnt = (readlane_d(lcnt, 0) + readlane_d(lcnt, 10)) + readlane_d(lcnt, 5);
   if (lane == 0 && gr.loss_acc) {
     double* acc = gr.loss_acc + 4 * (blockIdx.x & (kLossSlots - 1));
     if (lg != 0.0) atomicAdd(&acc[0], lg);

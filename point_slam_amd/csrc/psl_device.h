@@ -133,6 +133,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// a double of a given lane, wave-uniform
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l), hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // hardware float atomic add (no CAS loop)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
