@@ -269,7 +269,7 @@ extern "C" void psl_destroy(psl_ctx* c) {
   (void)hipFree(c->pos); (void)hipFree(c->spos); (void)hipFree(c->cell_of); (void)hipFree(c->cell_start);
   (void)hipFree(c->cell_fill); (void)hipFree(c->coarse); (void)hipFree(c->scan_tmp); (void)hipFree(c->bounds); (void)hipFree(c->meta);
   (void)hipFree(c->wf); (void)hipFree(c->wb); (void)hipFree(c->wf_index);
-  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
+  (void)hipFree(c->wb_index); (void)hipFree(c->d_counter); (void)hipFree(c->d_small); (void)hipFree(c->d_expo); if (c->trk_pref) (void)hipFree(c->trk_pref); (void)hipFree(c->knn_cand); (void)hipFree(c->adam_rows); if (c->adam_tab) (void)hipFree(c->adam_tab); if (c->touched) (void)hipFree(c->touched); if (c->loss_acc) (void)hipFree(c->loss_acc); if (c->img_hist) (void)hipFree(c->img_hist);
   if (c->dw_slabs) (void)hipFree(c->dw_slabs);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 4; ++i) if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);

@@ -169,6 +169,8 @@ struct psl_ctx {
   double* loss_acc = nullptr; int loss_acc_cap = 0;   // per-iteration loss sums of psl_map_iters: [iteration][kLossSlots][4]
   float* fwd_zero64 = nullptr;   // psl_map_iters, ray stage inside the backward: the colour-stage forward clears the backward's accumulators
   const void* track_fuse = nullptr;   // psl_track_iters (<= 1024 rays): TrackFuse* handed to launch_decode_bwd2 -- the tracker's ray stage inside the backward
+  const void* track_pose = nullptr;   // psl_track_iters: TrackPose* handed to knn_rays -- the pose step of the previous iteration in the k-NN launch's prologue (psl_pose.h)
+  float* trk_pref = nullptr; size_t trk_pref_cap = 0;   // camera-frame rays, sensor samples and depth masks of all iterations of a psl_track_iters call + the second pose / Adam buffer
   const void* ray_fuse = nullptr; const void* ray_wl = nullptr;   // ... RayFuse* / AdamWorklist* handed to launch_decode_bwd2
   float* d_small;        // 64 floats: dB_rel / exposure-affine accumulators
   float* d_expo;         // per-frame exposure scratch: affines [64][12], hidden activations [64][128], d(affine) [64][12]

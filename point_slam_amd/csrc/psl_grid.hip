@@ -15,6 +15,7 @@
 //     (decoder.py:157,367; neural_point.py:210-213).
 #include <cstdlib>
 #include "psl_common.h"
+#include "psl_pose.h"
 #include "psl_device.h"
 
 namespace psl {
@@ -527,7 +528,79 @@ __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* _
 // <U, MINW>: records in flight per lane and the wavefronts per SIMD the register budget is cut for.  <8, 5> (81 VGPRs, six resident) is the
 // latency shape of the small launches; <4, 8> (64 VGPRs: a third more queries resident per CU) is the default from 5 000
 // queries on, where the chip is filled several times over (PSL_KNN_FLAT_LARGE, see knn_rays)
-template <int U, int MINW>
+// The pose step of the tracker's previous iteration, by every workgroup of the k-NN launch (TrackPose, psl_pose.h).  The ray
+// gradients are reduced exactly as k_track_pre does it with one ray per thread of 1 024: "virtual wavefront" vw = rays 64 vw .. 64 vw + 63
+// is summed by a butterfly, the wavefront totals are added in order by one thread, which then steps the pose on private copies.
+__device__ __forceinline__ void track_pose_prologue(const TrackPose& tp, float (*red)[12], float* s_pose) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (!tp.do_step) {
+    if (tid < 7) s_pose[tid] = tp.pose_in[tid];
+    __syncthreads();
+    return;
+  }
+  const int nw = min((tp.n + 63) >> 6, 16);
+  for (int vw = w; vw < nw; vw += 4) {
+    float acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+    const int r = 64 * vw + lane;
+    if (r < tp.n) {
+      // g_rays_o = sum_s dp_s ; g_rays_d = sum_s z_s dp_s  (k_ray_grad)
+      float go[3] = {0.f, 0.f, 0.f}, gd3[3] = {0.f, 0.f, 0.f};
+      const float gt = tp.gd_prev[r];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float4 g = tp.dp[r * S + s];
+        if (tp.dp2) { const float4 g2 = tp.dp2[r * S + s]; g.x += g2.x; g.y += g2.y; g.z += g2.z; }
+        const float z = sample_z(gt, s, tp.near_s, tp.far_s);
+        go[0] += g.x; go[1] += g.y; go[2] += g.z;
+        gd3[0] += z * g.x; gd3[1] += z * g.y; gd3[2] += z * g.z;
+      }
+      const float d0 = tp.dirs_prev[r * 3], d1 = tp.dirs_prev[r * 3 + 1], d2 = tp.dirs_prev[r * 3 + 2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        acc[a * 3 + 0] += d0 * gd3[a]; acc[a * 3 + 1] += d1 * gd3[a]; acc[a * 3 + 2] += d2 * gd3[a];   // dL/dR[a][k]
+        acc[9 + a] += go[a];                                                                          // dL/dT[a]
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) red[vw][j] = acc[j];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float G[3][3], gT[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][a * 3 + k]; G[a][k] = t; }
+      float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][9 + a]; gT[a] = t;
+    }
+    float pose[7], mv[14];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) pose[j] = tp.pose_in[j];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) mv[j] = tp.adam_in[j];
+    pose_adam(G, gT, pose, mv, tp.step, tp.lr_T, tp.lr_q, &tp.bias);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s_pose[j] = pose[j];
+    if (blockIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) tp.pose_out[j] = pose[j];
+#pragma unroll
+      for (int j = 0; j < 14; ++j) tp.adam_out[j] = mv[j];
+    }
+  }
+  __syncthreads();
+}
+
+template <int U, int MINW, bool POSE>
 __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                        const int* __restrict__ cell_start,
                                                        const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -536,8 +609,11 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
                                                        float r_fixed, float r2_fixed, float near_s, float far_s, int n_rays,
                                                        int* __restrict__ I_out, int* __restrict__ cnt_out,
                                                        unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse,
-                                                       int trace) {
+                                                       int trace, TrackPose tp) {
   __shared__ FlatLds lds[4];
+  __shared__ float s_red[POSE ? 16 : 1][12];
+  __shared__ float s_pose[8];
+  if constexpr (POSE) track_pose_prologue(tp, s_red, s_pose);
   const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (p >= n_rays * S) return;
   const unsigned long long t0 = trace ? clock64() : 0ull;
@@ -548,8 +624,19 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
   float r, r2;
   if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
   float qx, qy, qz;
-  sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
-               rays_d[ray * 3 + 2], zq, qx, qy, qz);
+  if constexpr (POSE) {
+    // get_rays_from_uv with the stepped pose (ray_setup_one, psl_slam.hip): the same expressions
+    float q[4] = {s_pose[0], s_pose[1], s_pose[2], s_pose[3]}, R[3][3], o[3] = {s_pose[4], s_pose[5], s_pose[6]}, d[3];
+    quat_to_rot(q, R);
+    const float d0 = tp.dirs[ray * 3], d1 = tp.dirs[ray * 3 + 1], d2 = tp.dirs[ray * 3 + 2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
+    if (si == 0 && lane < 3) { tp.rays_o[ray * 3 + lane] = o[lane]; tp.rays_d[ray * 3 + lane] = d[lane]; }
+    sample_point(o[0], o[1], o[2], d[0], d[1], d[2], zq, qx, qy, qz);
+  } else {
+    sample_point(rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2], rays_d[ray * 3], rays_d[ray * 3 + 1],
+                 rays_d[ray * 3 + 2], zq, qx, qy, qz);
+  }
   u64 mine;
   unsigned long long n_cand = 0;
   int n_pass = 0;
@@ -896,14 +983,19 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     static int large_from = -2;
     if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : 5000; }
     unsigned long long* cand = (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr;   // one atomic per query: only while measured
-    if (large_from >= 0 && n_rays * S >= large_from)
-      PSL_KLAUNCH((k_knn_rays_flat<4, 8>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+    if (!ctx->track_pose && large_from >= 0 && n_rays * S >= large_from)
+      PSL_KLAUNCH((k_knn_rays_flat<4, 8, false>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                          rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4);
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TrackPose{});
+    else if (ctx->track_pose)     // psl_track_iters, batches <= 1 024 rays: the pose step of the previous iteration in the prologue
+      PSL_KLAUNCH((k_knn_rays_flat<8, 5, true>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4,
+                         *static_cast<const TrackPose*>(ctx->track_pose));
     else
-      PSL_KLAUNCH((k_knn_rays_flat<8, 5>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
+      PSL_KLAUNCH((k_knn_rays_flat<8, 5, false>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
                          rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4);
+                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TrackPose{});
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <vector>
 #include "psl_decode.h"
+#include "psl_pose.h"
 
 namespace psl {
 
@@ -14,21 +15,6 @@ int render_fwd_impl(psl_ctx* ctx, const psl_render_args* a, hipStream_t s, bool 
 int render_bwd_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, hipStream_t s);
 int geo_iter_impl(psl_ctx* ctx, const psl_render_args* a, const psl_render_grads* g, const int* active, double* loss_acc,
                   const AdamWorklist* wl, hipStream_t s, bool repack);
-
-// quad2rotation (src/common.py:225-248), same operation order
-__device__ __forceinline__ void quat_to_rot(const float* q, float R[3][3]) {
-  float qr = q[0], qi = q[1], qj = q[2], qk = q[3];
-  float two_s = 2.0f / (((qr * qr + qi * qi) + qj * qj) + qk * qk);
-  R[0][0] = 1.f - two_s * (qj * qj + qk * qk);
-  R[0][1] = two_s * (qi * qj - qk * qr);
-  R[0][2] = two_s * (qi * qk + qj * qr);
-  R[1][0] = two_s * (qi * qj + qk * qr);
-  R[1][1] = 1.f - two_s * (qi * qi + qk * qk);
-  R[1][2] = two_s * (qj * qk - qi * qr);
-  R[2][0] = two_s * (qi * qk - qj * qr);
-  R[2][1] = two_s * (qj * qk + qi * qr);
-  R[2][2] = 1.f - two_s * (qi * qi + qj * qj);
-}
 
 struct FrameDev {            // one RGB-D frame resident in HBM
   const float* depth;        // [H][W]
@@ -66,10 +52,12 @@ __device__ __forceinline__ void ray_setup_one(int i, const psl_cam_intr& cam, in
   int w = W1 - W0;
   int u = W0 + idx % w, v = H0 + idx / w;
   float d0 = ((float)u - cam.cx) / cam.fx, d1 = -((float)v - cam.cy) / cam.fy, d2 = -1.0f;
+  if (b.rays_d) {      // (null: camera-frame part only -- k_track_rays_all; the tracker's k-NN launch turns the directions)
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    b.rays_d[i * 3 + a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
-    b.rays_o[i * 3 + a] = T[a];
+    for (int a = 0; a < 3; ++a) {
+      b.rays_d[i * 3 + a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
+      b.rays_o[i * 3 + a] = T[a];
+    }
   }
   size_t px = (size_t)v * cam.W + u;
   float dep = fr.depth[px];
@@ -292,57 +280,6 @@ __global__ void k_map_loss_finalize(const double* __restrict__ acc, int n_iters,
   loss_out[4 * it + 3] = (float)cnt;
 }
 
-// bias corrections of Adam step `step`, in double like torch's Python scalars
-struct AdamBias { double bc1; float sqrt_bc2; };
-__device__ __forceinline__ AdamBias adam_bias(int step) {
-  AdamBias c;
-  c.bc1 = 1.0 - pow((double)0.9f, (double)step);
-  c.sqrt_bc2 = (float)sqrt(1.0 - pow((double)0.999f, (double)step));
-  return c;
-}
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, const AdamBias& c) {
-  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-  m = m + (1.0f - b1) * (g - m);
-  v = v * b2 + ((1.0f - b2) * g) * g;
-  float denom = sqrtf(v) / c.sqrt_bc2 + eps;
-  p = p + ((-(float)((double)lr / c.bc1)) * m) / denom;
-}
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float lr, int step) {
-  adam1(p, g, m, v, lr, adam_bias(step));
-}
-
-// one thread: quaternion chain of dL/dR, then Adam on the 7 pose parameters
-__device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&gT)[3], float* cam_tensor, float* adam_mv,
-                                          int step, float lr_T, float lr_q, const AdamBias* host_bias = nullptr) {
-  float qr = cam_tensor[0], qi = cam_tensor[1], qj = cam_tensor[2], qk = cam_tensor[3];
-  float nn = qr * qr + qi * qi + qj * qj + qk * qk;
-  float s = 2.0f / nn;
-  // R = I + s*M(q)
-  float M[3][3] = {{-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr},
-                   {qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr},
-                   {qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)}};
-  float GM = 0.f;
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) GM += G[a][k] * M[a][k];
-  float dMr = G[0][1] * (-qk) + G[0][2] * qj + G[1][0] * qk + G[1][2] * (-qi) + G[2][0] * (-qj) + G[2][1] * qi;
-  float dMi = G[0][1] * qj + G[0][2] * qk + G[1][0] * qj + G[1][1] * (-2.f * qi) + G[1][2] * (-qr) + G[2][0] * qk +
-              G[2][1] * qr + G[2][2] * (-2.f * qi);
-  float dMj = G[0][0] * (-2.f * qj) + G[0][1] * qi + G[0][2] * qr + G[1][0] * qi + G[1][2] * qk + G[2][0] * (-qr) +
-              G[2][1] * qk + G[2][2] * (-2.f * qj);
-  float dMk = G[0][0] * (-2.f * qk) + G[0][1] * (-qr) + G[0][2] * qi + G[1][0] * qr + G[1][1] * (-2.f * qk) +
-              G[1][2] * qj + G[2][0] * qi + G[2][1] * qj;
-  float ds = -s * s;   // d s / d q_x = -s^2 q_x
-  float gq[4] = {ds * qr * GM + s * dMr, ds * qi * GM + s * dMi, ds * qj * GM + s * dMj, ds * qk * GM + s * dMk};
-  // once, not per parameter; k_track_pre gets the two double pow() from the host (measured: 13.0 -> 12.5 us)
-  const AdamBias bias = host_bias ? *host_bias : adam_bias(step);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) adam1(cam_tensor[j], gq[j], adam_mv[j], adam_mv[7 + j], lr_q, bias);
-#pragma unroll
-  for (int j = 0; j < 3; ++j) adam1(cam_tensor[4 + j], gT[j], adam_mv[4 + j], adam_mv[11 + j], lr_T, bias);
-}
-
 // d(loss)/d(pose) from the per-ray gradients, analytic quaternion chain, Adam on (T: lr, quat: 0.2 lr)
 // (Tracker.py:305-311,323,183; get_camera_from_tensor common.py:251-267).
 __global__ __launch_bounds__(256) void k_pose_step(RayBufs b, int n, float* cam_tensor, float* adam_mv /*[14]*/, int step,
@@ -395,7 +332,8 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
                                                     int n, float* cam_tensor, float* adam_mv, int step, float lr_T,
                                                     float lr_q, psl_cam_intr cam, int H0, int H1, int W0, int W1,
                                                     const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx,
-                                                    AdamBias bias) {
+                                                    AdamBias bias, const float* __restrict__ pose_src = nullptr,
+                                                    const float* __restrict__ adam_src = nullptr) {
   __shared__ float red[16][12];
   // one ray per thread up to 1 024 rays (the base mix: 200); written as strided loops (any n), launched for n <= 1 024 only:
   // measured in round 5, ONE workgroup striding over 1 500 / 5 000 rays loses to the parallel ray kernels (cfg 1 -4 %, TUM -9 %)
@@ -442,6 +380,10 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
         for (int k = 0; k < 3; ++k) { float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][a * 3 + k]; G[a][k] = t; }
         float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][9 + a]; gT[a] = t;
       }
+      if (pose_src) {      // the last pose of a call whose iterations stepped it inside their k-NN launches sits in the second buffer
+        for (int j = 0; j < 7; ++j) cam_tensor[j] = pose_src[j];
+        for (int j = 0; j < 14; ++j) adam_mv[j] = adam_src[j];
+      }
       pose_adam(G, gT, cam_tensor, adam_mv, step, lr_T, lr_q, &bias);
       __threadfence_block();
     }
@@ -449,6 +391,19 @@ __global__ __launch_bounds__(1024) void k_track_pre(int do_step, int do_setup, c
   }
   if (!do_setup) return;
   for (int r = threadIdx.x; r < n; r += blockDim.x) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx, cam_tensor, b);
+  __syncthreads();
+  depth_inlier_block(b.gd, b.active, n);
+}
+
+// Everything of the tracker's ray set-up that does not depend on the pose, for ALL iterations of a psl_track_iters call in one launch
+// (workgroup = iteration): camera-frame directions, sensor depth / colour / query radius of the pre-drawn pixels, depth-outlier mask.
+// b points at iteration 0's slices; iteration `it` lives `stride` floats further in each.
+__global__ __launch_bounds__(1024) void k_track_rays_all(RayBufs b, int stride, int n, psl_cam_intr cam, int H0, int H1, int W0, int W1,
+                                                         const FrameDev* __restrict__ fdev, const int* __restrict__ pix_idx) {
+  const int it = blockIdx.x;
+  b.dirs += (size_t)it * stride; b.gd += (size_t)it * stride; b.gc += (size_t)it * stride; b.active += (size_t)it * stride;
+  if (b.rq) b.rq += (size_t)it * stride;
+  for (int r = threadIdx.x; r < n; r += blockDim.x) ray_setup_one(r, cam, H0, H1, W0, W1, fdev, 1, n, pix_idx + (size_t)it * n, nullptr, b);
   __syncthreads();
   depth_inlier_block(b.gd, b.active, n);
 }
@@ -819,7 +774,7 @@ static int env_flag(const char* name, int dflt) { const char* e = getenv(name); 
 int g_color_split = env_flag("PSL_COLOR_SPLIT", 1);   // colour-stage launch structure: 0 fused tiles, 2 split kernels, 1 by launch size (psl_decode.h)
 int g_wave_trunk_tiles = env_flag("PSL_WAVE_TRUNK", 1024);   // split structure: trunk as one wavefront per tile from this many tiles on
 int g_lazy_adam = env_flag("PSL_LAZY_ADAM", 1);
-int g_track_fused = env_flag("PSL_TRACK_FUSED", 2);   // 2: k_track_mid inside the decode backward (TrackFuse); 1: its own launch; 0: the ten-launch iteration
+int g_track_fused = env_flag("PSL_TRACK_FUSED", 3);   // 3: + the pose step inside the k-NN launch (TrackPose); 2: k_track_mid inside the decode backward (TrackFuse); 1: its own launch; 0: the ten-launch iteration
 int g_dw_fused = env_flag("PSL_DW_FUSED", 1);
 int g_knn_overlap = env_flag("PSL_KNN_OVERLAP", 1);
 int g_knn_side_blocks = env_flag("PSL_KNN_SIDE_BLOCKS", 512);
@@ -969,6 +924,43 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
   const RenderWs rw = carve_ws(ra.ws, n, ra.flags | (ctx->cfg.encode_rel_pos ? 0x10000 : 0));
   if (fused) { ctx->fused_ray = true; rg.g_rays_o = nullptr; rg.g_rays_d = nullptr; }
   if (mid_in_bwd) ctx->fwd_zero64 = ctx->d_small;     // the forward clears the backward's accumulators (k_track_mid did)
+  // ... and since round 6 k_track_pre's work is gone from the iteration too (three launches: k-NN, forward, backward): what does not
+  // depend on the pose (pixels, camera-frame directions, depth mask) is prepared for all iterations by ONE launch per call, and the pose
+  // step runs in the prologue of every workgroup of the k-NN launch (TrackPose, psl_pose.h), between two pose / Adam buffers.
+  const bool pose_in_knn = mid_in_bwd && g_track_fused >= 3 && t->n_iters > 0;
+  struct PoseGuard { psl_ctx* c; ~PoseGuard() { c->track_pose = nullptr; } } pose_guard{ctx};
+  const int pstride = (9 * n + 3) & ~3;          // per iteration: dirs 3n | gd n | gc 3n | rq n | active n
+  float* pose_buf[2] = {t->cam_tensor, nullptr};
+  float* adam_buf[2] = {t->adam_state, nullptr};
+  auto pref = [&](int it) {
+    RayBufs q = b;
+    float* base = ctx->trk_pref + (size_t)it * pstride;
+    q.dirs = base; q.gd = base + 3 * n; q.gc = base + 4 * n; q.rq = b.rq ? base + 7 * n : nullptr; q.active = (int*)(base + 8 * n);
+    return q;
+  };
+  if (pose_in_knn) {
+    const size_t need = (size_t)t->n_iters * pstride + 32;
+    if (ctx->trk_pref_cap < need) {
+      if (ctx->trk_pref) { PSL_HIP(hipStreamSynchronize(s)); (void)hipFree(ctx->trk_pref); ctx->trk_pref = nullptr; ctx->trk_pref_cap = 0; }
+      PSL_HIP(hipMalloc(&ctx->trk_pref, sizeof(float) * need)); psl::poison(ctx->trk_pref, sizeof(float) * need);
+      ctx->trk_pref_cap = need;
+      dbg_range("trk_pref", ctx->trk_pref, sizeof(float) * need);
+    }
+    pose_buf[1] = ctx->trk_pref + (size_t)t->n_iters * pstride; adam_buf[1] = pose_buf[1] + 8;
+    ProfScope ps(ctx, PROF_MISC, s);
+    RayBufs q = pref(0);
+    q.rays_o = nullptr; q.rays_d = nullptr;
+    hipLaunchKernelGGL(k_track_rays_all, dim3(t->n_iters), dim3(1024), 0, s, q, pstride, n, t->cam, eh, t->cam.H - eh, ew, t->cam.W - ew,
+                       fdev, t->pix_idx);
+    PSL_LAUNCH_CHECK();
+  }
+  auto adam_bias_host = [&](int it) {
+    AdamBias bias;
+    const int step = std::max(t->step0 + it, 1);
+    bias.bc1 = 1.0 - pow((double)0.9f, (double)step);
+    bias.sqrt_bc2 = (float)sqrt(1.0 - pow((double)0.999f, (double)step));
+    return bias;
+  };
   auto track_pre = [&](int it, int do_step, int do_setup) {
     ProfScope ps(ctx, PROF_MISC, s);
     // bias corrections of Adam step `step0 + it` with the formulas of adam_bias(), evaluated here instead of by one thread
@@ -982,7 +974,22 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
                        t->pix_idx + (size_t)std::min(it, t->n_iters - 1) * n, bias);
   };
   for (int it = 0; it < t->n_iters; ++it) {
-    if (fused) {
+    RayBufs bi = b;                            // this iteration's rays (pose_in_knn: its slices of the per-call buffers)
+    TrackPose tp{};
+    if (pose_in_knn) {
+      bi = pref(it);
+      const RayBufs bp = pref(std::max(it - 1, 0));
+      ra.gt_depth = bi.gd; ra.r_query = bi.rq;
+      tp.do_step = it > 0 ? 1 : 0;
+      tp.dp = (const float4*)rw.dp; tp.dp2 = (const float4*)rw.dp2;
+      tp.dirs_prev = bp.dirs; tp.gd_prev = bp.gd;
+      tp.pose_in = pose_buf[(it > 0 ? it - 1 : 0) & 1]; tp.adam_in = adam_buf[(it > 0 ? it - 1 : 0) & 1];
+      tp.pose_out = pose_buf[it & 1]; tp.adam_out = adam_buf[it & 1];
+      tp.step = t->step0 + it; tp.lr_T = t->lr_T; tp.lr_q = t->lr_quat; tp.bias = adam_bias_host(it);
+      tp.dirs = bi.dirs; tp.rays_o = b.rays_o; tp.rays_d = b.rays_d; tp.n = n;
+      tp.near_s = ctx->cfg.near_end_surface; tp.far_s = ctx->cfg.far_end_surface;
+      ctx->track_pose = &tp;
+    } else if (fused) {
       track_pre(it, it > 0 ? 1 : 0, 1);       // pose step of iteration it-1 (Adam step number step0 + it), rays of iteration it
       PSL_LAUNCH_CHECK();
     } else {
@@ -995,12 +1002,13 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     ra.fallback_geo = t->fallback + (size_t)it * 64;
     ra.fallback_col = t->fallback + (size_t)it * 64 + 32;
     int rc = render_fwd_impl(ctx, &ra, s, it == 0);
+    ctx->track_pose = nullptr;
     if (rc) return rc;
     float* lo = t->loss_out ? t->loss_out + 4 * (size_t)it : loss_scratch;
     TrackFuse tf{};
     if (mid_in_bwd) {
-      tf = TrackFuse{b.active, b.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
-                     t->cam_tensor, t->best_out, lo, 1};
+      tf = TrackFuse{bi.active, bi.gc, t->sigmoid_coef, t->w_color, t->handle_dynamic, t->use_color, n, b.depth, b.var, b.rgb, b.valid,
+                     pose_in_knn ? pose_buf[it & 1] : t->cam_tensor, t->best_out, lo, 1};
       ctx->track_fuse = &tf;
     } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
@@ -1023,7 +1031,16 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
                          ex->adam + (EX_N + EXD), ex->step0 + it + 1, ex->lr_mlp, ex->lr_feat);
     PSL_LAUNCH_CHECK();
   }
-  if (fused && t->n_iters > 0) { track_pre(t->n_iters, 1, 0); PSL_LAUNCH_CHECK(); }   // the last pose step
+  if (pose_in_knn) {      // the last pose step, into the caller's buffers (the pose of the last iteration may sit in the second pair)
+    ProfScope ps(ctx, PROF_MISC, s);
+    const int last = (t->n_iters - 1) & 1;
+    hipLaunchKernelGGL(k_track_pre, dim3(1), dim3(1024), 0, s, 1, 0, (const float4*)rw.dp, (const float4*)rw.dp2,
+                       ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, pref(t->n_iters - 1), n, t->cam_tensor, t->adam_state,
+                       t->step0 + t->n_iters, t->lr_T, t->lr_quat, t->cam, eh, t->cam.H - eh, ew, t->cam.W - ew, fdev, t->pix_idx,
+                       adam_bias_host(t->n_iters), last ? (const float*)pose_buf[1] : (const float*)nullptr,
+                       last ? (const float*)adam_buf[1] : (const float*)nullptr);
+    PSL_LAUNCH_CHECK();
+  } else if (fused && t->n_iters > 0) { track_pre(t->n_iters, 1, 0); PSL_LAUNCH_CHECK(); }   // the last pose step
   return PSL_OK;
 }
 

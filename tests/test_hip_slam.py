@@ -179,10 +179,11 @@ def test_track_native_matches_dropin():
 
 @pytest.mark.parametrize("n_pix,exposure", [(200, False), (1000, False), (1500, False), (5000, False), (5000, True)])
 def test_track_launch_structures_agree(n_pix, exposure):
-    """psl_track_iters under its three launch structures (psl_debug_option("track_fused", v)): 0 = the ten launches of rounds
+    """psl_track_iters under its four launch structures (psl_debug_option("track_fused", v)): 0 = the ten launches of rounds
     1-2 (ray set-up, depth mask, k-NN, forward, compositing, loss, compositing backward, backward, ray gradient, pose step),
     1 = pre / mid launches up to 1 024 rays (rounds 3-4), 2 = the ray stage inside the decode backward up to 1 024 rays
-    (TrackFuse), ten launches beyond -- the default.  Same draws, eight iterations: the per-iteration
+    (TrackFuse, round 5), 3 = also the pose step inside the k-NN launch and the pose-independent ray set-up of all iterations in one
+    launch per call (TrackPose, round 6), ten launches beyond 1 024 rays -- the default.  Same draws, eight iterations: the per-iteration
     losses agree to float rounding of the sums over rays, the poses after eight Adam steps to a fraction of one step; the
     batch sizes of every shipped config (200 base, 1 500 Replica, 5 000 TUM / ScanNet, the last with per-frame exposure)."""
     from point_slam_amd import _lib
@@ -197,7 +198,7 @@ def test_track_launch_structures_agree(n_pix, exposure):
     L = _lib.lib()
     outs, draws = {}, None
     try:
-        for ver in (0, 1, 2):
+        for ver in (0, 1, 2, 3):
             _lib.check(L.psl_debug_option(b"track_fused", ver))
             from point_slam_amd.decoders import PointDecoders
             from point_slam_amd.slam import HipSLAM
@@ -214,10 +215,10 @@ def test_track_launch_structures_agree(n_pix, exposure):
             torch.cuda.synchronize()
             outs[ver] = (best.cpu().clone(), s.last_cam.cpu().clone(), s.last_losses.cpu().clone())
     finally:
-        _lib.check(L.psl_debug_option(b"track_fused", 2))
+        _lib.check(L.psl_debug_option(b"track_fused", 3))
     step = cfg["tracking"]["lr"]
     rep = {}
-    for ver in (1, 2):
+    for ver in (1, 2, 3):
         dl = float(((outs[ver][2][:, :3] - outs[0][2][:, :3]).abs() / outs[0][2][:, :3].abs().clamp_min(1e-6)).max())
         dn = float((outs[ver][2][:, 3] - outs[0][2][:, 3]).abs().max())
         dc = float((outs[ver][1] - outs[0][1]).abs().max())
