@@ -539,6 +539,11 @@ __device__ __forceinline__ void track_pose_prologue(const TrackPose& tp, float (
     return;
   }
   const int nw = min((tp.n + 63) >> 6, 16);
+  float pose0[7], mv0[14];                 // requested before the reduction (uniform addresses)
+#pragma unroll
+  for (int j = 0; j < 7; ++j) pose0[j] = tp.pose_in[j];
+#pragma unroll
+  for (int j = 0; j < 14; ++j) mv0[j] = tp.adam_in[j];
   for (int vw = w; vw < nw; vw += 4) {
     float acc[12];
 #pragma unroll
@@ -574,27 +579,32 @@ __device__ __forceinline__ void track_pose_prologue(const TrackPose& tp, float (
     }
   }
   __syncthreads();
-  if (tid == 0) {
+  // wavefront totals added in order, one component per lane; then one thread steps the pose
+  float tj = 0.f;
+  if (tid < 12) for (int q = 0; q < nw; ++q) tj += red[q][tid];
+  if (tid < 64) {
     float G[3][3], gT[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][a * 3 + k]; G[a][k] = t; }
-      float t = 0.f; for (int q = 0; q < nw; ++q) t += red[q][9 + a]; gT[a] = t;
+      for (int k = 0; k < 3; ++k) G[a][k] = __shfl(tj, a * 3 + k);
+      gT[a] = __shfl(tj, 9 + a);
     }
-    float pose[7], mv[14];
+    if (tid == 0) {
+      float pose[7], mv[14];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) pose[j] = tp.pose_in[j];
+      for (int j = 0; j < 7; ++j) pose[j] = pose0[j];
 #pragma unroll
-    for (int j = 0; j < 14; ++j) mv[j] = tp.adam_in[j];
-    pose_adam(G, gT, pose, mv, tp.step, tp.lr_T, tp.lr_q, &tp.bias);
+      for (int j = 0; j < 14; ++j) mv[j] = mv0[j];
+      pose_adam(G, gT, pose, mv, tp.step, tp.lr_T, tp.lr_q, &tp.bias);
 #pragma unroll
-    for (int j = 0; j < 7; ++j) s_pose[j] = pose[j];
-    if (blockIdx.x == 0) {
+      for (int j = 0; j < 7; ++j) s_pose[j] = pose[j];
+      if (blockIdx.x == 0) {
 #pragma unroll
-      for (int j = 0; j < 7; ++j) tp.pose_out[j] = pose[j];
+        for (int j = 0; j < 7; ++j) tp.pose_out[j] = pose[j];
 #pragma unroll
-      for (int j = 0; j < 14; ++j) tp.adam_out[j] = mv[j];
+        for (int j = 0; j < 14; ++j) tp.adam_out[j] = mv[j];
+      }
     }
   }
   __syncthreads();
@@ -613,22 +623,29 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
   __shared__ FlatLds lds[4];
   __shared__ float s_red[POSE ? 16 : 1][12];
   __shared__ float s_pose[8];
-  if constexpr (POSE) track_pose_prologue(tp, s_red, s_pose);
-  const int p = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  if (p >= n_rays * S) return;
+  const int p_raw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int p = POSE ? min(p_raw, n_rays * S - 1) : p_raw;      // (POSE: every wavefront goes through the prologue's barriers)
+  if (!POSE && p >= n_rays * S) return;
   const unsigned long long t0 = trace ? clock64() : 0ull;
   const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
+  // everything that does not depend on the pose is requested in front of the prologue
   const GridMeta m = *meta;
   const float zq = z_vals ? z_vals[p] : sample_z(depth[ray], si, near_s, far_s);
   float r, r2;
   if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
+  float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
+  if constexpr (POSE) { dc0 = tp.dirs[ray * 3]; dc1 = tp.dirs[ray * 3 + 1]; dc2 = tp.dirs[ray * 3 + 2]; }
+  if constexpr (POSE) {
+    track_pose_prologue(tp, s_red, s_pose);
+    if (p_raw >= n_rays * S) return;
+  }
   float qx, qy, qz;
   if constexpr (POSE) {
     // get_rays_from_uv with the stepped pose (ray_setup_one, psl_slam.hip): the same expressions
     float q[4] = {s_pose[0], s_pose[1], s_pose[2], s_pose[3]}, R[3][3], o[3] = {s_pose[4], s_pose[5], s_pose[6]}, d[3];
     quat_to_rot(q, R);
-    const float d0 = tp.dirs[ray * 3], d1 = tp.dirs[ray * 3 + 1], d2 = tp.dirs[ray * 3 + 2];
+    const float d0 = dc0, d1 = dc1, d2 = dc2;
 #pragma unroll
     for (int a = 0; a < 3; ++a) d[a] = __fadd_rn(__fadd_rn(__fmul_rn(d0, R[a][0]), __fmul_rn(d1, R[a][1])), __fmul_rn(d2, R[a][2]));
     if (si == 0 && lane < 3) { tp.rays_o[ray * 3 + lane] = o[lane]; tp.rays_d[ray * 3 + lane] = d[lane]; }
