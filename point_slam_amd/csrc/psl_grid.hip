@@ -610,7 +610,9 @@ __device__ __forceinline__ void track_pose_prologue(const TrackPose& tp, float (
   __syncthreads();
 }
 
-template <int U, int MINW, bool POSE>
+// POSE: 0 = rays from memory; 1 = the tracker's pose step in the prologue, rays turned from camera-frame directions (TrackPose);
+// 2 = directions turned with the pose in memory, no step (tracker batches above 1 024 rays: their pose step stays a launch of its own)
+template <int U, int MINW, int POSE>
 __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __restrict__ meta, const float4* __restrict__ spos,
                                                        const int* __restrict__ cell_start,
                                                        const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -621,11 +623,11 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
                                                        unsigned long long* __restrict__ cand_counter, const int* __restrict__ coarse,
                                                        int trace, TrackPose tp) {
   __shared__ FlatLds lds[4];
-  __shared__ float s_red[POSE ? 16 : 1][12];
+  __shared__ float s_red[POSE == 1 ? 16 : 1][12];
   __shared__ float s_pose[8];
   const int p_raw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const int p = POSE ? min(p_raw, n_rays * S - 1) : p_raw;      // (POSE: every wavefront goes through the prologue's barriers)
-  if (!POSE && p >= n_rays * S) return;
+  const int p = POSE == 1 ? min(p_raw, n_rays * S - 1) : p_raw;      // (POSE 1: every wavefront goes through the prologue's barriers)
+  if (POSE != 1 && p >= n_rays * S) return;
   const unsigned long long t0 = trace ? clock64() : 0ull;
   const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
@@ -635,15 +637,21 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
   float r, r2;
   if (r_query) { r = r_query[ray]; r2 = __fmul_rn(r, r); } else { r = r_fixed; r2 = r2_fixed; }
   float dc0 = 0.f, dc1 = 0.f, dc2 = 0.f;
-  if constexpr (POSE) { dc0 = tp.dirs[ray * 3]; dc1 = tp.dirs[ray * 3 + 1]; dc2 = tp.dirs[ray * 3 + 2]; }
-  if constexpr (POSE) {
+  if constexpr (POSE != 0) { dc0 = tp.dirs[ray * 3]; dc1 = tp.dirs[ray * 3 + 1]; dc2 = tp.dirs[ray * 3 + 2]; }
+  float ps[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (POSE == 1) {
     track_pose_prologue(tp, s_red, s_pose);
     if (p_raw >= n_rays * S) return;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) ps[j] = s_pose[j];
+  } else if constexpr (POSE == 2) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) ps[j] = tp.pose_in[j];
   }
   float qx, qy, qz;
-  if constexpr (POSE) {
-    // get_rays_from_uv with the stepped pose (ray_setup_one, psl_slam.hip): the same expressions
-    float q[4] = {s_pose[0], s_pose[1], s_pose[2], s_pose[3]}, R[3][3], o[3] = {s_pose[4], s_pose[5], s_pose[6]}, d[3];
+  if constexpr (POSE != 0) {
+    // get_rays_from_uv with the (stepped) pose (ray_setup_one, psl_slam.hip): the same expressions
+    float q[4] = {ps[0], ps[1], ps[2], ps[3]}, R[3][3], o[3] = {ps[4], ps[5], ps[6]}, d[3];
     quat_to_rot(q, R);
     const float d0 = dc0, d1 = dc1, d2 = dc2;
 #pragma unroll
@@ -1000,19 +1008,18 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     static int large_from = -2;
     if (large_from == -2) { const char* e = getenv("PSL_KNN_FLAT_LARGE"); large_from = e ? atoi(e) : 5000; }
     unsigned long long* cand = (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr;   // one atomic per query: only while measured
-    if (!ctx->track_pose && large_from >= 0 && n_rays * S >= large_from)
-      PSL_KLAUNCH((k_knn_rays_flat<4, 8, false>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TrackPose{});
-    else if (ctx->track_pose)     // psl_track_iters, batches <= 1 024 rays: the pose step of the previous iteration in the prologue
-      PSL_KLAUNCH((k_knn_rays_flat<8, 5, true>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4,
-                         *static_cast<const TrackPose*>(ctx->track_pose));
-    else
-      PSL_KLAUNCH((k_knn_rays_flat<8, 5, false>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, rays_o,
-                         rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),
-                         ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TrackPose{});
+    const TrackPose* tpp = static_cast<const TrackPose*>(ctx->track_pose);
+    const bool large = large_from >= 0 && n_rays * S >= large_from;
+#define PSL_KNN_FLAT(UU, WW, PP, TP)                                                                                               \
+    PSL_KLAUNCH((k_knn_rays_flat<UU, WW, PP>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, \
+                rays_o, rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),                        \
+                ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TP)
+    if (tpp && !tpp->rotate_only) PSL_KNN_FLAT(8, 5, 1, *tpp);       // psl_track_iters, batches <= 1 024 rays: pose step in the prologue
+    else if (tpp && large) PSL_KNN_FLAT(4, 8, 2, *tpp);              // larger tracker batches: directions turned here, no ray set-up launch
+    else if (tpp) PSL_KNN_FLAT(8, 5, 2, *tpp);
+    else if (large) PSL_KNN_FLAT(4, 8, 0, TrackPose{});
+    else PSL_KNN_FLAT(8, 5, 0, TrackPose{});
+#undef PSL_KNN_FLAT
     PSL_LAUNCH_CHECK();
     return PSL_OK;
   }

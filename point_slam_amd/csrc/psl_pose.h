@@ -77,6 +77,7 @@ __device__ __forceinline__ void pose_adam(const float (&G)[3][3], const float (&
 // bits), and turns the camera-frame directions of its own rays; workgroup 0 writes the stepped pose and Adam state to the OTHER of two
 // buffers (the old ones are still being read by the rest of the grid).  Replaces one 12.5-us single-workgroup launch per iteration.
 struct TrackPose {
+  int rotate_only;                        // 1: no step at all, pose_in is the pose (batches above 1 024 rays; POSE = 2 instantiation)
   int do_step;                            // 0 in the first iteration: the pose is pose_in
   const float4* dp; const float4* dp2;    // [n S] d(loss)/d(sample point) of the previous backward (dp2: second accumulator or null)
   const float* dirs_prev; const float* gd_prev;   // camera-frame directions / sensor depths of the previous iteration's rays

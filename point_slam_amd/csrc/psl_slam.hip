@@ -938,7 +938,10 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     q.dirs = base; q.gd = base + 3 * n; q.gc = base + 4 * n; q.rq = b.rq ? base + 7 * n : nullptr; q.active = (int*)(base + 8 * n);
     return q;
   };
-  if (pose_in_knn) {
+  // batches above 1 024 rays (and handle_dynamic = False) keep their ray stage and pose step as launches, but the per-call
+  // preparation serves them too: ray set-up and depth mask leave the iteration, the k-NN launch turns the directions (POSE = 2)
+  const bool prefetch = g_track_fused >= 3 && t->n_iters > 0 && (pose_in_knn || !fused);
+  if (prefetch) {
     const size_t need = (size_t)t->n_iters * pstride + 32;
     if (ctx->trk_pref_cap < need) {
       if (ctx->trk_pref) { PSL_HIP(hipStreamSynchronize(s)); (void)hipFree(ctx->trk_pref); ctx->trk_pref = nullptr; ctx->trk_pref_cap = 0; }
@@ -992,6 +995,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     } else if (fused) {
       track_pre(it, it > 0 ? 1 : 0, 1);       // pose step of iteration it-1 (Adam step number step0 + it), rays of iteration it
       PSL_LAUNCH_CHECK();
+    } else if (prefetch) {
+      bi = pref(it);
+      ra.gt_depth = bi.gd; ra.r_query = bi.rq;
+      tp.rotate_only = 1; tp.pose_in = t->cam_tensor; tp.dirs = bi.dirs; tp.rays_o = b.rays_o; tp.rays_d = b.rays_d; tp.n = n;
+      ctx->track_pose = &tp;
     } else {
       ProfScope ps(ctx, PROF_MISC, s);
       hipLaunchKernelGGL(k_ray_setup, dim3((n + 255) / 256), dim3(256), 0, s, t->cam, eh, t->cam.H - eh,
@@ -1012,11 +1020,11 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
       ctx->track_fuse = &tf;
     } else if (fused) {
       ProfScope ps(ctx, PROF_COMPOSITE, s, 324.0 * n, true);
-      PSL_KLAUNCH(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, b, n, ctx->cfg.near_end_surface,
+      PSL_KLAUNCH(k_track_mid, dim3(1), dim3(1024), 0, s, (const float4*)rw.raw, rw.cnt, bi, n, ctx->cfg.near_end_surface,
                          ctx->cfg.far_end_surface, ctx->cfg.min_nn_num, t->sigmoid_coef, t->w_color, t->handle_dynamic,
                          t->use_color, t->cam_tensor, t->best_out, lo, (float4*)rw.d_raw, ctx->d_small);
     } else {
-      hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, b, n, t->w_color, t->handle_dynamic, t->use_color,
+      hipLaunchKernelGGL(k_tracker_loss, dim3(1), dim3(1024), 0, s, bi, n, t->w_color, t->handle_dynamic, t->use_color,
                          t->cam_tensor, t->best_out, lo);
     }
     PSL_LAUNCH_CHECK();
@@ -1024,7 +1032,7 @@ extern "C" int psl_track_iters(psl_ctx* ctx, const psl_track_args* t, void* stre
     ctx->track_fuse = nullptr;
     if (rc) return rc;
     if (!fused)
-      hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, b, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
+      hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(256), 0, s, bi, n, t->cam_tensor, t->adam_state, t->step0 + it + 1,
                          t->lr_T, t->lr_quat);
     if (ex)
       hipLaunchKernelGGL(k_exposure_step, dim3(1), dim3(128), 0, s, ex->mlp, ex->feats, 1, ex_g, ex_aff, ex_act, ex->adam,
