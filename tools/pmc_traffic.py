@@ -63,6 +63,7 @@ CLASS_OF = [
     ("k_dwE", lambda g: True, "dw_gemm", "fused"),
     ("AdamRowsSeg", lambda g: True, "adam", "fused"),
     ("SA_SA_SA_SA_ffffiPiSB_Py", lambda g: True, "knn", "fused"),
+    ("SB_SB_SB_SB_ffffiPiSC_Py", lambda g: True, "knn", "fused"),       # k_knn_rays_flat<U, MINW, POSE> (TrackPose argument, round 6)
     ("k_map_ray_fused", lambda g: True, "map_ray", "fused"),
 ]
 DOUBLE_FETCH = {"geo_iter", "decode_fwd", "decode_fwd_track", "decode_fwd_geo", "decode_bwd", "decode_bwd_track", "decode_bwd_geo",
