@@ -396,21 +396,28 @@ def test_long_tracker_run_ends_where_the_oracle_ends(trained_world, n_pix, n_ite
         od, oc, orq = fr.depth.cpu(), fr.color.cpu(), fr.r_query.cpu()
         ls, cams, obest, _, _ = O.tracker_loop(cfg, st["P"], st["cloud"], st["geo"], st["col"], cam0, pix, fb, od, oc, orq, cam, eh, ew, **kw)
         cam0_ulp = torch.nextafter(cam0, torch.full_like(cam0, 10.0))
-        _, cams_u, obest_u, _, _ = O.tracker_loop(cfg, st["P"], st["cloud"], st["geo"], st["col"], cam0_ulp, pix, fb, od, oc, orq, cam, eh, ew, **kw)
+        ls_u, cams_u, obest_u, _, _ = O.tracker_loop(cfg, st["P"], st["cloud"], st["geo"], st["col"], cam0_ulp, pix, fb, od, oc, orq, cam, eh, ew, **kw)
     finally:
         tr["sample_with_color_grad"] = full0
     ref = torch.tensor(ls, dtype=torch.float64)
     rel = (hip_losses - ref).abs() / ref.abs()
+    self_rel = (torch.tensor(ls_u, dtype=torch.float64) - ref).abs() / ref.abs()      # the oracle against itself, one ulp apart
     band_best = float((obest_u - obest).abs().max())
     band_end = float((cams_u[-1] - cams[-1]).abs().max())
     err = lambda c: float((c[4:] - truth[4:]).norm() * 100.0)        # translation error against the truth, cm
     rep = dict(test="long_tracker_outcome", n_pix=n_pix, n_iters=n_iters, loss_rel_first=float(rel[0]), loss_rel_first10=float(rel[:10].max()),
                loss_rel_max=float(rel.max()), loss_first=float(ref[0]), loss_last_oracle=float(ref[-1]), loss_last_hip=float(hip_losses[-1]),
                best_abs=float((best - obest).abs().max()), end_abs=float((hip_end - cams[-1]).abs().max()),
-               oracle_self_1ulp_best=band_best, oracle_self_1ulp_end=band_end, lr=tr["lr"],
+               oracle_self_1ulp_best=band_best, oracle_self_1ulp_end=band_end, oracle_self_1ulp_loss_rel_first10=float(self_rel[:10].max()),
+               oracle_self_1ulp_loss_rel_max=float(self_rel.max()), lr=tr["lr"],
                err_start_cm=err(cam0), err_hip_cm=err(best), err_oracle_cm=err(obest), err_oracle_ulp_cm=err(obest_u))
     report(**rep)
-    assert rep["loss_rel_first"] < 1e-4 and rep["loss_rel_first10"] < 2e-3
+    # the first loss is a parity statement; the next nine already carry the run's own sensitivity (the trained map differs from run to
+    # run -- float atomics in its training -- and so does how fast two exact runs part: 3e-4 and 2.6e-3 were both measured with
+    # bit-identical kernels, tools/track_structs_probe.py), so they are held to the oracle's own one-ulp divergence over the same
+    # iterations, never tighter than 5e-3
+    assert rep["loss_rel_first"] < 1e-4
+    assert rep["loss_rel_first10"] < max(5e-3, 4.0 * rep["oracle_self_1ulp_loss_rel_first10"]), rep
     # the end pose inside a small multiple of the oracle's own sensitivity (never tighter than a few Adam steps)
     band = max(band_best, band_end, 3.0 * tr["lr"])
     assert rep["best_abs"] <= 4.0 * band and rep["end_abs"] <= 4.0 * band
