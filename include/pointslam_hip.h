@@ -54,7 +54,7 @@ typedef struct psl_config {
   float max_query_radius;   /* largest radius any query may use; sets the grid cell size.
                                dynamic mode: radius_add_max*radius_query_ratio (:113,115) */
   int32_t encode_rel_pos;   /* model.encode_rel_pos_in_col               :13  */
-  int32_t max_points;       /* position capacity of this ctx (points)         */
+  int32_t max_points;       /* position capacity of this ctx (points), <= 2^25 */
 } psl_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */
@@ -411,7 +411,9 @@ int psl_profile_enable(psl_ctx* ctx, int on);
 int64_t psl_knn_candidates(psl_ctx* ctx);
 /* run-time A/B switches for tests and profiling: "knn" 0 = by launch size, 1 = one wavefront per sample, 2 = one per
  * ray; "lazy_adam" 0 = dense Adam sweep over every selected feature row, 1 (default) = lazy replay (psl_map_iters);
- * "track_fused" 0 = separate per-ray kernels in psl_track_iters, 1 (default) = fused for batches <= 1024 rays;
+ * "track_fused" launch structure of psl_track_iters: 0 = ten launches per iteration; 1 = pre / mid launches for batches <= 1024 rays;
+ * 2 = the ray stage inside the decode backward (four launches); 3 (default) = also the pose step inside the k-NN launch and the
+ * pose-independent ray set-up of all iterations in one launch per call (three launches; eight above 1024 rays) -- bit-identical results;
  * "color_split" launch structure of the colour-stage decode (decoder.py:341-449): 0 = fused 16-sample tiles, 2 = split F_theta /
  * trunk kernels, 1 (default) = split beyond 384 tiles; "wave_trunk" = tiles from which the split structure's trunk forward runs
  * one wavefront per tile (default 1024, 0 = never).  Results are the same to fp32 rounding of one sum order (the colour head) */

@@ -104,6 +104,10 @@ def test_argument_errors_are_reported_not_thrown():
     none = C.c_void_p(None)
     assert L.psl_create(0, None, None) < 0 and L.psl_last_error()
     assert L.psl_render_ws_floats(-1, 0) < 0
+    # the gradient scatters address a row by a 32-bit byte offset: capacities above 2^25 rows are refused at creation
+    cfg = _lib.psl_config(max_points=(1 << 25) + 1, max_query_radius=0.16, n_surface=5, nn_num=8, c_dim=32)
+    ctx = C.c_void_p()
+    assert L.psl_create(0, C.byref(cfg), C.byref(ctx)) < 0 and b"max_points" in L.psl_last_error()
     assert L.psl_track_ws_floats(-5) < 0 and L.psl_map_ws_floats(-1, 1) < 0
     assert L.psl_frame_radii(none, 480, 640, 0.15, 0.08, 0.02, 2.0, none, none, none, none) < 0
     assert b"psl_frame_radii" in L.psl_last_error()
