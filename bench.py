@@ -260,6 +260,7 @@ def run_step(i, slam, frames, cams0, every, cfg, world, args, state):
             state["sync"].exchange(slam.npc, slam.theta)
             ev[1].record()
             state.setdefault("exchange_ev", []).append(ev)
+            state.setdefault("exchange_host_ms", []).append(dict(getattr(state["sync"], "last_host_ms", {})))   # host time per phase
         if (i // every) % max(cfg["mapping"]["keyframe_every"] // every, 1) == 0:
             slam.keyframes.append(fr)
             if len(slam.keyframes) > 40:        # the reference keeps every keyframe on the CPU; bounded here
@@ -807,6 +808,7 @@ def main():
         mine = dict(rank=rank, device=str(dev), cpu_affinity=affinity, host_threads=torch.get_num_threads(), points_end=points_end, points_after_final_exchange=slam.npc.pts_num(),
                     added=state["added"], mapped=state["mapped"], final_exchange_ms=round(t_ex * 1e3, 3),
                     exchange_ms=[round(x * 1e3, 3) for x in state.get("exchange_s", [])],
+                    exchange_host_ms=state.get("exchange_host_ms", []),       # where the calling thread spent it: rows / decoder / new_points
                     exchange_ms_p50=ex_ms[len(ex_ms) // 2] if ex_ms else None, exchange_ms_p100=ex_ms[-1] if ex_ms else None,
                     ate_rmse_cm=(ate_of(state.get("traj", []), frames) or {}).get("rmse_cm"),
                     render_loss_after_final_exchange=loss_after,

@@ -48,6 +48,8 @@ import ctypes as C
 import os
 from typing import List, Optional, Tuple
 
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -330,16 +332,23 @@ class FrameParallelSync:
 
     def exchange(self, npc, theta: Optional[torch.Tensor] = None, dedupe: bool = True) -> List[int]:
         """One exchange (all four steps).  `theta`: the master parameter blob, updated in place (colour group)."""
+        # HOST time of the three phases (what the calling thread spends inside each: enqueueing, the collectives' host side and the
+        # host synchronisations they contain -- on a GPU the device work overlaps the next phase's enqueue): `last_host_ms`
+        t0 = time.perf_counter()
         # 3. features of the points that existed at the last exchange
         self._reconcile_rows(npc)
+        t1 = time.perf_counter()
         # 4. colour decoder
         if theta is not None and self.snap_theta is not None:
             d = theta[:self.n_color] - self.snap_theta
             dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
             theta[:self.n_color] = self.snap_theta + d / dist.get_world_size(self.group)
+        t2 = time.perf_counter()
         # 1-2. new points
         creators: list = []
         counts = merge_new_points(npc, self.n_base, self.group, dedupe, self.transport, creators if self.merge == "owner" else None)
+        t3 = time.perf_counter()
+        self.last_host_ms = dict(rows=round((t1 - t0) * 1e3, 3), decoder=round((t2 - t1) * 1e3, 3), new_points=round((t3 - t2) * 1e3, 3))
         if self.merge == "owner" and creators and creators[0].numel():     # the creator table only serves the owner-writes rule
             geo = npc.get_geo_feats()
             cap = max(getattr(npc, "_max_points", 0) or 0, geo.shape[0], self.n_base + int(creators[0].numel()))

@@ -278,3 +278,82 @@ def test_owner_writes_merge_rule_world3():
     assert geo[2] == 10.0 * 3 and col[2] == -10.0             # seed-map row: lowest contributor (rank 1)
     assert geo[7] == 1.0 * 8                                  # its creator alone
     assert float(geo[[0, 1, 3, 4, 5, 6, 8, 9, 11, 12, 14]].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world 8: the rank count of BASELINE config 4 at realistic RATIOS -- every rank trains a few thousand rows that
+# overlap its neighbours', adds tens of locations of which some collide across ranks, and the colour decoder moves on all of them.  The
+# replicas must come out identical, and the HOST time of each phase of the exchange is recorded per rank (FrameParallelSync.last_host_ms):
+# the record the 8-GPU run will be read against (on this box the eight ranks share eight cores and gloo's TCP loopback).
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from point_slam_amd.dist import FrameParallelSync
+    g = torch.Generator().manual_seed(7)
+    n0 = 6000
+    base = torch.rand(n0, 3, generator=g) * 4.0 + 5.0
+    bg, bc = torch.rand(n0, 32, generator=g), torch.rand(n0, 32, generator=g)
+    cloud = FakeCloud(base.clone(), bg.clone(), bc.clone())
+    theta = torch.arange(64, dtype=torch.float32)
+    sync = FrameParallelSync(cloud, theta, n_color=48)
+    host = []
+    for interval in range(2):
+        gr = torch.Generator().manual_seed(1000 * interval + rank)
+        # rows: a window of 1 500 rows per rank, half of it shared with the next rank; every other announced row really changes
+        first = (rank * 750 + 300 * interval) % (n0 - 1500)
+        rows = torch.arange(first, first + 1500)
+        sync.note_rows(cloud, rows)
+        ch = rows[::2]
+        cloud.geo[ch] += torch.rand(ch.shape[0], 32, generator=gr)
+        cloud.col[ch] -= torch.rand(ch.shape[0], 32, generator=gr)
+        theta[:48] += float(rank + 1)
+        # new locations: 24 per rank on a lattice far from the seed map; ranks r and r + 4 propose the SAME lattice cell shifted by 5 mm
+        cell = torch.arange(24, dtype=torch.float32)
+        centres = torch.stack([1.0 + 0.2 * cell, torch.full((24,), 1.0 + 0.3 * (rank % 4)), torch.full((24,), 1.0 + 0.5 * interval)], 1)
+        if rank >= 4:
+            centres = centres + 0.005
+        new = _triplets(centres)
+        cloud.append_points(new, torch.rand(new.shape[0], 32, generator=gr), torch.rand(new.shape[0], 32, generator=gr))
+        counts = sync.exchange(cloud, theta)
+        host.append(dict(sync.last_host_ms, **{k: int(v) for k, v in sync.last_stats.items()}))
+    q.put(tuple(_np(x) for x in (rank, counts, cloud.pts_num(), cloud.pos.clone(), cloud.geo.clone(), cloud.col.clone(), theta.clone(), host)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_world8_replicas_identical_and_host_time_recorded():
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([tuple(_t(x) for x in q.get(timeout=300)) for _ in range(8)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = res[0]
+    for r in res:
+        rank, counts, n_after, pos, geo, col, theta, host = r
+        # (counts = what every rank proposed) ranks 4..7 lose every location to ranks 0..3: same cells, 5 mm apart, inside the 4-cm add radius
+        assert counts == [72] * 8
+        assert n_after == 6000 + 2 * 4 * 72
+        assert torch.equal(pos, r0[3]) and torch.equal(geo, r0[4]) and torch.equal(col, r0[5]) and torch.equal(theta, r0[6])
+        for h in host:
+            assert h["rows_noted"] == 1500 and h["rows_sent"] == 750 and h["rows_received"] == 8 * 750
+            assert set(("rows", "decoder", "new_points")) <= set(h) and all(h[k] >= 0.0 for k in ("rows", "decoder", "new_points"))
+    # colour decoder: mean of the changes, (1 + ... + 8) / 8 = 4.5 per interval
+    assert torch.allclose(r0[6][:48], torch.arange(48, dtype=torch.float32) + 9.0) and torch.equal(r0[6][48:], torch.arange(48, 64, dtype=torch.float32))
+    rep = dict(test="exchange_world8_host_ms", world=8, backend="gloo (CPU tensors, eight ranks on this box's cores)",
+               per_rank=[dict(rank=r[0], intervals=r[7]) for r in res],
+               worst_total_ms=max(sum(h[k] for k in ("rows", "decoder", "new_points")) for r in res for h in r[7]))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "exchange_world8_host_ms.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass
+    print("REPORT", json.dumps(rep)[:400])
