@@ -55,6 +55,8 @@ typedef struct psl_config {
                                dynamic mode: radius_add_max*radius_query_ratio (:113,115) */
   int32_t encode_rel_pos;   /* model.encode_rel_pos_in_col               :13  */
   int32_t max_points;       /* position capacity of this ctx (points), <= 2^25 */
+  int32_t nn_weighting;     /* pointcloud.nn_weighting :110 -- 0 'distance' 1/(D+1e-10), 1 'expo' exp(-20 sqrt(D))
+                               (src/conv_onet/models/decoder.py:152-156,362-366); ABI v7 */
 } psl_config;
 
 /* ---- lifecycle ----------------------------------------------------------- */

@@ -45,6 +45,8 @@ def cfg_variant(name):
     elif name == "tum":            # fixed radius, no rel-pos MLP (configs/TUM_RGBD/tum.yaml)
         cfg["use_dynamic_radius"] = False
         cfg["model"]["encode_rel_pos_in_col"] = False
+    elif name == "replica_expo":   # pointcloud.nn_weighting = 'expo' (decoder.py:154-156, 364-366; no shipped config)
+        cfg["pointcloud"]["nn_weighting"] = "expo"
     elif name == "scannet":        # exposure, rho=0.04 (configs/ScanNet/scannet.yaml)
         cfg["model"]["encode_rel_pos_in_col"] = False
         cfg["model"]["encode_exposure"] = True
@@ -322,6 +324,22 @@ def run_tracker_case(name, n_pts, n_rays, seed, handle_dynamic=True):
     save(name, out)
 
 
+def run_expo_cases():
+    """pointcloud.nn_weighting = 'expo'.  The TRACKER cannot run with it in the reference: decoder.py:157 / 367 zero the output of
+    torch.exp in place and autograd raises in backward as soon as the weights carry a gradient (is_tracker) -- checked here, and the
+    library refuses PSL_PTS_GRAD with 'expo' for the same reason.  The mapper's stages (no gradient through the weights) work."""
+    try:
+        run_render_case("_expo_tracker_must_raise", "replica_expo", "color", True, 500, 16, 112)
+    except RuntimeError as e:
+        assert "inplace" in str(e) or "in-place" in str(e), e
+        print("[expo] reference tracker backward raises as expected:", str(e)[:90])
+    else:
+        raise AssertionError("the reference's tracker backward was expected to raise with nn_weighting='expo'")
+    run_render_case("render_expo_color_mapper", "replica_expo", "color", False, 3000, 96, 111, sparse_frac=0.35,
+                    store_param_grads=True)
+    run_render_case("render_expo_geometry_mapper", "replica_expo", "geometry", False, 2000, 96, 110)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -330,6 +348,9 @@ def main():
         return
     if "--scannet-mapper" in sys.argv:   # encode_exposure with exposure_feat=None: raw colour logits, no sigmoid (decoder.py:432-448)
         run_render_case("render_scannet_color_mapper", "scannet", "color", False, 2000, 64, 109)
+        return
+    if "--expo" in sys.argv:   # nn_weighting = 'expo': the mapper's two stages (feature / decoder gradients)
+        run_expo_cases()
         return
     if "--zero-depth" in sys.argv:   # only the sensor-hole cases (the others are unchanged)
         run_render_case("render_holes_nearpcl_mapper", "replica", "color", False, 3000, 96, 107, sparse_frac=0.35,
@@ -354,6 +375,7 @@ def main():
                     zero_depth_frac=0.4, sample_near_pcl=False)
 
     run_render_case("render_scannet_color_mapper", "scannet", "color", False, 2000, 64, 109)
+    run_expo_cases()
 
 
 if __name__ == "__main__":

@@ -153,10 +153,10 @@ def neighbor_count(D: Tensor, radius) -> Tensor:
 # --------------------------------------------------------------------------
 # feature interpolation
 # --------------------------------------------------------------------------
-def idw_weights(D: Tensor, r2) -> Tensor:
-    """w = 1/(D+1e-10); w[D>r2]=0; L1 normalise with eps 1e-12.
-    src/conv_onet/models/decoder.py:152-160 / 362-368 ('distance' weighting)."""
-    w = 1.0 / (D + 1e-10)
+def idw_weights(D: Tensor, r2, weighting: str = "distance") -> Tensor:
+    """w = 1/(D+1e-10) ('distance') or exp(-20 sqrt(D)) ('expo'); w[D>r2]=0; L1 normalise with eps 1e-12.
+    src/conv_onet/models/decoder.py:152-160 / 362-368 (pointcloud.nn_weighting, configs/point_slam.yaml:110)."""
+    w = 1.0 / (D + 1e-10) if weighting == "distance" else torch.exp(-20 * torch.sqrt(D))
     w = torch.where(D > r2, torch.zeros_like(w), w)
     return w / w.abs().sum(1, keepdim=True).clamp_min(1e-12)
 
@@ -180,26 +180,26 @@ def safe_gather(t: Tensor, I: Tensor) -> Tensor:
     return t[I.clamp_min(0)]
 
 
-def geo_features(p, D, I, cnt, geo_feats, cloud, r2, min_nn, fallback, pts_grad):
+def geo_features(p, D, I, cnt, geo_feats, cloud, r2, min_nn, fallback, pts_grad, weighting="distance"):
     """MLP_geometry.get_feature_at_pos, decoder.py:130-173."""
     if pts_grad:  # is_tracker: re-evaluate D so that it carries d/dp (decoder.py:143-148)
         D = sqdist(p[:, None, :], safe_gather(cloud, I))
         D = torch.where(I < 0, torch.full_like(D, float("inf")), D)
     has_nb = cnt > (min_nn - 1)
-    w = idw_weights(D, r2)
+    w = idw_weights(D, r2, weighting)
     c = (w[..., None] * safe_gather(geo_feats, I)).sum(1)
     c = torch.where(has_nb[:, None], c, fallback[None, :].expand_as(c))
     return c, has_nb
 
 
 def col_features(p, D, I, cnt, col_feats, cloud, r2, min_nn, fallback, pts_grad, P: Dict[str, Tensor],
-                 encode_rel_pos: bool):
+                 encode_rel_pos: bool, weighting="distance"):
     """MLP_color.get_feature_at_pos, decoder.py:341-390 (+ F_theta, decoder.py:225-240)."""
     if pts_grad:
         D = sqdist(p[:, None, :], safe_gather(cloud, I))
         D = torch.where(I < 0, torch.full_like(D, float("inf")), D)
     has_nb = cnt > (min_nn - 1)
-    w = idw_weights(D, r2)
+    w = idw_weights(D, r2, weighting)
     nf = safe_gather(col_feats, I)                               # [P,K,C]
     if encode_rel_pos:
         rel = safe_gather(cloud, I) - p[:, None, :]              # decoder.py:372-373
@@ -352,12 +352,13 @@ def render_batch_ray(cfg: dict, P: Dict[str, Tensor], cloud: Tensor, geo_feats: 
         D, I = knn
     cnt = neighbor_count(D, rq)
     min_nn = cfg["pointcloud"]["min_nn_num"]
-    cg, has_nb = geo_features(pts, D, I, cnt, geo_feats, cloud, r2, min_nn, fallback_geo, pts_grad)
+    weighting = cfg["pointcloud"].get("nn_weighting", "distance")
+    cg, has_nb = geo_features(pts, D, I, cnt, geo_feats, cloud, r2, min_nn, fallback_geo, pts_grad, weighting)
     valid_ray = has_nb.view(-1, S).sum(1) >= int(S / 2 + 1)          # decoder.py:200-201
     occ = geo_mlp(pts, cg, P)
     if stage == "color":
         cc, _ = col_features(pts, D, I, cnt, col_feats, cloud, r2, min_nn, fallback_col, pts_grad, P,
-                             cfg["model"]["encode_rel_pos_in_col"])
+                             cfg["model"]["encode_rel_pos_in_col"], weighting)
         sig = (not cfg["model"]["encode_exposure"]) or (exposure_affine is not None)
         rgb_pts = col_mlp(pts, cc, P, exposure_affine, sig)
     else:

@@ -17,7 +17,7 @@ class PslError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
+ABI_VERSION = 7     # include/pointslam_hip.h: psl_abi_version(); v2: psl_render_args.z_vals; v3: exposure blocks,
 #                     full-image pixel indices in psl_track_args, step0_params in psl_map_args; v4: psl_dedupe_count / psl_dedupe_blocks,
 #                     psl_comm_* / psl_allgather_new_points (RCCL inside the library), psl_map_args refinement fields;
 #                     v5: psl_allgather_decide (rank-invariant capacity decision), psl_selftest_math; v6: psl_comm_reserve, psl_pose_const_speed, psl_selftest_traffic
@@ -27,7 +27,7 @@ EXPOSURE_DIM, EXPOSURE_MLP_FLOATS = 8, 2700
 class psl_config(C.Structure):
     _fields_ = [("n_surface", C.c_int32), ("nn_num", C.c_int32), ("c_dim", C.c_int32), ("min_nn_num", C.c_int32),
                 ("near_end_surface", C.c_float), ("far_end_surface", C.c_float), ("radius_query", C.c_float),
-                ("max_query_radius", C.c_float), ("encode_rel_pos", C.c_int32), ("max_points", C.c_int32)]
+                ("max_query_radius", C.c_float), ("encode_rel_pos", C.c_int32), ("max_points", C.c_int32), ("nn_weighting", C.c_int32)]
 
 
 class psl_render_args(C.Structure):

@@ -148,6 +148,7 @@ static int fill_decode_args(psl_ctx* ctx, const psl_render_args* a, DecodeArgs& 
   memset(&d, 0, sizeof(d));
   int flags = a->flags;
   if (ctx->cfg.encode_rel_pos) flags |= 0x10000;
+  if (ctx->cfg.nn_weighting == 1) flags |= kFlagExpoW;
   d.P = a->n_rays * S;
   d.n_rays = a->n_rays;
   d.flags = flags;
@@ -175,6 +176,12 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
   if ((a->flags & PSL_STAGE_COLOR) && (!a->col_feats || !a->col_embed_B || !a->fallback_col)) {
     set_error("%s: colour stage needs col_feats, col_embed_B, fallback_col", who); return PSL_ERR_ARG;
   }
+  if ((a->flags & PSL_PTS_GRAD) && ctx->cfg.nn_weighting == 1) {
+    // the reference cannot do it either: weights = exp(-20 sqrt(D)); weights[D > bound] = 0 modifies the exp's output in place and
+    // autograd raises when the tracker back-propagates to the pose (decoder.py:154-157, 364-367)
+    set_error("%s: nn_weighting 'expo' has no pose gradient (the reference raises in backward: in-place write on exp's output, decoder.py:157)", who);
+    return PSL_ERR_UNSUPPORTED;
+  }
   if ((a->flags & PSL_HAS_AFFINE) && !a->exposure_affine) { set_error("%s: PSL_HAS_AFFINE without affine", who); return PSL_ERR_ARG; }
   if (ctx->index_points != ctx->n_points) { set_error("%s: index is stale, call psl_index_build", who); return PSL_ERR_STATE; }
   return PSL_OK;
@@ -185,7 +192,7 @@ static int check_render_args(psl_ctx* ctx, const psl_render_args* a, const char*
 using namespace psl;
 
 extern "C" const char* psl_last_error(void) { return g_err; }
-extern "C" int psl_abi_version(void) { return 6; }
+extern "C" int psl_abi_version(void) { return 7; }
 
 extern "C" int psl_param_count(void) { return kNumParams; }
 extern "C" int psl_param_color_count(void) { return kNumColorParams; }
@@ -207,6 +214,7 @@ extern "C" int psl_create(int device, const psl_config* cfg, psl_ctx** out) {
     return PSL_ERR_UNSUPPORTED;
   }
   if (cfg->max_points <= 0 || cfg->max_query_radius <= 0.f) { set_error("psl_create: bad capacity/radius"); return PSL_ERR_ARG; }
+  if (cfg->nn_weighting != 0 && cfg->nn_weighting != 1) { set_error("psl_create: nn_weighting must be 0 ('distance') or 1 ('expo')"); return PSL_ERR_ARG; }
   if (cfg->max_points > kMaxPointsScatter) {          // psl_decode2.h: gradient rows are addressed by 32-bit byte offsets
     set_error("psl_create: max_points %d exceeds %d", cfg->max_points, kMaxPointsScatter); return PSL_ERR_ARG;
   }

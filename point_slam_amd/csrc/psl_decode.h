@@ -391,6 +391,17 @@ __device__ __forceinline__ SampleGeom sample_geom(const DecodeArgs& a, int p) {
   return g;
 }
 
+// Interpolation weight of a neighbour at squared distance D before the L1 normalisation (decoder.py:152-157 geometry, :362-367 colour):
+// pointcloud.nn_weighting 'distance' = 1 / (D + 1e-10), 'expo' = exp(-20 sqrt(D)); 0 beyond the query radius.  DecodeArgs.flags bit
+// kFlagExpoW selects 'expo' (psl_config.nn_weighting; no shipped config uses it).
+constexpr int kFlagExpoW = 0x20000;
+__device__ __forceinline__ float nn_weight(float D, float r2, bool expo) {
+  if (D > r2) return 0.f;
+  return expo ? expf(__fmul_rn(-20.0f, sqrtf(D))) : 1.0f / (D + 1e-10f);
+}
+// (No derivative with respect to D for 'expo': the tracker's pose gradient through exp(-20 sqrt(D)) does not exist in the reference either --
+// decoder.py:157 zeroes the exp's output in place and autograd raises in backward --, so psl_render_fwd refuses PSL_PTS_GRAD with it.)
+
 // (2*pi*p) . B[:, f] -- the Fourier phase of decoder.py:33 (matmul of [.,3] by [3,F])
 __device__ __forceinline__ float fourier_phase(float x, float y, float z, const float* __restrict__ B, int F, int f) {
   float x2 = __fmul_rn(TWO_PI, x), y2 = __fmul_rn(TWO_PI, y), z2 = __fmul_rn(TWO_PI, z);

@@ -82,7 +82,7 @@ __device__ __forceinline__ void geo_tile(const DecodeArgs& a, const float* __res
   for (int k = 0; k < K; ++k) {
     const float4 q = a.pos[max(nb[k], 0)];
     const float D = (nb[k] >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-    w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+    w[k] = nn_weight(D, sg.r2, (a.flags & kFlagExpoW) != 0);
   }
   // the reference sums the 8 weights inside F.normalize(p=1); any order is within 1 ulp
   const float wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
@@ -251,7 +251,7 @@ __device__ __forceinline__ void color_tile(const DecodeArgs& a, const float* __r
     const SampleGeom sg = sample_geom(a, p);
     const float4 q = a.pos[max(i, 0)];
     const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-    float w = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+    float w = nn_weight(D, sg.r2, (a.flags & kFlagExpoW) != 0);
     float sum = w;
     sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
     w = w / fmaxf(sum, 1e-12f);
@@ -473,7 +473,7 @@ __device__ __forceinline__ void nbr_unit_fwd(const DecodeArgs& a, const float* _
     for (int r = 0; r < 4; ++r) { xf[0][r] = (i >= 0) ? v0[r] : 0.f; xf[1][r] = (i >= 0) ? v1[r] : 0.f; }
   }
   const float D = (i >= 0) ? dist2(q.x, q.y, q.z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-  float wgt = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+  float wgt = nn_weight(D, sg.r2, (a.flags & kFlagExpoW) != 0);
   wgt = wgt / fmaxf(group8_sum(wgt), 1e-12f);
   const float rx = (i >= 0) ? __fsub_rn(q.x, sg.x) : 0.f, ry = (i >= 0) ? __fsub_rn(q.y, sg.y) : 0.f,
               rz = (i >= 0) ? __fsub_rn(q.z, sg.z) : 0.f;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float D = (nb[k] >= 0) ? dist2(qp[k].x, qp[k].y, qp[k].z, sg.x, sg.y, sg.z) : __int_as_float(0x7F800000);
-    w[k] = (D > sg.r2) ? 0.f : 1.0f / (D + 1e-10f);
+    w[k] = nn_weight(D, sg.r2, (a.flags & kFlagExpoW) != 0);
   }
   const float wsum = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
   const float inv = fmaxf(wsum, 1e-12f);

@@ -85,7 +85,8 @@ class HipNeuralPointCloud(object):
                             far_end_surface=cfg['rendering']['far_end_surface'],
                             radius_query=self.radius_query, max_query_radius=max_r,
                             encode_rel_pos=1 if cfg['model']['encode_rel_pos_in_col'] else 0,
-                            max_points=max_points)
+                            max_points=max_points,
+                            nn_weighting={"distance": 0, "expo": 1}[pc.get('nn_weighting', 'distance')])       # decoder.py:89,288
         dev = torch.device(self.device)
         self._dev_index = dev.index if dev.index is not None else 0
         h = C.c_void_p()

@@ -45,6 +45,8 @@ def cfg_variant(name):
     if name == "tum":
         cfg["use_dynamic_radius"] = False
         cfg["model"]["encode_rel_pos_in_col"] = False
+    elif name == "replica_expo":     # pointcloud.nn_weighting = 'expo' (decoder.py:154-156, 364-366; no shipped config)
+        cfg["pointcloud"]["nn_weighting"] = "expo"
     elif name == "scannet":
         cfg["model"]["encode_rel_pos_in_col"] = False
         cfg["model"]["encode_exposure"] = True
@@ -87,7 +89,9 @@ def fixture_cfg(fx):
 # logits (PSL_NO_SIGMOID); the per-frame affine + sigmoid are applied by the caller (decoder.py:432-448, Mapper.py:530-548)
 RENDER_CASES = ["render_replica_color_tracker", "render_replica_color_mapper", "render_replica_geometry_mapper",
                 "render_tum_color_mapper", "render_scannet_color_tracker", "render_holes_nearpcl_mapper",
-                "render_holes_uniform_tracker", "render_scannet_color_mapper"]
+                "render_holes_uniform_tracker", "render_scannet_color_mapper",
+                # nn_weighting = 'expo' (round 6): the mapper's two stages; the reference's TRACKER raises with it (gen_golden.py)
+                "render_expo_color_mapper", "render_expo_geometry_mapper"]
 ORACLE_ONLY_CASES = []
 
 

@@ -441,3 +441,47 @@ def test_map_iters_140_iterations_vs_oracle(semantics):
         assert rep["lazy_loss_rel_mean"] <= 3.0 * rep["dense_loss_rel_mean"] + 1e-5
         assert rep["lazy_geo_mean"] <= 3.0 * rep["dense_geo_mean"] + 1e-6
         assert rep["lazy_col_mean"] <= 3.0 * rep["dense_col_mean"] + 1e-6
+
+
+def test_map_iters_expo_weighting_vs_oracle():
+    """pointcloud.nn_weighting = 'expo' (decoder.py:154-156, 364-366; no shipped config uses it, the reference's tracker cannot run with it)
+    through psl_map_iters: 24 iterations (9 geometry-stage ones through the one-launch geometry kernel, then the colour stage with F_theta),
+    frozen colour decoder so that nothing amplifies rounding, against O.mapper_iterations on identical draws -- every loss inside 1e-4."""
+    from oracle import pointslam_oracle as O
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _long_scene(dev)
+    cfg["pointcloud"]["nn_weighting"] = "expo"
+    cfg["mapping"]["fix_color_decoder"] = True
+    n_iters, ppf = 24, 400
+    n_geo = int(n_iters * cfg["mapping"]["geo_iter_ratio"])
+    g = torch.Generator().manual_seed(31)
+    idx = torch.randint(cam["H"] * cam["W"], (n_iters, 3 * ppf), generator=g, dtype=torch.int32)
+    fb = torch.zeros(n_iters, 2, 32).normal_(mean=0, std=0.01, generator=g)
+    draws = (idx.to(dev).contiguous(), fb.to(dev).contiguous())
+    s, sel = _native_long_run(cfg, cam, frames, pts, dev, n_iters, ppf, n_geo, draws, True, "torch2", n_mapped=0)
+    ls = s.last_losses.cpu().double()[:, 0]
+    geo, col = s.npc.geo_feats.cpu().clone(), s.npc.col_feats.cpu().clone()
+    sel = sel.cpu().long()
+    from point_slam_amd.decoders import PointDecoders
+    from point_slam_amd.slam import HipSLAM
+    s0 = HipSLAM(cfg, cam, device="cuda:0", max_points=200000, engine="native",
+                 decoders=PointDecoders(cfg).load_reference_state(load_decoders("replica")))
+    s0.seed_points(pts, seed=77)
+    st = _oracle_inputs(s0)
+    del s0
+    O.KNN_WORKERS = 8
+    ls_o, geo_o, col_o, _, _, _ = O.mapper_iterations(cfg, st["P"], st["cloud"], st["geo"], st["col"], sel, _oracle_frames(frames),
+                                                      idx.reshape(n_iters, 3, ppf), fb, n_geo, cam, torch1_zero_grads=False)
+    ref = torch.tensor(ls_o, dtype=torch.float64)
+    rel = (ls - ref).abs() / ref.abs()
+    # the same run with 'distance' weights must differ visibly: the option is live in every kernel of the loop
+    cfg_d, _, _, _ = _long_scene(dev)
+    cfg_d["mapping"]["fix_color_decoder"] = True
+    s_d, _ = _native_long_run(cfg_d, cam, frames, pts, dev, n_iters, ppf, n_geo, draws, True, "torch2", n_mapped=0)
+    ls_d = s_d.last_losses.cpu().double()[:, 0]
+    rep = dict(test="map_iters_expo_vs_oracle", n_iters=n_iters, n_geo=n_geo, loss_rel_max=float(rel.max()), loss_rel_geo_stage=float(rel[:n_geo + 1].max()),
+               geo_mean=float((geo[sel] - geo_o[sel]).abs().mean()), col_mean=float((col[sel] - col_o[sel]).abs().mean()),
+               distance_vs_expo_loss_rel=float(((ls_d - ls).abs() / ls.abs()).max()))
+    report(**rep)
+    assert rep["loss_rel_max"] <= 1e-4 and rep["geo_mean"] < 1e-4 and rep["col_mean"] < 1e-4
+    assert rep["distance_vs_expo_loss_rel"] > 1e-3

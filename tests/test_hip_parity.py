@@ -220,6 +220,23 @@ def test_render_forward_matches_reference(dev, case, color_structure):
     assert rep["color_loss_rel"] < 1e-4
 
 
+def test_expo_weighting_refuses_the_pose_gradient(dev):
+    """pointcloud.nn_weighting = 'expo' with is_tracker=True: the reference raises in backward (decoder.py:157 / 367 zero the output of
+    torch.exp in place; checked by oracle/gen_golden.py run_expo_cases) -- the library refuses the call instead of inventing a gradient."""
+    from point_slam_amd import _lib
+    fx = load_npz("render_expo_color_mapper")
+    cfg = fixture_cfg(fx)
+    assert cfg["pointcloud"]["nn_weighting"] == "expo"
+    dec = make_decoders(cfg, fx["cfg_name"], dev)
+    npc = make_npc(cfg, fx["cloud"], fx["geo"], fx["col"], dev)
+    rend = make_renderer(cfg, fx["coef"])
+    rend.fixed_fallback = (fx["fb_geo"].to(dev), fx["fb_col"].to(dev))
+    ro, rd = fx["rays_o"].to(dev).requires_grad_(True), fx["rays_d"].to(dev).requires_grad_(True)
+    with pytest.raises(_lib.PslError, match="expo"):
+        rend.render_batch_ray(npc, dec, rd, ro, dev, "color", gt_depth=fx["gt_depth"].to(dev), npc_geo_feats=fx["geo"].to(dev),
+                              npc_col_feats=fx["col"].to(dev), is_tracker=True, dynamic_r_query=fx["r_query"].to(dev))
+
+
 # ------------------------------------------------------------------------------ render backward
 @pytest.mark.parametrize("case", RENDER_CASES)
 def test_render_backward_matches_reference(dev, case, color_structure):
