@@ -150,7 +150,7 @@ def test_refine_runs_five_passes_over_all_rows():
     assert bool(torch.isfinite(s.last_losses).all())
 
 
-@pytest.mark.parametrize("case", ["tracker_iters_tum", "tracker_iters_scannet"])
+@pytest.mark.parametrize("case", ["tracker_iters_tum", "tracker_iters_scannet", "tracker_iters_replica_1500"])
 def test_track_iters_native_matches_reference_loop(case, color_structure):
     from point_slam_amd.slam import Frame
     dev = torch.device("cuda:0")
