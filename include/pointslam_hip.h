@@ -416,6 +416,8 @@ int64_t psl_knn_candidates(psl_ctx* ctx);
  * "track_fused" launch structure of psl_track_iters: 0 = ten launches per iteration; 1 = pre / mid launches for batches <= 1024 rays;
  * 2 = the ray stage inside the decode backward (four launches); 3 (default) = also the pose step inside the k-NN launch and the
  * pose-independent ray set-up of all iterations in one launch per call (three launches; eight above 1024 rays) -- bit-identical results;
+ * "knn_start_hint" bits 0 / 1: ray k-NN launches below 5 000 queries start at the pass the row lengths suggest / carry the eighth-best
+ * bound of a pass that did not close into the next one (default 3); bits 2 / 3 the same for larger launches (default off) -- same answers;
  * "color_split" launch structure of the colour-stage decode (decoder.py:341-449): 0 = fused 16-sample tiles, 2 = split F_theta /
  * trunk kernels, 1 (default) = split beyond 384 tiles; "wave_trunk" = tiles from which the split structure's trunk forward runs
  * one wavefront per tile (default 1024, 0 = never).  Results are the same to fp32 rounding of one sum order (the colour head) */

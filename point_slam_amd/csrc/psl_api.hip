@@ -384,7 +384,7 @@ static const char* kProfNames[PROF_N] = {"knn", "decode_fwd", "composite_fwd", "
 extern "C" const char* psl_profile_name(int i) { return (i >= 0 && i < PROF_N) ? kProfNames[i] : ""; }
 extern "C" int psl_profile_classes(void) { return PROF_N; }
 
-namespace psl { extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
+namespace psl { extern int g_knn_start_hint; extern int g_knn_version, g_lazy_adam, g_track_fused, g_dw_fused, g_knn_overlap, g_geo_fused, g_ray_in_bwd, g_remap_cv2; int knn_trace_dump(); }
 // debug / A-B switch settable at run time (tests compare kernel generations inside one process)
 extern "C" int psl_debug_option(const char* name, int value) {
   if (!name) return PSL_ERR_ARG;
@@ -399,6 +399,7 @@ extern "C" int psl_debug_option(const char* name, int value) {
   if (!strcmp(name, "ray_in_bwd")) { psl::g_ray_in_bwd = value; return PSL_OK; }
   if (!strcmp(name, "remap_cv2")) { psl::g_remap_cv2 = value; return PSL_OK; }
   if (!strcmp(name, "knn_trace_dump")) return psl::knn_trace_dump();
+  if (!strcmp(name, "knn_start_hint")) { psl::g_knn_start_hint = value; return PSL_OK; }
   set_error("psl_debug_option: unknown option %s", name);
   return PSL_ERR_ARG;
 }

@@ -357,9 +357,11 @@ __device__ __forceinline__ int log2_bucket(unsigned long long v) { int b = 0; wh
 //      at a time -- up to 512 records in flight per wavefront instead of 48.
 // A box with fewer than 8 candidates cannot close the search and is not scanned at all.  Same keys, same order relation,
 // bit-identical answers to knn_scan_rows_lane.
+int g_knn_start_hint = 3;                      // psl_debug_option("knn_start_hint", bits): see knn_rays (bits 1 / 2 of the kernels' `trace` argument switch the two mechanisms off)
 constexpr int kFlatRows = 128;                  // >= rows of all passes of a query together (9 + 25 + 81 at cell = r_max / 4)
 constexpr int kFlatPasses = 3;                 // cell = r_max / 4: radii cell, 2 cell, r
 struct FlatLds { int rbeg[kFlatRows]; int rcnt[kFlatRows];            // [begin, length) of every row of every pass
+                 float rd2[kFlatRows];                                  // lower bound of the squared (y, z) distance from the query to the row
                  int beg[kFlatRows]; int cnt[kFlatRows]; int off[kFlatRows + 1]; };   // non-empty rows of the current pass
 
 // [begin, length) of row (cz, cy) of the box of radius `re` around q, TRIMMED to the sphere: a row whose (y, z) interval
@@ -368,7 +370,7 @@ struct FlatLds { int rbeg[kFlatRows]; int rcnt[kFlatRows];            // [begin,
 // Conservative: the box inflation of box_of plus a margin on the cell intervals; boundary cells are unbounded (points
 // beyond the grid's extent are clamped into them).
 __device__ __forceinline__ void flat_row_range(const GridMeta& m, const int* __restrict__ cell_start, const CellBox& bx, int row,
-                                               int ny_b, float qx, float qy, float qz, float re, int& beg, int& cnt) {
+                                               int ny_b, float qx, float qy, float qz, float re, int& beg, int& cnt, float& d2yz) {
   const int cz = bx.lo[2] + row / ny_b, cy = bx.lo[1] + row % ny_b;
   const float rr = re * 1.0001f + 1e-6f, eps = 1e-4f * m.cell;
   float dy = 0.f, dz = 0.f;
@@ -379,7 +381,8 @@ __device__ __forceinline__ void flat_row_range(const GridMeta& m, const int* __r
     if (qz < lz && cz > 0) dz = lz - qz; else if (qz > hz && cz < m.nz - 1) dz = qz - hz;
     dy = fmaxf(dy - eps, 0.f); dz = fmaxf(dz - eps, 0.f);
   }
-  const float w2 = rr * rr - dy * dy - dz * dz;
+  d2yz = dy * dy + dz * dz;
+  const float w2 = rr * rr - d2yz;
   beg = 0; cnt = 0;
   if (!(w2 >= 0.f)) return;
   const float w = sqrtf(w2) * 1.0001f + eps;
@@ -393,14 +396,15 @@ __device__ __forceinline__ void flat_row_range(const GridMeta& m, const int* __r
 // one pass over the rows [row0, row0 + nrows) of the table that wave_knn_flat has filled
 template <int U>
 __device__ __forceinline__ void knn_scan_flat(const float4* __restrict__ spos, float qx, float qy, float qz, u64& mine, u64& thr,
-                                              unsigned long long& cand, FlatLds& L, int row0, int nrows, bool need_full) {
+                                              unsigned long long& cand, FlatLds& L, int row0, int nrows, bool need_full, float dmax2) {
   const int lane = threadIdx.x & 63;
   // compact the non-empty rows into the pass table: position = number of non-empty rows before this one
   int n_tab = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int row = lane + 64 * h;
-    const int b = row < nrows ? L.rbeg[row0 + row] : 0, c = row < nrows ? L.rcnt[row0 + row] : 0;
+    const int b = row < nrows ? L.rbeg[row0 + row] : 0;
+    const int c = (row < nrows && !(L.rd2[row0 + row] > dmax2)) ? L.rcnt[row0 + row] : 0;   // rows beyond the bound a smaller pass left hold nothing
     const u64 ne = __ballot(c > 0);
     if (c > 0) { const int k = n_tab + __popcll(ne & ((1ull << lane) - 1ull)); L.beg[k] = b; L.cnt[k] = c; }
     n_tab += __popcll(ne);
@@ -463,7 +467,7 @@ template <int U>
 __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* __restrict__ spos,
                                               const int* __restrict__ cell_start, float qx, float qy, float qz, float r,
                                               float r2, u64& mine, unsigned long long& cand, const int* __restrict__ coarse,
-                                              int& passes, FlatLds& L) {
+                                              int& passes, FlatLds& L, bool start_hint, bool carry_bound) {
   const int lane = threadIdx.x & 63;
   passes = 0;
   // the radii of the expanding search (one cell, doubling, the last one = r) and their boxes: known before any load.
@@ -495,33 +499,71 @@ __device__ __forceinline__ void wave_knn_flat(const GridMeta& m, const float4* _
   }
   // ONE trip for the row ranges of ALL passes (two rows per lane) and, concurrently, the coarse occupancy test
   int rb[2], rc[2];
+  float rd[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int gr = lane + 64 * h;
-    rb[h] = 0; rc[h] = 0;
+    rb[h] = 0; rc[h] = 0; rd[h] = 0.f;
 #pragma unroll
     for (int k = 0; k < kFlatPasses; ++k)
-      if (gr >= base[k] && gr < base[k + 1]) flat_row_range(m, cell_start, bx[k], gr - base[k], nyb[k], qx, qy, qz, re[k], rb[h], rc[h]);
+      if (gr >= base[k] && gr < base[k + 1]) flat_row_range(m, cell_start, bx[k], gr - base[k], nyb[k], qx, qy, qz, re[k], rb[h], rc[h], rd[h]);
   }
   const bool empty = coarse && wave_box_empty(m, coarse, qx, qy, qz, qx, qy, qz, r);
   if (empty) { mine = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull; return; }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { const int gr = lane + 64 * h; if (gr < base[kFlatPasses]) { L.rbeg[gr] = rb[h]; L.rcnt[gr] = rc[h]; } }
+  for (int h = 0; h < 2; ++h) { const int gr = lane + 64 * h; if (gr < base[kFlatPasses]) { L.rbeg[gr] = rb[h]; L.rcnt[gr] = rc[h]; L.rd2[gr] = rd[h]; } }
   wave_lds_sync();
+  // Where to start (round 6).  A pass whose whole candidate list fits ONE trip of U records per lane costs the same whatever its
+  // radius (two dependent memory trips + the table), and a larger radius closes the search wherever a smaller one would have, and more
+  // often: the search starts at the LARGEST pass of at most 64 U candidates -- known from the row lengths, before anything is scanned.
+  // Any starting pass gives the same answer: a pass closes only with eight points inside its own radius, all of which it has scanned.
+  int start = 0;
+  if (start_hint) {
+    unsigned pk = 0;                          // bits 0..15: candidates of pass 1, bits 16..31: of pass 2 (rows clamped to 511: 128 rows < 2^16)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int gr = lane + 64 * h;
+      const unsigned c = (unsigned)min(rc[h], 511);
+      if (gr >= base[1] && gr < base[2]) pk += c;
+      if (gr >= base[2] && gr < base[3]) pk += c << 16;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pk += (unsigned)__shfl_xor((int)pk, o);
+    if (np >= 2 && (pk & 0xFFFFu) <= 64u * U) start = 1;
+    if (np >= 3 && (pk >> 16) <= 64u * U) start = 2;
+  }
+  // Every pass admits candidates up to the QUERY radius, not only up to its own (round 6): a pass that does not close -- fewer than
+  // eight points inside its radius -- still leaves the eighth-best distance of its box, an upper bound of the answer's, and the next pass
+  // starts from it: its list admits nothing farther, and rows of its box whose (y, z) distance exceeds the bound are not read at all.
+  // (Before, the last pass of a sample 10 cm off a surface read the 1 000-3 600 points of the whole 16-cm sphere to find eight at 10-11 cm;
+  //  the slowest query of a launch sets its duration.)  Same answers: a pass closes when its eighth entry lies inside its own radius.
+  const u64 sentinel_r = ((u64)__float_as_uint(r2) << 32) | 0xFFFFFFFFull;
+  u64 carry = 0ull;
   bool closed = false;
 #pragma unroll
   for (int k = 0; k < kFlatPasses; ++k) {
-    if (k < np && !closed) {
+    if (k < np && k >= start && !closed) {
       const bool last = k == np - 1;
       const float t2 = last ? r2 : __fmul_rn(re[k], re[k]);
-      const u64 sentinel = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
-      mine = sentinel;
-      u64 thr = sentinel;
-      knn_scan_flat<U>(spos, qx, qy, qz, mine, thr, cand, L, base[k], base[k + 1] - base[k], last);
+      const u64 sentinel_k = ((u64)__float_as_uint(t2) << 32) | 0xFFFFFFFFull;
+      // the bound is only usable where this pass reads every point inside it: its own radius must reach the bound (always true for the
+      // last pass, whose radius is the query radius)
+      const bool bounded = carry_bound && carry != 0ull && (last || (unsigned)(carry >> 32) <= __float_as_uint(t2));
+      const u64 init = bounded ? carry : (carry_bound ? sentinel_r : sentinel_k);
+      mine = init;
+      u64 thr = init;
+      const float dmax2 = bounded ? __uint_as_float((unsigned)(carry >> 32)) : __int_as_float(0x7F800000);
+      knn_scan_flat<U>(spos, qx, qy, qz, mine, thr, cand, L, base[k], base[k + 1] - base[k], last || bounded, dmax2);
       ++passes;
-      closed = last || thr != sentinel;
+      const bool full = thr != init;                       // the eighth slot holds a point
+      closed = last || (full && thr <= sentinel_k);
+      // next float above the eighth-best distance, "no point" index: admits the eighth-best itself when the next pass meets it again, and a
+      // slot that stayed empty would decode as "no neighbour" (cannot happen: the eight points of this pass lie inside the next one's reach)
+      const u64 up = ((u64)((unsigned)(thr >> 32) + 1u) << 32) | 0xFFFFFFFFull;
+      carry = (carry_bound && full) ? (up < sentinel_r ? up : sentinel_r) : 0ull;
     }
   }
+  // (slots that never received a point keep `init`, whose index part is the "no neighbour" marker in every case)
 }
 
 // ray mode, small launches: one wave per SAMPLE with the flat enumeration; outputs as k_knn_rays
@@ -628,7 +670,7 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
   const int p_raw = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const int p = POSE == 1 ? min(p_raw, n_rays * S - 1) : p_raw;      // (POSE 1: every wavefront goes through the prologue's barriers)
   if (POSE != 1 && p >= n_rays * S) return;
-  const unsigned long long t0 = trace ? clock64() : 0ull;
+  const unsigned long long t0 = (trace & 1) ? clock64() : 0ull;
   const int ray = p / S, si = p - ray * S;
   const int lane = threadIdx.x & 63;
   // everything that does not depend on the pose is requested in front of the prologue
@@ -665,12 +707,12 @@ __global__ __launch_bounds__(256, MINW) void k_knn_rays_flat(const GridMeta* __r
   u64 mine;
   unsigned long long n_cand = 0;
   int n_pass = 0;
-  wave_knn_flat<U>(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass, lds[(threadIdx.x >> 6) & 3]);
+  wave_knn_flat<U>(m, spos, cell_start, qx, qy, qz, r, r2, mine, n_cand, coarse, n_pass, lds[(threadIdx.x >> 6) & 3], (trace & 2) == 0, (trace & 4) == 0);
   const unsigned ib = (unsigned)(mine & 0xFFFFFFFFull), db = (unsigned)(mine >> 32);
   const int cnt = __popcll(__ballot(lane < K && ib != 0xFFFFFFFFu && db < __float_as_uint(r2)));
   if (lane < K) I_out[p * K + lane] = (ib == 0xFFFFFFFFu) ? -1 : (int)ib;
   if (lane == 0) { cnt_out[p] = cnt; if (cand_counter) atomicAdd(cand_counter + 8 * (blockIdx.x & (kKnnCandSlots - 1)), n_cand); }
-  if (trace && lane == 0) {
+  if ((trace & 1) && lane == 0) {
     const unsigned long long cyc = clock64() - t0;
     atomicAdd(&g_knn_trace.n, 1ull); atomicAdd(&g_knn_trace.sum_cyc, cyc); atomicMax(&g_knn_trace.max_cyc, cyc);
     atomicAdd(&g_knn_trace.sum_cand, n_cand); atomicMax(&g_knn_trace.max_cand, n_cand);
@@ -1000,7 +1042,8 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   const int ver = (g_knn_version == 2 || g_knn_version == 4) ? g_knn_version : (max_blocks > 0 ? 2 : 4);
   if (ver == 4) {
     static int trace4 = -1;
-    if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0; }
+    if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0;
+                      const char* h = getenv("PSL_KNN_START_HINT"); if (h) g_knn_start_hint = atoi(h); }
     // queries from which the high-occupancy instantiation <4 records in flight, 8 wavefronts per SIMD> is used (it is held to
     // 64 VGPRs and spills two registers to scratch, profiles/r05_kernel_resources.json; PSL_KNN_FLAT_LARGE, < 0 = never).
     // Measured [MI355X, round 4]: 25 000 queries (TUM / ScanNet tracker) 74.6 -> 64.1 us, TUM yaml +2.7 %, ScanNet +1 %,
@@ -1010,10 +1053,17 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
     unsigned long long* cand = (ctx->prof_on || trace4) ? ctx->knn_cand : nullptr;   // one atomic per query: only while measured
     const TrackPose* tpp = static_cast<const TrackPose*>(ctx->track_pose);
     const bool large = large_from >= 0 && n_rays * S >= large_from;
+    // g_knn_start_hint: bit 0 = start at the pass the row lengths suggest, bit 1 = carry the eighth-best bound into the next pass; each for the
+    // launches below 5 000 queries, bits 2 / 3 the same for the larger ones.  Default 3: measured [MI355X] 26.5 -> 22.2 us on the 1 000-query
+    // tracker launch (the bound does it; the start pass alone 26.0); at 7 500 queries 35.5 -> 34.2 us on the 1 M-point cloud but 28.1 -> 28.4 on
+    // the 50 k-point cloud of config 1, and 69.6 -> 73.7 us at 25 000 queries (more admitted candidates and insertions per query: the wrong
+    // trade where the launch is bound by its total work), so the larger launches keep the plain expanding search
+    const int hb = (n_rays * S >= 5000) ? (g_knn_start_hint >> 2) : g_knn_start_hint;
+    const int knn_mode_bits = ((hb & 1) ? 0 : 2) | ((hb & 2) ? 0 : 4);
 #define PSL_KNN_FLAT(UU, WW, PP, TP)                                                                                               \
     PSL_KLAUNCH((k_knn_rays_flat<UU, WW, PP>), dim3((n_rays * S + 3) / 4), dim3(256), 0, s, ctx->meta, ctx->spos, ctx->cell_start, \
                 rays_o, rays_d, depth, z_vals, r_query, ctx->cfg.radius_query, r2_of(ctx->cfg.radius_query),                        \
-                ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4, TP)
+                ctx->cfg.near_end_surface, ctx->cfg.far_end_surface, n_rays, I_out, cnt_out, cand, ctx->coarse, trace4 | knn_mode_bits, TP)
     if (tpp && !tpp->rotate_only) PSL_KNN_FLAT(8, 5, 1, *tpp);       // psl_track_iters, batches <= 1 024 rays: pose step in the prologue
     else if (tpp && large) PSL_KNN_FLAT(4, 8, 2, *tpp);              // larger tracker batches: directions turned here, no ray set-up launch
     else if (tpp) PSL_KNN_FLAT(8, 5, 2, *tpp);

@@ -169,13 +169,20 @@ def test_ray_knn_matches_oracle_at_1m_points(world, n_rays, seed):
     P = 5 * R
     Ppad = (P + 15) // 16 * 16
     got = {}
-    for ver in (2, 4):    # the two kernels that exist: one wavefront per ray (the mapper's side-stream prefetch), one per sample
+    # the two kernels that exist: one wavefront per ray (the mapper's side-stream prefetch), one per sample -- the latter with its two
+    # round-6 mechanisms (start pass chosen from the row lengths, eighth-best bound carried into the next pass) off everywhere (0) and
+    # on at every launch size (15; the default, 3, applies them below 5 000 queries only)
+    for ver, hint in ((2, 3), (4, 0), (4, 15)):
         _lib.check(L.psl_debug_option(b"knn", ver))
+        _lib.check(L.psl_debug_option(b"knn_start_hint", hint))
         ws.zero_()
         _lib.check(L.psl_render_fwd(s.npc.handle, C.byref(a), _lib.stream_ptr()))
         torch.cuda.synchronize()
-        got[ver] = (ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long().clone(),
-                    ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu().clone())
+        got[(ver, hint)] = (ws[:Ppad * 8].view(torch.int32).reshape(Ppad, 8)[:P].cpu().long().clone(),
+                            ws[Ppad * 8:Ppad * 9].view(torch.int32)[:P].cpu().clone())
+    _lib.check(L.psl_debug_option(b"knn_start_hint", 3))
+    assert torch.equal(got[(4, 0)][0], got[(4, 15)][0]) and torch.equal(got[(4, 0)][1], got[(4, 15)][1])
+    got = {2: got[(2, 3)], 4: got[(4, 15)]}
     I, cnt = got[2]
     z = O.z_samples(gd.cpu(), 0.98, 1.02, 5)
     q = O.sample_points(ro.cpu(), rd.cpu(), z)
