@@ -1039,7 +1039,8 @@ int knn_rays(psl_ctx* ctx, const float* rays_o, const float* rays_d, const float
   //    walk several rays each, next to the decode kernels of the previous block).
   // Rounds 2-4 carried two more per-sample kernels (row walk; four wavefronts per sample, "measured equal"): deleted in
   // round 5, the flat enumeration replaced both everywhere (DESIGN_HISTORY.md).
-  const int ver = (g_knn_version == 2 || g_knn_version == 4) ? g_knn_version : (max_blocks > 0 ? 2 : 4);
+  // (a launch that carries the tracker's pose step or turns its directions -- ctx->track_pose -- exists in the per-sample kernel only)
+  const int ver = ctx->track_pose ? 4 : ((g_knn_version == 2 || g_knn_version == 4) ? g_knn_version : (max_blocks > 0 ? 2 : 4));
   if (ver == 4) {
     static int trace4 = -1;
     if (trace4 < 0) { const char* e = getenv("PSL_KNN_TRACE"); trace4 = (e && e[0] == '1') ? 1 : 0;

@@ -229,6 +229,37 @@ def test_track_launch_structures_agree(n_pix, exposure):
     report(test="track_launch_structures", n_pix=n_pix, exposure=exposure, **{f"v{k}": v for k, v in rep.items()})
 
 
+def test_tracker_ignores_the_per_ray_knn_switch():
+    """psl_debug_option("knn", 2) forces the one-wavefront-per-ray k-NN kernel on the launches that can use either kernel.  The tracker's
+    launch cannot since round 6 (its pose step / the turn of its ray directions live in the per-sample kernel's prologue): with the switch
+    set it must keep its kernel and end at the same pose, bit for bit, at both launch structures (200 and 1 500 rays)."""
+    from point_slam_amd import _lib
+    from point_slam_amd.decoders import PointDecoders
+    from point_slam_amd.slam import HipSLAM, camera_tensor_from_c2w
+    dev = torch.device("cuda:0")
+    cfg, cam, frames, pts = _scene(dev)
+    cam0 = camera_tensor_from_c2w(frames[1].c2w) + torch.tensor([0.002, -0.001, 0.0015, 0.001, 0.01, -0.008, 0.006])
+    L = _lib.lib()
+    for n_pix in (200, 1500):
+        ends = {}
+        try:
+            for ver in (0, 2):
+                _lib.check(L.psl_debug_option(b"knn", ver))
+                s = HipSLAM(cfg, cam, device="cuda:0", max_points=400000, engine="native",
+                            decoders=PointDecoders(cfg).load_reference_state(load_decoders("replica")))
+                s.seed_points(pts)
+                torch.manual_seed(11)
+                draws = s._draws(6, n_pix, (cam["H"] - 40) * (cam["W"] - 40))
+                s._draws = lambda *a, **k: draws
+                s.track(frames[1], cam0, n_iters=6, n_pix=n_pix)
+                torch.cuda.synchronize()
+                ends[ver] = (s.last_cam.cpu().clone(), s.last_losses.cpu().clone())
+        finally:
+            _lib.check(L.psl_debug_option(b"knn", 0))
+        assert torch.equal(ends[0][0], ends[2][0]) and torch.equal(ends[0][1], ends[2][1]), n_pix
+        assert bool(torch.isfinite(ends[0][1]).all())
+
+
 @pytest.mark.parametrize("remap", ["cv2", "exact"])
 def test_frustum_select_matches_oracle(remap):
     """Both depth-lookup rules of the frustum selection (Mapper.py:149-155) against their oracle restatements: "cv2" =
