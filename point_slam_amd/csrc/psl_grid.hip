@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ p
     int c = (cz * m->ny + cy) * m->nx + cx;
     cell_of[i] = c;
     atomicAdd(&cell_fill[c], 1);
-    atomicAdd(&coarse[((cz >> 2) * m->cny + (cy >> 2)) * m->cnx + (cx >> 2)], 1);
+    // occupancy FLAG of the 4x4x4-cell block (wave_box_empty tests it against zero only): a plain store -- as a counter it was 10^6
+    // atomics on ~10^4 addresses, the hot part of this kernel
+    coarse[((cz >> 2) * m->cny + (cy >> 2)) * m->cnx + (cx >> 2)] = 1;
   }
 }
 

@@ -682,7 +682,9 @@ __global__ __launch_bounds__(256) void k_frustum_dmax(const float4* __restrict__
   unsigned b = __float_as_uint(d);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o));
-  if ((threadIdx.x & 63) == 0 && b) atomicMax(dmax_bits, b);
+  // one address for the whole launch: a wavefront whose maximum cannot raise the value it reads there leaves without the atomic
+  // (16 k same-address atomics were 120 us of a kernel that reads 16 MB)
+  if ((threadIdx.x & 63) == 0 && b > __atomic_load_n(dmax_bits, __ATOMIC_RELAXED)) atomicMax(dmax_bits, b);
 }
 
 template <bool CV2>
