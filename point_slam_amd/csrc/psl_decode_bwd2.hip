@@ -1419,6 +1419,8 @@ __global__ __launch_bounds__(NBR_WG_B, 3) void k_nbr_bwd(DecodeArgs a, Bwd2Out o
 template <bool PTSG, bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_bwd2(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int color_tiles,
                                                                                             RayFuse rf, AdamWorklist wl, int wl_block0, TrackFuse tf) {
+  // above the mapper's side-stream k-NN prefetch (priority 0), whose waves share the SIMDs of this launch for 2 of every 7 ms of a mapped frame
+  __builtin_amdgcn_s_setprio(1);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (COLOR && (int)blockIdx.x >= wl_block0) {
     worklist_role_wave(wl, ((int)blockIdx.x - wl_block0) * (int)blockDim.x + (int)threadIdx.x);

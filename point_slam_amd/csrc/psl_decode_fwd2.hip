@@ -812,6 +812,8 @@ __global__ __launch_bounds__(WG, 2) void k_trunk_fwd(DecodeArgs a, const float* 
 // workgroups, geometry role only); two instantiations so that profiles tell them apart.
 template <bool COLOR>
 __global__ __launch_bounds__(COLOR ? WG : 64, COLOR ? 4 : 2) void k_decode_fwd2(DecodeArgs a, const float* __restrict__ WF, int color_tiles) {
+  // above the mapper's side-stream k-NN prefetch (priority 0), whose waves share the SIMDs of this launch for 2 of every 7 ms of a mapped frame
+  __builtin_amdgcn_s_setprio(1);
   if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);

@@ -298,6 +298,8 @@ __device__ __forceinline__ void geo_iter_tile(const DecodeArgs& a, const float* 
 __global__ __launch_bounds__(64, 2) void k_geo_iter(DecodeArgs a, const float* __restrict__ WF, const float* __restrict__ WB,
                                                     GeoIterRays gr, float* g_geo, const int* __restrict__ row_map,
                                                     unsigned char* t_geo, AdamWorklist wl, int n_tiles, int n_wl_blocks) {
+  // above the mapper's side-stream k-NN prefetch (priority 0), whose waves share the SIMDs of this launch for 2 of every 7 ms of a mapped frame
+  __builtin_amdgcn_s_setprio(2);
   __shared__ ScatterLds sl;
   BlkTrace bt(a);
   if ((int)blockIdx.x < n_tiles) {

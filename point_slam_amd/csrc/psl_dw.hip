@@ -149,6 +149,7 @@ __device__ __forceinline__ void dw_tile(const DwJob& J, int item, int chunk, flo
 }
 
 __global__ __launch_bounds__(256) void k_dw(DwArgs d) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   const int wid = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   if (wid >= d.n_items) return;
   int item = wid;

@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void k_map_adam(AdamRowsSeg geo, AdamRowsSeg c
 template <int LPR>
 __global__ __launch_bounds__(256) void k_map_adam_lazy(AdamRowsSeg geo, AdamRowsSeg col, AdamParSeg par, int nb_rows, int n_groups,
                                                        float b1, float b2, float eps, AdamLazy lz) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   int blk0 = blockIdx.x;
   if (blk0 >= nb_rows * n_groups) { adam_par_segment(par, blk0 - nb_rows * n_groups, b1, b2, eps); return; }
   __shared__ float2 stab[kAdamTabLds];
