@@ -1131,6 +1131,7 @@ __device__ __forceinline__ void trunk_tile_bwd(const DecodeArgs& a, const Bwd2Ou
 // first n2 workgroups: double tiles, the rest single ones (trunk_plan, psl_decode_fwd2.hip)
 template <bool PTSG>
 __global__ __launch_bounds__(WG, 2) void k_trunk_bwd(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int n2, RayFuse rf, TrackFuse tf) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
   const int b = (int)blockIdx.x;
@@ -1390,6 +1391,7 @@ __device__ __forceinline__ void nbr_unit_bwd(const DecodeArgs& a, const Bwd2Out&
 template <bool PTSG, bool RELPOS>
 __global__ __launch_bounds__(NBR_WG_B, 3) void k_nbr_bwd(DecodeArgs a, Bwd2Out o, const float* __restrict__ WB, int geo_blocks, int n_units,
                                                         AdamWorklist wl, int wl_block0) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = (int)blockIdx.x;
   if (b >= wl_block0) {

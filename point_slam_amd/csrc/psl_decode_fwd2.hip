@@ -594,6 +594,7 @@ __device__ __forceinline__ void nbr_unit_fwd(const DecodeArgs& a, const float* _
 // grid: [0, geo_blocks) four one-wave geometry tiles each (the longest units start first), then four F_theta units each
 template <bool RELPOS>
 __global__ __launch_bounds__(NBR_WG, 3) void k_nbr_fwd(DecodeArgs a, const float* __restrict__ WF, int geo_blocks, int n_units) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   if (a.zero64 && blockIdx.x == 0 && threadIdx.x < 64) a.zero64[threadIdx.x] = 0.f;   // accumulators of the backward that follows
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
@@ -797,6 +798,7 @@ TrunkPlan trunk_plan(int tiles) {      // tiles = 16-sample sub-tiles of the lau
   return TrunkPlan{tiles / 2, tiles & 1};                             // throughput regime: double tiles throughout
 }
 __global__ __launch_bounds__(WG, 2) void k_trunk_fwd(DecodeArgs a, const float* __restrict__ WF, int n2) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BlkTrace bt(a);
   const int b = (int)blockIdx.x;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void k_map_ray_fused(const float4* __restrict_
                                                        float* __restrict__ zero64, const float* __restrict__ frame_affine,
                                                        int pix_per_frame, float* __restrict__ g_frame_affine, AdamWorklist wl,
                                                        int nb_ray) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   if ((int)blockIdx.x >= nb_ray) { adam_worklist_role(wl, ((int)blockIdx.x - nb_ray) * (int)blockDim.x + (int)threadIdx.x); return; }
   // frame_affine != null (ScanNet, colour stage): the decoder returned raw colour logits; the affine of the ray's window
   // frame (slot r / pix_per_frame) and the sigmoid are applied to the COMPOSITED logits here (Mapper.py:530-548), and

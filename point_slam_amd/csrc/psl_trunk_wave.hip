@@ -163,6 +163,7 @@ __device__ __forceinline__ void wave_trunk_fwd(const DecodeArgs& a, const float*
 }
 
 __global__ __launch_bounds__(256, 3) void k_trunk_fwd_w(DecodeArgs a, const float* __restrict__ WF, int tiles) {
+  __builtin_amdgcn_s_setprio(1);      // above the side-stream k-NN prefetch (see k_decode_fwd2)
   BlkTrace bt(a);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int tile = (int)blockIdx.x * 4 + wave;
